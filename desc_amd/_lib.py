@@ -1,0 +1,281 @@
+"""ctypes binding of libdesc_amd.so -- the C ABI declared in include/desc_amd.h.
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is
+visible when a solver handle is created, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdesc_amd.so")
+
+DESC_OK = 0
+STEP_CONSTANT, STEP_PIECEWISE, STEP_HYBRID = 0, 1, 2
+BUILD_HOST, BUILD_DEVICE = 0, 1
+
+# every symbol include/desc_amd.h declares (tests check that the library exports them)
+EXPORTS = [
+    "desc_last_error", "desc_version", "desc_device_count",
+    "desc_structure_build", "desc_structure_import", "desc_structure_get", "desc_structure_free",
+    "desc_sample_key", "desc_params_default",
+    "desc_pgd_create", "desc_pgd_destroy", "desc_pgd_run", "desc_pgd_reset", "desc_pgd_iterate",
+    "desc_pgd_iterate_timed", "desc_pgd_sync", "desc_pgd_download", "desc_pgd_get_s0",
+    "desc_pgd_sizes", "desc_pgd_kernel_name", "desc_pgd_solve", "desc_selftest_group_sum",
+]
+
+I32P = C.POINTER(C.c_int32)
+I64P = C.POINTER(C.c_int64)
+F64P = C.POINTER(C.c_double)
+
+
+class Problem(C.Structure):
+    _fields_ = [("n", C.c_int64), ("m", C.c_int64), ("ind_i", I32P), ("ind_j", I32P), ("rij", F64P)]
+
+
+class StructureView(C.Structure):
+    _fields_ = [("n", C.c_int64), ("m", C.c_int64), ("m_pos", C.c_int64), ("m_cycle", C.c_int64),
+                ("n_sample", C.c_int32), ("max_cnt", C.c_int32),
+                ("codeg", I32P), ("pos_edge", I32P), ("cum_ind", I64P),
+                ("k", I32P), ("e_jk", I32P), ("e_ki", I32P), ("ikj", I32P), ("jki", I32P)]
+
+
+class Params(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("step_kind", C.c_int32), ("lr", C.c_double),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("decay_interval", C.c_double),
+                ("hybrid_strategy", C.c_int32), ("t0", C.c_int32), ("patience", C.c_int32),
+                ("stop_tol", C.c_double), ("n_sample_min", C.c_int32), ("seed", C.c_uint64),
+                ("verbose", C.c_int32), ("device", C.c_int32), ("build_where", C.c_int32),
+                ("check_every", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("s_vec", F64P), ("obj_trace", F64P), ("avg_change_trace", F64P), ("w", F64P),
+                ("adam_m", F64P), ("adam_v", F64P), ("iters_run", C.c_int32), ("t_end", C.c_int32),
+                ("ms_structure", C.c_double), ("ms_upload", C.c_double), ("ms_cycle_d", C.c_double),
+                ("ms_pgd", C.c_double), ("ms_total", C.c_double)]
+
+
+class DescError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libdesc_amd.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DescError(
+            f"{LIB_PATH} is missing: build it with `python -m desc_amd.build` (hipcc, gfx950). "
+            "The DESC_PGD hot path has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.desc_last_error.restype = C.c_char_p
+    L.desc_version.restype = C.c_char_p
+    L.desc_pgd_kernel_name.restype = C.c_char_p
+    L.desc_pgd_kernel_name.argtypes = [C.c_void_p]
+    L.desc_sample_key.restype = C.c_uint64
+    L.desc_sample_key.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+    L.desc_params_default.argtypes = [C.POINTER(Params)]
+    L.desc_params_default.restype = None
+    L.desc_structure_build.argtypes = [C.POINTER(Problem), C.c_int32, C.c_uint64, C.c_int32, C.c_int32,
+                                       C.POINTER(C.c_void_p)]
+    L.desc_structure_import.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int32, I32P, I64P, I32P, I32P,
+                                        I32P, I32P, I32P, C.POINTER(C.c_void_p)]
+    L.desc_structure_get.argtypes = [C.c_void_p, C.POINTER(StructureView)]
+    L.desc_structure_free.argtypes = [C.c_void_p]
+    L.desc_structure_free.restype = None
+    L.desc_pgd_create.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+    L.desc_pgd_destroy.argtypes = [C.c_void_p]
+    L.desc_pgd_destroy.restype = None
+    L.desc_pgd_run.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Result)]
+    L.desc_pgd_reset.argtypes = [C.c_void_p, C.POINTER(Params)]
+    L.desc_pgd_iterate.argtypes = [C.c_void_p, C.c_int32]
+    L.desc_pgd_iterate_timed.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.desc_pgd_sync.argtypes = [C.c_void_p]
+    L.desc_pgd_download.argtypes = [C.c_void_p, C.POINTER(Result)]
+    L.desc_pgd_get_s0.argtypes = [C.c_void_p, F64P]
+    L.desc_pgd_sizes.argtypes = [C.c_void_p, I64P, I64P, I64P, I32P]
+    L.desc_pgd_solve.argtypes = [C.POINTER(Problem), C.POINTER(Params), C.POINTER(Result)]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != DESC_OK:
+        raise DescError(f"desc_amd error {rc}: {load().desc_last_error().decode()}")
+
+
+def ptr(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def default_params():
+    p = Params()
+    load().desc_params_default(C.byref(p))
+    return p
+
+
+class ProblemArrays:
+    """Keeps the NumPy buffers behind a desc_problem alive."""
+
+    def __init__(self, n, ind_i, ind_j, rij=None):
+        self.ind_i = np.ascontiguousarray(ind_i, dtype=np.int32)
+        self.ind_j = np.ascontiguousarray(ind_j, dtype=np.int32)
+        self.rij = None if rij is None else np.ascontiguousarray(rij, dtype=np.float64).reshape(-1)
+        m = self.ind_i.shape[0]
+        if self.rij is not None and self.rij.shape[0] != 9 * m:
+            raise ValueError("rij must hold m*9 doubles")
+        self.c = Problem(int(n), m, ptr(self.ind_i, I32P), ptr(self.ind_j, I32P), ptr(self.rij, F64P))
+
+
+def _view_arrays(v: StructureView):
+    def arr(p, count, dt):
+        if count == 0:
+            return np.zeros(0, dtype=dt)
+        return np.ctypeslib.as_array(p, shape=(count,)).copy()
+
+    return dict(n=v.n, m=v.m, m_pos=v.m_pos, m_cycle=v.m_cycle, n_sample=v.n_sample, max_cnt=v.max_cnt,
+                codeg=arr(v.codeg, v.m, np.int32), pos_edge=arr(v.pos_edge, v.m_pos, np.int32),
+                cum_ind=arr(v.cum_ind, v.m_pos + 1, np.int64), k=arr(v.k, v.m_cycle, np.int32),
+                e_jk=arr(v.e_jk, v.m_cycle, np.int32), e_ki=arr(v.e_ki, v.m_cycle, np.int32),
+                ikj=arr(v.ikj, v.m_cycle, np.int32), jki=arr(v.jki, v.m_cycle, np.int32))
+
+
+class Structure:
+    """Owner of a desc_structure*."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    @classmethod
+    def build(cls, prob: ProblemArrays, n_sample_min=30, seed=0, where=BUILD_HOST, device=0):
+        h = C.c_void_p()
+        check(load().desc_structure_build(C.byref(prob.c), n_sample_min, seed, where, device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, n, m, n_sample, pos_edge, cum_ind, k, e_jk, e_ki, ikj, jki):
+        a = [np.ascontiguousarray(x, dtype=np.int32) for x in (pos_edge, k, e_jk, e_ki, ikj, jki)]
+        cum = np.ascontiguousarray(cum_ind, dtype=np.int64)
+        h = C.c_void_p()
+        check(load().desc_structure_import(int(n), int(m), a[0].shape[0], int(n_sample), ptr(a[0], I32P),
+                                           ptr(cum, I64P), ptr(a[1], I32P), ptr(a[2], I32P), ptr(a[3], I32P),
+                                           ptr(a[4], I32P), ptr(a[5], I32P), C.byref(h)))
+        return cls(h)
+
+    def arrays(self):
+        v = StructureView()
+        check(load().desc_structure_get(self.handle, C.byref(v)))
+        return _view_arrays(v)
+
+    def sizes(self):
+        v = StructureView()
+        check(load().desc_structure_get(self.handle, C.byref(v)))
+        return dict(n=v.n, m=v.m, m_pos=v.m_pos, m_cycle=v.m_cycle, n_sample=v.n_sample, max_cnt=v.max_cnt)
+
+    def free(self):
+        if self.handle:
+            load().desc_structure_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Solver:
+    """Owner of a desc_pgd* (problem + structure resident in HBM)."""
+
+    def __init__(self, prob: ProblemArrays, structure: Structure, device=0):
+        h = C.c_void_p()
+        check(load().desc_pgd_create(C.byref(prob.c), structure.handle, device, C.byref(h)))
+        self.handle = h
+        m, mp, mc, mx = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        check(load().desc_pgd_sizes(h, C.byref(m), C.byref(mp), C.byref(mc), C.byref(mx)))
+        self.m, self.m_pos, self.m_cycle, self.max_cnt = m.value, mp.value, mc.value, mx.value
+
+    def kernel_name(self):
+        return load().desc_pgd_kernel_name(self.handle).decode()
+
+    def s0(self):
+        out = np.zeros(max(self.m_cycle, 1))
+        check(load().desc_pgd_get_s0(self.handle, ptr(out, F64P)))
+        return out[:self.m_cycle]
+
+    def _result(self, iters, want_w=False, adam=None):
+        bufs = dict(s_vec=np.zeros(max(self.m, 1)), obj=np.zeros(max(iters, 1)), avg=np.zeros(max(iters, 1)))
+        r = Result()
+        r.s_vec = ptr(bufs["s_vec"], F64P)
+        r.obj_trace = ptr(bufs["obj"], F64P)
+        r.avg_change_trace = ptr(bufs["avg"], F64P)
+        if want_w:
+            bufs["w"] = np.zeros(max(self.m_cycle, 1))
+            r.w = ptr(bufs["w"], F64P)
+        if adam is not None:
+            bufs["adam_m"], bufs["adam_v"] = adam
+            r.adam_m = ptr(bufs["adam_m"], F64P)
+            r.adam_v = ptr(bufs["adam_v"], F64P)
+        return r, bufs
+
+    def _pack(self, r, bufs):
+        it = r.iters_run
+        out = dict(S_vec=bufs["s_vec"][:self.m], obj=bufs["obj"][:it], avg=bufs["avg"][:it], iters_run=it,
+                   t_end=r.t_end, ms_upload=r.ms_upload, ms_cycle_d=r.ms_cycle_d, ms_pgd=r.ms_pgd,
+                   ms_total=r.ms_total, ms_structure=r.ms_structure)
+        if "w" in bufs:
+            out["w"] = bufs["w"][:self.m_cycle]
+        if "adam_m" in bufs:
+            out["adam_m"], out["adam_v"] = bufs["adam_m"], bufs["adam_v"]
+        return out
+
+    def run(self, params: Params, want_w=False, adam=None):
+        r, bufs = self._result(params.iters, want_w, adam)
+        check(load().desc_pgd_run(self.handle, C.byref(params), C.byref(r)))
+        return self._pack(r, bufs)
+
+    def reset(self, params: Params):
+        self._iters_cap = params.iters
+        check(load().desc_pgd_reset(self.handle, C.byref(params)))
+
+    def iterate(self, n):
+        check(load().desc_pgd_iterate(self.handle, n))
+
+    def iterate_timed(self, n, per_kernel=False):
+        ms, mk = C.c_float(), C.c_float()
+        check(load().desc_pgd_iterate_timed(self.handle, n, C.byref(ms), C.byref(mk) if per_kernel else None))
+        return ms.value, (mk.value if per_kernel else None)
+
+    def sync(self):
+        check(load().desc_pgd_sync(self.handle))
+
+    def download(self, want_w=False):
+        r, bufs = self._result(getattr(self, "_iters_cap", 1), want_w)
+        check(load().desc_pgd_download(self.handle, C.byref(r)))
+        return self._pack(r, bufs)
+
+    def destroy(self):
+        if self.handle:
+            load().desc_pgd_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def device_count():
+    rc = load().desc_device_count()
+    if rc < 0:
+        raise DescError(load().desc_last_error().decode())
+    return rc

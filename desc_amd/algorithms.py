@@ -1,0 +1,181 @@
+"""Host-side mirror of the reference's solver entry points.
+
+The reference is MATLAB and no MATLAB/Octave/MEX toolchain exists in the build
+environment, so the host layer above the C ABI is written in Python with the
+reference's names, argument meaning and conventions:
+
+    S_vec = DESC_PGD(Ind, RijMat, params)        Algorithms/DESC_PGD.m:14
+
+``Ind`` is ``m x 2`` with 1-based node ids ``i<j``; ``RijMat`` is ``3 x 3 x m``;
+``params`` is a struct-like object (attributes or dict keys) with the fields the
+reference reads: ``iters`` (:170), ``Gradient`` (:207), ``make_plots`` (:235) and,
+when plotting, ``ErrVec`` / ``R_orig`` (:236-238).  ``learning_rate`` is accepted
+and ignored, as in the reference (:169 is commented out).  Optional fields that do
+not exist in the reference: ``seed`` (cycle-sampling seed; MATLAB uses its global
+RNG), ``device``, ``verbose``, ``build_where``.
+
+All numerical work of the hot path happens in libdesc_amd.so on the GPU; this file
+only marshals arguments.  MATLAB wrappers with the same signatures and the MEX shim
+over the same ABI are in matlab/.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from .stepsize import ConstantStepSize, HybridGradient, PiecewiseStepSize
+
+
+def _get(params, name, default=None):
+    if isinstance(params, dict):
+        return params.get(name, default)
+    return getattr(params, name, default)
+
+
+def _set(params, name, value):
+    if isinstance(params, dict):
+        params[name] = value
+    else:
+        try:
+            setattr(params, name, value)
+        except Exception:
+            pass
+
+
+def marshal_edges(Ind, RijMat=None):
+    """MATLAB arrays -> C-ABI arrays.
+
+    Returns (n, ind_i, ind_j, rij, perm): 0-based int32 endpoints sorted by (i,j),
+    rij as an (m*9,) float64 buffer in the reference's memory order
+    (element (r,c,l) at 9*l + r + 3*c), and ``perm`` such that row ``perm[t]`` of the
+    caller's ``Ind`` is the t-th sorted edge (``None`` when already sorted).  The
+    reference silently requires sorted input (DESC_PGD.m:5,31-34); unsorted input is
+    sorted here and outputs are returned in the caller's order."""
+    Ind = np.asarray(Ind)
+    if Ind.ndim != 2 or Ind.shape[1] != 2:
+        raise ValueError("Ind must be m x 2")
+    m = Ind.shape[0]
+    Ii = Ind[:, 0].astype(np.int64)
+    Ij = Ind[:, 1].astype(np.int64)
+    if m and (np.any(Ii != Ind[:, 0]) or np.any(Ij != Ind[:, 1])):
+        raise ValueError("Ind must hold integer node ids")
+    if m and (Ii.min() < 1 or np.any(Ii >= Ij)):
+        raise ValueError("Ind rows must be 1-based with Ind(:,1) < Ind(:,2)")
+    n = int(Ind.max()) if m else 0                                # DESC_PGD.m:21
+    perm = None
+    if m > 1:
+        key = Ii * (n + 1) + Ij
+        if np.any(key[1:] <= key[:-1]):
+            perm = np.lexsort((Ij, Ii))
+            if np.any(np.diff(key[perm]) == 0):
+                raise ValueError("Ind lists an edge twice")
+            Ii, Ij = Ii[perm], Ij[perm]
+    rij = None
+    if RijMat is not None:
+        R = np.asarray(RijMat, dtype=np.float64)
+        if R.shape != (3, 3, m):
+            raise ValueError("RijMat must be 3 x 3 x m")
+        if perm is not None:
+            R = R[:, :, perm]
+        # MATLAB memory order of a 3x3xm array: r + 3c + 9l
+        rij = np.ascontiguousarray(np.transpose(R, (2, 1, 0))).reshape(-1)
+    return n, (Ii - 1).astype(np.int32), (Ij - 1).astype(np.int32), rij, perm
+
+
+def gradient_to_params(G, p: _lib.Params):
+    """Translate a params.Gradient plugin object into the flat C struct."""
+    if isinstance(G, ConstantStepSize):
+        p.step_kind = _lib.STEP_CONSTANT
+        p.lr = G.learning_rate
+        p.t0 = 0
+    elif isinstance(G, PiecewiseStepSize):
+        p.step_kind = _lib.STEP_PIECEWISE
+        p.lr = G.learning_rate
+        p.decay_interval = float(G.decay_interval)
+        p.t0 = int(G.t)
+    elif isinstance(G, HybridGradient):
+        p.step_kind = _lib.STEP_HYBRID
+        p.lr = G.lr
+        p.beta1, p.beta2 = G.beta_1, G.beta_2
+        p.decay_interval = float(G.decay_interval)
+        p.hybrid_strategy = int(G.strategy)
+        p.t0 = int(G.t)
+    else:
+        raise TypeError("params.Gradient must be a ConstantStepSize, PiecewiseStepSize or HybridGradient "
+                        "object (Utils/*.m); arbitrary GetStep callbacks cannot run inside the HIP sweep")
+
+
+def make_c_params(params):
+    p = _lib.default_params()
+    iters = _get(params, "iters")
+    if iters is None:
+        raise ValueError("params.iters is required (DESC_PGD.m:170)")
+    p.iters = int(iters)
+    G = _get(params, "Gradient")
+    if G is None:
+        raise ValueError("params.Gradient is required (DESC_PGD.m:207)")
+    gradient_to_params(G, p)
+    p.seed = int(_get(params, "seed", 0))
+    p.device = int(_get(params, "device", 0))
+    p.verbose = 1 if _get(params, "verbose", True) else 0
+    p.build_where = int(_get(params, "build_where", _lib.BUILD_HOST))
+    return p, G
+
+
+def DESC_PGD(Ind, RijMat, params, return_info=False):
+    """[S_vec] = DESC_PGD(Ind, RijMat, params) -- Algorithms/DESC_PGD.m:14.
+
+    Returns the estimated corruption level of every edge (length-m vector in the
+    caller's edge order).  With ``return_info`` also a dict with the objective and
+    average-change traces, iteration count, timings and structure sizes."""
+    p, G = make_c_params(params)
+    if _get(params, "make_plots", False):
+        raise NotImplementedError(
+            "params.make_plots=true (per-iteration GCW + alignment, DESC_PGD.m:235-239) is outside the "
+            "accelerated hot path; run with make_plots=false")
+    n, ii, jj, rij, perm = marshal_edges(Ind, RijMat)
+    m = ii.shape[0]
+    if m == 0:
+        raise ValueError("empty edge list")
+    prob = _lib.ProblemArrays(n, ii, jj, rij)
+    verbose = bool(p.verbose)
+    st = _lib.Structure.build(prob, p.n_sample_min, p.seed, p.build_where, p.device)
+    try:
+        solver = _lib.Solver(prob, st, p.device)
+        sizes = st.sizes()
+        ms_structure = 0.0
+    finally:
+        st.free()
+    try:
+        if verbose:
+            print("compute R cycle")                      # DESC_PGD.m:132
+            print("S0Mat")                                # :145
+            print("Initialization completed!")            # :160
+            print("Reweighting Procedure Started ...")    # :162
+        adam = None
+        if isinstance(G, HybridGradient) and G.strategy == 0:
+            mt = G.m_t if (G.t > 0 and G.m_t is not None) else np.zeros(solver.m_cycle)
+            vt = G.v_t if (G.t > 0 and G.v_t is not None) else np.zeros(solver.m_cycle)
+            if mt.shape[0] != solver.m_cycle:
+                raise ValueError("HybridGradient state has a different length than this problem's cycle vector")
+            adam = (np.ascontiguousarray(mt, dtype=np.float64).copy(), np.ascontiguousarray(vt, dtype=np.float64).copy())
+        out = solver.run(p, adam=adam)
+    finally:
+        solver.destroy()
+    # plugin state after the run (handle-object semantics)
+    if isinstance(G, (PiecewiseStepSize, HybridGradient)):
+        G.t = int(out["t_end"])
+    if adam is not None:
+        G.m_t, G.v_t = out["adam_m"], out["adam_v"]
+    S_sorted = out["S_vec"]
+    if perm is not None:
+        S_vec = np.empty_like(S_sorted)
+        S_vec[perm] = S_sorted
+    else:
+        S_vec = S_sorted
+    if return_info:
+        info = dict(out)
+        info.update(sizes)
+        info["ms_structure"] = ms_structure
+        return S_vec, info
+    return S_vec

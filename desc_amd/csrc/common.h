@@ -1,0 +1,49 @@
+// Internal declarations shared by the host-side translation units of libdesc_amd.so.
+#pragma once
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "desc_amd.h"
+
+namespace desc {
+
+// thread-local error text behind desc_last_error()
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+// splitmix64 finaliser; the sampling key is defined on top of it (see desc_sample_key)
+inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+inline uint64_t sample_key(uint64_t seed, uint64_t edge, uint64_t k) {
+    uint64_t a = mix64(seed ^ ((edge + 1) * 0x9E3779B97F4A7C15ull));
+    return mix64(a ^ ((k + 1) * 0xD1B54A32D192ED03ull));
+}
+
+}  // namespace desc
+
+// The sampled 3-cycle structure (DESC_PGD.m:29-127) in host memory.
+struct desc_structure {
+    int64_t n = 0, m = 0, m_pos = 0, m_cycle = 0;
+    int32_t n_sample = 0, max_cnt = 0;
+    std::vector<int32_t> codeg, pos_edge;
+    std::vector<int64_t> cum_ind;
+    std::vector<int32_t> k, e_jk, e_ki, ikj, jki;
+    double ms_build = 0.0;
+};
+
+namespace desc {
+// a-1..a-3 on the host (structure_host.cpp)
+int build_structure_host(const desc_problem* prob, int32_t n_sample_min, uint64_t seed,
+                         desc_structure* out);
+// a-1..a-3 on the device (structure_device.hip)
+int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint64_t seed,
+                           int32_t device, desc_structure* out);
+int validate_problem(const desc_problem* prob, bool need_rij);
+}  // namespace desc

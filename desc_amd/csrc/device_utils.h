@@ -1,0 +1,74 @@
+// Device-side helpers for gfx950 (wave64): group reductions by DPP / permlane-swap,
+// XCD-aware block remap, HIP error plumbing.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+#define DESC_HIP(call)                                                                        \
+    do {                                                                                      \
+        hipError_t _e = (call);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return desc::fail(DESC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), \
+                              __FILE__, __LINE__);                                            \
+    } while (0)
+
+namespace desc {
+
+// One DPP-moved copy of a double (two 32-bit v_mov_b32_dpp).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// v_permlane16_swap: exchanges the odd 16-lane rows of the first operand with the
+// even rows of the second; with both operands = v the two results are
+// [r0,r0,r2,r2] and [r1,r1,r3,r3], whose sum is the xor-16 butterfly.
+__device__ __forceinline__ double swap16_sum_f64(double v) {
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+// v_permlane32_swap: exchanges the upper half of the first operand with the lower
+// half of the second -> [lo,lo] and [hi,hi]; sum = xor-32 butterfly.
+__device__ __forceinline__ double swap32_sum_f64(double v) {
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
+// Sum over aligned groups of G lanes (G = 16, 32 or 64); every lane of a group
+// receives its group's total.  Fixed butterfly order -> bitwise reproducible.
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+    static_assert(G == 16 || G == 32 || G == 64, "group width");
+    v += dpp_mov_f64<0xB1>(v);    // quad_perm:[1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);    // quad_perm:[2,3,0,1]
+    v += dpp_mov_f64<0x141>(v);   // row_half_mirror
+    v += dpp_mov_f64<0x140>(v);   // row_mirror
+    if (G >= 32) v = swap16_sum_f64(v);
+    if (G >= 64) v = swap32_sum_f64(v);
+    return v;
+}
+
+// number of set predicate lanes in this lane's group of G
+template <int G>
+__device__ __forceinline__ int group_count(bool pred, int lane) {
+    unsigned long long mk = __ballot(pred);
+    if (G == 64) return __popcll(mk);
+    unsigned long long sub = (mk >> ((lane / G) * G)) & ((1ull << G) - 1ull);
+    return __popcll(sub);
+}
+
+// Blocks b and b+8 share an XCD (round-robin dispatch, observed; speed only).
+// Give each XCD a contiguous range of logical blocks so neighbouring edge
+// segments -- which gather each other's cycle weights -- share one L2.
+__device__ __forceinline__ int xcd_logical_block(int b, int nb) {
+    return (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+}
+
+}  // namespace desc

@@ -1,0 +1,168 @@
+/* desc_amd.h -- C ABI of libdesc_amd.so (MI355X / gfx950 HIP implementation of the
+ * DESC projected-gradient hot path).
+ *
+ * The reference (ColeWyeth/DESC) is pure MATLAB and has no FFI of its own; the
+ * boundary this library replaces is the MATLAB function signature
+ *     S_vec = DESC_PGD(Ind, RijMat, params)            Algorithms/DESC_PGD.m:14
+ * (the same body is inlined in Algorithms/DESC.m:16-261, called from
+ * Demo/compare_algorithms.m:72).  A MEX shim (matlab/desc_pgd_mex.c) or any other
+ * FFI (ctypes: desc_amd/_lib.py) binds exactly the entry points below.  Plain
+ * pointers and sizes only; no exceptions cross the boundary; every function
+ * returns DESC_OK (0) or a negative error code, with text from desc_last_error().
+ *
+ * Conventions
+ *   - all indices are 0-based int32 (the MATLAB side subtracts 1);
+ *   - edges are rows (ind_i[l], ind_j[l]) with ind_i < ind_j, strictly sorted by
+ *     (ind_i, ind_j) -- the order DESC_PGD.m:5,31-34 silently relies on;
+ *   - rij is m x 9 doubles, block l = RijMat(:,:,l) in MATLAB column-major order
+ *     (element (r,c) at rij[9*l + r + 3*c]), i.e. mxGetDoubles(RijMat) unchanged;
+ *   - all arithmetic is IEEE double (the reference has no single precision).
+ *   - the caller owns every host buffer it passes; the library owns device memory.
+ */
+#ifndef DESC_AMD_H
+#define DESC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DESC_OK              0
+#define DESC_ERR_INVALID    -1   /* bad argument / unsorted Ind / out-of-range index     */
+#define DESC_ERR_HIP        -2   /* HIP runtime error (no device, OOM, launch failure)   */
+#define DESC_ERR_TOO_LARGE  -3   /* m_cycle or m exceeds the 2^31-1 / 2^30 index budget  */
+#define DESC_ERR_STATE      -4   /* call order violated (e.g. iterate before reset)      */
+
+/* step-size plugin kinds: params.Gradient of the reference (DESC_PGD.m:207) */
+#define DESC_STEP_CONSTANT   0   /* Utils/ConstantStepSize.m:9-11   step = -lr*g                       */
+#define DESC_STEP_PIECEWISE  1   /* Utils/PiecewiseStepSize.m:13-18 step = -lr/(fix(t/decay)+1)*g      */
+#define DESC_STEP_HYBRID     2   /* Utils/HybridGradient.m:23-41    Adam, or 100*lr/(fix(t/decay)+1)   */
+
+/* where a-1..a-3 (graph, codegree, sampling, mirror maps) are built */
+#define DESC_BUILD_HOST      0
+#define DESC_BUILD_DEVICE    1
+
+const char* desc_last_error(void);
+const char* desc_version(void);
+/* number of visible HIP devices, or a negative error code */
+int desc_device_count(void);
+
+/* ---------------------------------------------------------------- problem -- */
+typedef struct desc_problem {
+    int64_t n;              /* number of nodes = max(Ind(:))            DESC_PGD.m:21 */
+    int64_t m;              /* number of edges                          DESC_PGD.m:22 */
+    const int32_t* ind_i;   /* m, 0-based, ind_i[l] < ind_j[l]          DESC_PGD.m:19 */
+    const int32_t* ind_j;   /* m                                        DESC_PGD.m:20 */
+    const double* rij;      /* m*9, may be NULL for structure-only calls  DESC_PGD.m:7 */
+} desc_problem;
+
+/* -------------------------------------------------------------- structure -- */
+/* The sampled 3-cycle structure of DESC_PGD.m:29-127, sparse.  Cycle c of the
+ * l-th edge-with-cycles (edge id pos_edge[l] = (i,j)) lives at
+ * cum_ind[l] <= c < cum_ind[l+1] and has third vertex k[c]; inside a segment the
+ * k are ascending. */
+typedef struct desc_structure desc_structure;   /* opaque, library-owned */
+
+typedef struct desc_structure_view {
+    int64_t n, m;
+    int64_t m_pos;            /* edges with >=1 triangle                       DESC_PGD.m:50 */
+    int64_t m_cycle;          /* sampled cycles in total                       DESC_PGD.m:51 */
+    int32_t n_sample;         /* max(ceil(median(codeg>0)/4), n_sample_min)    DESC_PGD.m:43 */
+    int32_t max_cnt;          /* longest segment                                             */
+    const int32_t* codeg;     /* m      codegree of every edge (0 = no triangle) DESC_PGD.m:29-40 */
+    const int32_t* pos_edge;  /* m_pos  CoDeg_pos_ind (0-based edge ids)       DESC_PGD.m:36 */
+    const int64_t* cum_ind;   /* m_pos+1                                       DESC_PGD.m:49 */
+    const int32_t* k;         /* m_cycle  IJK                                  DESC_PGD.m:93 */
+    const int32_t* e_jk;      /* m_cycle  Ind_jk: edge id of {j,k}             DESC_PGD.m:87 */
+    const int32_t* e_ki;      /* m_cycle  Ind_ki: edge id of {k,i}             DESC_PGD.m:88 */
+    const int32_t* ikj;       /* m_cycle  IKJ: cycle (ik;j), -1 if not sampled DESC_PGD.m:116 */
+    const int32_t* jki;       /* m_cycle  JKI: cycle (jk;i), -1 if not sampled DESC_PGD.m:125 */
+} desc_structure_view;
+
+/* Build the structure from the edge list.  `datasample` (DESC_PGD.m:84, MATLAB
+ * global RNG) is replaced by a counter-based keyed selection: an edge with
+ * codeg >= n_sample keeps the n_sample common neighbours k with the smallest
+ * desc_sample_key(seed, edge, k).  where = DESC_BUILD_HOST | DESC_BUILD_DEVICE. */
+int desc_structure_build(const desc_problem* prob, int32_t n_sample_min, uint64_t seed,
+                         int32_t where, int32_t device, desc_structure** out);
+/* Adopt a caller-supplied structure (oracle-parity runs; arrays are copied). */
+int desc_structure_import(int64_t n, int64_t m, int64_t m_pos, int32_t n_sample,
+                          const int32_t* pos_edge, const int64_t* cum_ind,
+                          const int32_t* k, const int32_t* e_jk, const int32_t* e_ki,
+                          const int32_t* ikj, const int32_t* jki, desc_structure** out);
+int desc_structure_get(const desc_structure* s, desc_structure_view* view);
+void desc_structure_free(desc_structure* s);
+uint64_t desc_sample_key(uint64_t seed, uint64_t edge, uint64_t k);
+
+/* ----------------------------------------------------------------- solver -- */
+typedef struct desc_params {
+    int32_t iters;            /* params.iters                                  DESC_PGD.m:170 */
+    int32_t step_kind;        /* DESC_STEP_*                                   DESC_PGD.m:207 */
+    double  lr;               /* learning_rate / lr property of the plugin                    */
+    double  beta1, beta2;     /* HybridGradient.beta_1/beta_2                                 */
+    double  decay_interval;   /* Piecewise/Hybrid decay_interval                              */
+    int32_t hybrid_strategy;  /* HybridGradient.strategy: 0 Adam, 1 decayed plain step        */
+    int32_t t0;               /* plugin counter t on entry (handle objects keep state)        */
+    int32_t patience;         /* 30                                            DESC_PGD.m:180 */
+    double  stop_tol;         /* 1e-5                                          DESC_PGD.m:243 */
+    int32_t n_sample_min;     /* 30                                            DESC_PGD.m:43  */
+    uint64_t seed;            /* sampling seed                                                */
+    int32_t verbose;          /* print the reference's progress lines          DESC_PGD.m:241 */
+    int32_t device;           /* HIP device ordinal                                           */
+    int32_t build_where;      /* DESC_BUILD_*  (one-shot desc_pgd_solve only)                 */
+    int32_t check_every;      /* host polls the device stop flag every this many iterations
+                                 (0 = library default); results do not depend on it           */
+} desc_params;
+void desc_params_default(desc_params* p);
+
+typedef struct desc_result {
+    double* s_vec;            /* m        out, caller-allocated: S_vec         DESC_PGD.m:229 */
+    double* obj_trace;        /* iters    out or NULL: obj_vals                DESC_PGD.m:233 */
+    double* avg_change_trace; /* iters    out or NULL: average_change          DESC_PGD.m:232 */
+    double* w;                /* m_cycle  out or NULL: wijk                    DESC_PGD.m:224 */
+    double* adam_m;           /* m_cycle  in/out or NULL: HybridGradient.m_t                  */
+    double* adam_v;           /* m_cycle  in/out or NULL: HybridGradient.v_t                  */
+    int32_t iters_run;        /* iterations executed (early stop, DESC_PGD.m:243-246)         */
+    int32_t t_end;            /* plugin counter after the run                                 */
+    /* timings, milliseconds */
+    double ms_structure;      /* a-1..a-3 build                                               */
+    double ms_upload;         /* host -> HBM                                                  */
+    double ms_cycle_d;        /* a-4 kernel                                                   */
+    double ms_pgd;            /* PGD loop, device time (HIP events)                           */
+    double ms_total;          /* wall clock of the call                                       */
+} desc_result;
+
+typedef struct desc_pgd desc_pgd;   /* opaque solver handle: one per (problem, device) */
+
+/* Upload problem + structure to HBM and evaluate the cycle inconsistencies
+ * S0_long (DESC_PGD.m:129-147).  The structure may be freed afterwards. */
+int desc_pgd_create(const desc_problem* prob, const desc_structure* s, int32_t device,
+                    desc_pgd** out);
+void desc_pgd_destroy(desc_pgd* h);
+/* Full run: init (DESC_PGD.m:148-167) + loop (:182-261) + download. */
+int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r);
+/* Pieces of desc_pgd_run, for benchmarks and the multi-GPU driver.  All work is
+ * enqueued on the handle's stream; _sync waits for it. */
+int desc_pgd_reset(desc_pgd* h, const desc_params* p);            /* :148-167                 */
+int desc_pgd_iterate(desc_pgd* h, int32_t n_iters);              /* enqueue n_iters sweeps   */
+int desc_pgd_iterate_timed(desc_pgd* h, int32_t n_iters, float* ms_total, float* ms_main_kernel_avg);
+int desc_pgd_sync(desc_pgd* h);
+int desc_pgd_download(desc_pgd* h, desc_result* r);              /* finishes objective trace */
+int desc_pgd_get_s0(desc_pgd* h, double* s0 /* m_cycle */);       /* S0_long                  */
+int desc_pgd_sizes(const desc_pgd* h, int64_t* m, int64_t* m_pos, int64_t* m_cycle, int32_t* max_cnt);
+/* name of the main-sweep kernel variant chosen for this handle (rocprof cross-reference) */
+const char* desc_pgd_kernel_name(const desc_pgd* h);
+
+/* One-shot: what the MEX shim calls.  Builds the structure (p->build_where),
+ * uploads, runs, downloads, frees. */
+int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* r);
+
+/* Test hook: sums `in` over aligned groups of G = 16/32/64 lanes with the kernels'
+ * DPP / permlane-swap reduction; every element of a group receives the group total. */
+int desc_selftest_group_sum(const double* in, double* out, int32_t count, int32_t G, int32_t device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DESC_AMD_H */

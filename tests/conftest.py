@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure).  Built on demand with gcc."""
+    from oracle import oracle as O
+    O.build()
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def lib():
+    """libdesc_amd.so.  Never rebuilt on the GPU box: the prebuilt .so travels with the tree."""
+    from desc_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build()
+    return _lib
