@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- DESC_PGD iterations/second on MI355X (BASELINE.json metric).
+
+A "step" is one PGD iteration (one sweep over all sampled 3-cycles: mirror sums,
+gradient, tangent projection, step, per-edge simplex projection, new S_vec) on a
+synthetic Uniform_Topology graph whose structure, rotations and cycle
+inconsistencies are already resident in HBM when the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W [--workload C1..C5]
+
+N = 1 runs BASELINE.json configs[1] (Uniform n=1000 p=0.5 q=0.3, sigma=0.1).
+Prints ONE JSON line (rank 0) with the contract's fields plus `roofline` (dominant
+kernel: the sweep, HBM-bound, algorithmic bytes 72*m_cycle + 12*m_pos per launch,
+SURVEY.md 8d) and `cpu_baseline` (the oracle's OpenMP C restatement timed on this
+host for a bounded number of iterations of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (generator kwargs, description)
+    "C1": dict(kind="uniform", n=200, p=0.5, q=0.2, sigma=0.1, model="uniform", seed=0),
+    "C2": dict(kind="uniform", n=1000, p=0.5, q=0.3, sigma=0.1, model="uniform", seed=1),
+    "C3": dict(kind="nonuniform", n=2000, p=0.2, p_node_crpt=0.5, p_edge_crpt=0.5, sigma_in=0.1, sigma_out=0.1,
+               crpt_type="self-consistent", seed=2),
+    "C4": dict(kind="uniform", n=5000, p=0.2, q=0.3, sigma=0.1, model="uniform", seed=3),
+    "C5": dict(kind="uniform", n=10000, p=0.1, q=0.3, sigma=0.1, model="uniform", seed=4),
+}
+HBM_PEAK_GBS = 8000.0     # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def describe(name):
+    w = WORKLOADS[name]
+    if w["kind"] == "uniform":
+        return (f"{name}: Uniform_Topology n={w['n']} p={w['p']} q={w['q']} sigma={w['sigma']} '{w['model']}' "
+                f"seed={w['seed']}; DESC_PGD ConstantStepSize(0.01)")
+    return (f"{name}: Nonuniform_Topology n={w['n']} p={w['p']} p_node_crpt={w['p_node_crpt']} "
+            f"p_edge_crpt={w['p_edge_crpt']} sigma_in={w['sigma_in']} sigma_out={w['sigma_out']} "
+            f"'{w['crpt_type']}' seed={w['seed']}; DESC_PGD ConstantStepSize(0.01)")
+
+
+def generate(name):
+    from desc_amd.algorithms import marshal_edges
+    from desc_amd.models import Nonuniform_Topology, Uniform_Topology
+    w = dict(WORKLOADS[name])
+    kind = w.pop("kind")
+    if kind == "uniform":
+        mo = Uniform_Topology(w["n"], w["p"], w["q"], w["sigma"], w["model"], seed=w["seed"])
+    else:
+        mo = Nonuniform_Topology(w["n"], w["p"], w["p_node_crpt"], w["p_edge_crpt"], w["sigma_in"], w["sigma_out"],
+                                 w["crpt_type"], seed=w["seed"])
+    nn, ii, jj, rij, perm = marshal_edges(mo.Ind, mo.RijMat)
+    return mo, nn, ii, jj, rij
+
+
+def cpu_baseline(nn, ii, jj, rij, arrays, budget_s=20.0, max_iters=50):
+    """Time the oracle's C/OpenMP restatement of the same sweep on this host."""
+    from oracle import oracle as O
+    O.build()
+    st = {k: arrays[k] for k in ("m", "m_pos", "m_cycle", "pos_edge", "cum_ind", "k", "e_jk", "e_ki", "ikj", "jki")}
+    S0 = O.cycle_d(ii, jj, rij.reshape(-1, 9), st)
+    t = time.perf_counter()
+    O.pgd_run(st, S0, 2, lr=0.01, patience=1 << 30)
+    per_iter = (time.perf_counter() - t) / 2
+    iters = int(max(2, min(max_iters, budget_s / max(per_iter, 1e-6))))
+    t = time.perf_counter()
+    ref = O.pgd_run(st, S0, iters, lr=0.01, patience=1 << 30)
+    dt = time.perf_counter() - t
+    return dict(value=iters / dt, unit="iters/s", cores=O.num_threads(), kind="port",
+                sample=f"{iters} PGD iterations of the same workload (oracle/desc_oracle.c, OpenMP)"), ref, iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0, help="cycle-sampling seed")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from desc_amd.sharded import bench_sharded
+        return bench_sharded(args, WORKLOADS, describe, generate, cpu_baseline)
+
+    from desc_amd import _lib
+    name = args.workload or "C2"
+    K, W = args.steps, args.warmup
+    t0 = time.perf_counter()
+    mo, nn, ii, jj, rij = generate(name)
+    t_gen = time.perf_counter() - t0
+    prob = _lib.ProblemArrays(nn, ii, jj, rij)
+    t0 = time.perf_counter()
+    st = _lib.Structure.build(prob, 30, args.seed, _lib.BUILD_HOST, 0)
+    t_struct = time.perf_counter() - t0
+    arrays = st.arrays()
+    t0 = time.perf_counter()
+    solver = _lib.Solver(prob, st, 0)
+    t_create = time.perf_counter() - t0
+    st.free()
+
+    p = _lib.default_params()
+    p.iters = W + 2 * K + 8
+    p.lr = 0.01
+    p.patience = (1 << 31) - 1          # the bench times exactly K sweeps: never stop early
+    p.seed = args.seed
+    solver.reset(p)
+    solver.iterate(W)
+    solver.sync()
+    # ---- timed region: exactly K steps, inputs resident in HBM ----
+    t0 = time.perf_counter()
+    solver.iterate(K)
+    solver.sync()
+    dt = time.perf_counter() - t0
+    # ---- roofline leg: the same K sweeps again, each sweep kernel bracketed by HIP events
+    #      on the launch stream (not part of `value`) ----
+    _, ms_kernel = solver.iterate_timed(K, per_kernel=True)
+    out = solver.download()
+    m_cycle, m_pos, m = solver.m_cycle, solver.m_pos, solver.m
+    kname = solver.kernel_name()
+    solver.destroy()
+
+    bytes_per_launch = 72.0 * m_cycle + 12.0 * m_pos
+    achieved = bytes_per_launch / (ms_kernel * 1e-3) / 1e9 if ms_kernel else 0.0
+    line = {
+        "metric": "DESC_PGD iters/sec", "value": K / dt, "unit": "iters/s", "n_gpus": 1, "steps": K, "warmup": W,
+        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": describe(name), "n": nn, "m": m, "m_pos": m_pos, "m_cycle": m_cycle,
+                   "n_sample": int(arrays["n_sample"]), "sampling_seed": args.seed, "parallelism": "1 GPU"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                     "bytes_per_launch": bytes_per_launch, "kernel_ms": ms_kernel},
+        "cycle_updates_per_s": m_cycle * K / dt,
+        "setup_ms": {"generate": t_gen * 1e3, "structure_host": t_struct * 1e3, "upload_and_cycle_d": t_create * 1e3},
+        "mean_abs_err_vs_truth": float(np.mean(np.abs(out["S_vec"] - mo.ErrVec))),
+    }
+    if not args.no_cpu_baseline:
+        cb, ref, it = cpu_baseline(nn, ii, jj, rij, arrays)
+        line["cpu_baseline"] = cb
+        line["gpu_over_cpu"] = line["value"] / cb["value"]
+    else:
+        line["cpu_baseline"] = None
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()
