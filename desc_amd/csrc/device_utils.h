@@ -60,8 +60,8 @@ template <int G>
 __device__ __forceinline__ int group_count(bool pred, int lane) {
     unsigned long long mk = __ballot(pred);
     if (G == 64) return __popcll(mk);
-    unsigned long long sub = (mk >> ((lane / G) * G)) & ((1ull << G) - 1ull);
-    return __popcll(sub);
+    constexpr unsigned long long field = (G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull);
+    return __popcll((mk >> ((lane / G) * G)) & field);
 }
 
 // Blocks b and b+8 share an XCD (round-robin dispatch, observed; speed only).

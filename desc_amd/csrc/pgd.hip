@@ -1,32 +1,49 @@
 // HIP kernels and solver handle for the DESC projected-gradient hot path on gfx950.
 //
 // Reference text reproduced (Algorithms/DESC_PGD.m, identical in DESC.m:16-261):
-//   k_cycle_d        :129-147  cycle inconsistency S0_long = |acos((tr(Rij Rjk Rki)-1)/2)|/pi
-//   k_init           :148-157  wijk = 1/cnt, S_vec = 1 / segment mean of S0
-//   k_sweep<G,STEP>  :185-230  mirror sums, gradient, tangent projection, plugin step
-//                              (Utils/ConstantStepSize.m:9-11, PiecewiseStepSize.m:13-18,
-//                              HybridGradient.m:23-41), simplex projection, new S_vec
-//   k_sweep_big<STEP>          the same for segments longer than 64 cycles
-//   k_objective      :233      obj = wijk*(S_vec(Ind_jk)'+S_vec(Ind_ki)')
-//   k_finalize       :232,243-257  average_change, early-stop bookkeeping (on device)
+//   :129-147  cycle inconsistency S0_long = |acos((tr(Rij Rjk Rki)-1)/2)|/pi
+//   :148-157  wijk = 1/cnt, S_vec = 1 / segment mean of S0
+//   :185-191  mirror-weight sums (scalar per edge, broadcast to masked positions)
+//   :193-207  gradient, tangent projection, plugin step (Utils/ConstantStepSize.m:9-11,
+//             PiecewiseStepSize.m:13-18, HybridGradient.m:23-41)
+//   :208-230  per-edge simplex projection, new S_vec
+//   :232-257  average_change, objective, early stop (evaluated on the device)
 //
-// Data layout in HBM (all struct-of-arrays, cycles of one edge contiguous, edges in
-// Ind order, third vertices ascending inside a segment):
-//   per cycle : e_jk,e_ki,ikj,jki int32; S0 f64; w[2] f64 (Jacobi double buffer)
-//   per edge  : S[2] f64 (double buffer), pos_edge int32, cum int32
-// One sweep moves 72 B per cycle: w r/w 16, S0 8, 4 index words 16,
-// 2 gathers of S 16, 2 gathers of w 16.  HBM-bound; no MFMA.
+// Two layouts of the same arithmetic (SWEEP VARIANTS):
 //
-// The objective of iteration t needs S_vec of *every* edge after iteration t, so it
+//  NODE (default).  Edges with cycles are stored band-major: nodes are cut into bands
+//  of B consecutive ids and the edges (i,j) of a band are ordered by (j,i), so that a
+//  run of consecutive segments shares j (its row of S stays in the CU's L1) while the
+//  band's i-rows stay in the XCD's L2.  S_vec is kept CSR-aligned (`Sfull`, every edge
+//  value stored in both endpoint rows) so S({j,k}) = Sfull[rowptr[j] + idx_j(k)] is a
+//  gather inside one contiguous row.  Per cycle one packed word holds idx_i(k), idx_j(k)
+//  and the two mirror-present bits (DESC_PGD.m:113,124).  The mirror sums are column
+//  sums of per-node weight matrices: T1(i,j) = sum_k w(ik;j) = column j of node i,
+//  T2(i,j) = column i of node j.  k_colsum_node streams every segment once per endpoint
+//  and accumulates the columns in LDS (per-wave private copies, fixed order ->
+//  bitwise reproducible); k_sweep_node then needs no gather of w at all.
+//    HBM traffic per cycle and iteration: sweep 28 B (w r/w 16, S0 8, packed word 4)
+//    + column sums 24 B (w 8 + packed word 4, per endpoint) = 52 B streamed, plus the
+//    row gathers of S served by L1/L2.
+//
+//  GATHER (fallback: max degree >= 32768, more LDS than a workgroup may hold, or
+//  segments longer than 64 cycles).  Natural edge order; per cycle e_jk, e_ki, ikj, jki
+//  and element-granular gathers S[e_jk], S[e_ki], w[ikj], w[jki]  (72 B per cycle as
+//  SURVEY.md 8d counts them).
+//
+// The objective of iteration t needs S_vec of every edge after iteration t, so it
 // cannot be fused into sweep t; it is accumulated for free inside sweep t+1 (which
-// gathers exactly those values) and once more by k_objective after the last sweep.
-// The early-stop test of iteration t is therefore evaluated on the device during
-// sweep t+1; when it fires, sweep t+1's output is discarded (the Jacobi double
+// gathers exactly those values) and once more by an objective kernel after the last
+// sweep.  The early-stop test of iteration t is therefore evaluated on the device
+// during sweep t+1; when it fires, sweep t+1's output is discarded (the Jacobi double
 // buffers still hold iteration t) and later launches return at once.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "device_utils.h"
@@ -40,6 +57,91 @@ struct DevState {
     int32_t final_parity;  // which double buffer holds the final iterate
 };
 
+struct StepArgs {
+    double* adam_m;
+    double* adam_v;
+    double step;                          // step size of this GetStep call
+    double lr, beta1, beta2, bc1, bc2;    // Adam (HybridGradient.m:28-35)
+};
+
+__device__ __forceinline__ double abs_acos_ext(double x) {
+    // MATLAB abs(acos(x)) with the complex extension outside [-1,1] (DESC_PGD.m:147)
+    if (x > 1.0) return acosh(x);
+    if (x < -1.0) return hypot(M_PI, acosh(-x));
+    return acos(x);
+}
+
+template <int STEP>
+__device__ __forceinline__ double apply_step(const StepArgs& a, double w, double g, int64_t c) {
+    if (STEP == DESC_STEP_HYBRID) {               // HybridGradient.m:28-35 (strategy 0)
+        double mt = (a.beta1 * a.adam_m[c]) + (1.0 - a.beta1) * g;
+        double vt = (a.beta2 * a.adam_v[c]) + (1.0 - a.beta2) * (g * g);
+        a.adam_m[c] = mt; a.adam_v[c] = vt;
+        double cm = mt / a.bc1, cv = vt / a.bc2;
+        return w + (-a.lr * cm / (sqrt(cv) + 1e-8));
+    }
+    return w + (-a.step * g);                     // ConstantStepSize.m:10 / PiecewiseStepSize.m:17
+}
+
+// Simplex projection threshold (DESC_PGD.m:215-223) for one segment held one value per
+// lane in a group of G lanes: T with sum(max(ws - T, 0)) = 1.  Michelot's fixed point
+// reaches the same active set as the reference's sort-and-scan (the first sorted i with
+// sum(w(i:end)-w(i)) < 1).
+template <int G>
+__device__ __forceinline__ double simplex_threshold(double ws, bool act0, int lane, bool single_pass) {
+    bool act = act0;
+    double T = 0.0;
+    for (;;) {
+        const double s = group_sum<G>(act ? ws : 0.0);
+        const int na = group_count<G>(act, lane);
+        T = (s - 1.0) / (double)max(na, 1);
+        const bool keep = act && (ws > T);
+        const bool changed = keep != act;
+        act = keep;
+        if (!__any(changed) || single_pass) break;
+    }
+    return T;
+}
+
+// product-of-three trace in the reference's accumulation order (DESC_PGD.m:137-146)
+__device__ __forceinline__ double cycle_trace(const double* A, const double* pb, bool tb, const double* pc, bool tc) {
+    double B[9], C[9];
+    for (int r = 0; r < 3; ++r)
+        for (int s = 0; s < 3; ++s) {
+            B[r + 3 * s] = tb ? pb[s + 3 * r] : pb[r + 3 * s];
+            C[r + 3 * s] = tc ? pc[s + 3 * r] : pc[r + 3 * s];
+        }
+    double tr = 0.0;
+    for (int r = 0; r < 3; ++r) {
+        double P[3];
+        for (int s = 0; s < 3; ++s) {
+            double acc = 0.0;
+            for (int u = 0; u < 3; ++u) acc = acc + A[r + 3 * u] * B[u + 3 * s];
+            P[s] = acc;
+        }
+        double acc = 0.0;
+        for (int u = 0; u < 3; ++u) acc = acc + P[u] * C[u + 3 * r];
+        tr = tr + acc;
+    }
+    return tr;
+}
+
+__device__ __forceinline__ void block_partials(double obj_acc, double chg_acc, double* partials, int lb) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    obj_acc = group_sum<64>(obj_acc);
+    chg_acc = group_sum<64>(chg_acc);
+    __shared__ double sh[8];
+    if (lane == 0) { sh[wv] = obj_acc; sh[4 + wv] = chg_acc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[2 * lb] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        partials[2 * lb + 1] = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+    }
+}
+
+// ===========================================================================
+// GATHER variant
+// ===========================================================================
 struct SweepArgs {
     const int32_t* cum;       // m_pos+1
     const int32_t* pos_edge;  // m_pos
@@ -52,38 +154,14 @@ struct SweepArgs {
     double* w_new;
     const double* S_old;
     double* S_new;
-    double* adam_m;
-    double* adam_v;
     const double* nv_tab;     // nv_tab[c] = 1/sqrt(c)   (DESC_PGD.m:199)
     double* partials;         // [grid][2]: objective of the old iterate, sum |dS|
     const DevState* state;
-    double step;              // step size of this call of GetStep
-    double lr, beta1, beta2, bc1, bc2;   // Adam
+    StepArgs st;
     int32_t m_pos;
+    int32_t ablate;           // diagnostics only (env DESC_DEBUG_ABLATE); 0 in production
 };
 
-__device__ __forceinline__ double abs_acos_ext(double x) {
-    // MATLAB abs(acos(x)) with the complex extension outside [-1,1] (DESC_PGD.m:147)
-    if (x > 1.0) return acosh(x);
-    if (x < -1.0) return hypot(M_PI, acosh(-x));
-    return acos(x);
-}
-
-template <int STEP>
-__device__ __forceinline__ double apply_step(const SweepArgs& a, double w, double g, int64_t c) {
-    if (STEP == DESC_STEP_HYBRID) {               // HybridGradient.m:28-35 (strategy 0)
-        double mt = (a.beta1 * a.adam_m[c]) + (1.0 - a.beta1) * g;
-        double vt = (a.beta2 * a.adam_v[c]) + (1.0 - a.beta2) * (g * g);
-        a.adam_m[c] = mt; a.adam_v[c] = vt;
-        double cm = mt / a.bc1, cv = vt / a.bc2;
-        return w + (-a.lr * cm / (sqrt(cv) + 1e-8));
-    }
-    return w + (-a.step * g);                     // ConstantStepSize.m:10 / PiecewiseStepSize.m:17
-}
-
-// ---------------------------------------------------------------------------
-// Main sweep: G lanes per edge segment (cnt <= G), 64/G segments per wave step.
-// ---------------------------------------------------------------------------
 template <int G, int STEP>
 __global__ __launch_bounds__(256) void k_sweep(SweepArgs a) {
     if (a.state->stop) return;
@@ -110,37 +188,24 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a) {
         int ia = -1, ib = -1;
         if (act0) {
             const int ejk = a.e_jk[c], eki = a.e_ki[c];
-            ia = a.ikj[c]; ib = a.jki[c];
+            if (!(a.ablate & 16)) { ia = a.ikj[c]; ib = a.jki[c]; }
             w = a.w_old[c]; d = a.S0[c];
-            ssum = a.S_old[ejk] + a.S_old[eki];
-            if (ia >= 0) wa = a.w_old[ia];
-            if (ib >= 0) wb = a.w_old[ib];
+            ssum = (a.ablate & 1) ? 1.0 + 1e-9 * (double)(ejk + eki) : a.S_old[ejk] + a.S_old[eki];
+            if (!(a.ablate & 2)) {
+                if (ia >= 0) wa = a.w_old[ia];
+                if (ib >= 0) wb = a.w_old[ib];
+            }
         }
-        // objective of the iterate being read (DESC_PGD.m:233, one sweep late)
-        obj_acc += w * ssum;
+        obj_acc += w * ssum;                       // objective of the iterate being read (:233, one sweep late)
         // mirror-weight sums: one scalar per edge, applied to masked positions only (:189-190)
-        const double T1 = group_sum<G>(wa), T2 = group_sum<G>(wb);
+        const double T1 = (a.ablate & 8) ? wa : group_sum<G>(wa), T2 = (a.ablate & 8) ? wb : group_sum<G>(wb);
         double g = ssum + ((ia >= 0 ? T1 : 0.0) + (ib >= 0 ? T2 : 0.0)) * d;          // :193
         // tangent projection grad - (grad*nv')*nv, nv = ones/sqrt(cnt)  (:199-201)
         const double nv = act0 ? a.nv_tab[cnt] : 0.0;
-        const double dot = group_sum<G>(act0 ? g * nv : 0.0);
+        const double dot = (a.ablate & 8) ? 0.0 : group_sum<G>(act0 ? g * nv : 0.0);
         g = g - dot * nv;
-        double ws = act0 ? apply_step<STEP>(a, w, g, c) : 0.0;                        // :207
-
-        // simplex projection (:215-224): threshold T with sum(max(w-T,0)) = 1.
-        // Michelot's fixed point gives the same active set as the reference's
-        // sort-and-scan (the first sorted i with sum(w(i:end)-w(i)) < 1).
-        bool act = act0;
-        double T = 0.0;
-        for (;;) {
-            const double s = group_sum<G>(act ? ws : 0.0);
-            const int na = group_count<G>(act, lane);
-            T = (s - 1.0) / (double)max(na, 1);
-            const bool keep = act && (ws > T);
-            const bool changed = keep != act;
-            act = keep;
-            if (!__any(changed)) break;
-        }
+        const double ws = act0 ? apply_step<STEP>(a.st, w, g, c) : 0.0;               // :207
+        const double T = simplex_threshold<G>(ws, act0, lane, a.ablate & 4);          // :215-223
         const double wn = act0 ? fmax(ws - T, 0.0) : 0.0;                             // :224
         const double snew = group_sum<G>(wn * d);                                     // :229
         if (act0) a.w_new[c] = wn;
@@ -150,23 +215,11 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a) {
             a.S_new[e] = snew;
         }
     }
-    // deterministic block partials
-    obj_acc = group_sum<64>(obj_acc);
-    chg_acc = group_sum<64>(chg_acc);
-    __shared__ double sh[8];
-    if (lane == 0) { sh[wv] = obj_acc; sh[4 + wv] = chg_acc; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        a.partials[2 * lb] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-        a.partials[2 * lb + 1] = (sh[4] + sh[5]) + (sh[6] + sh[7]);
-    }
+    block_partials(obj_acc, chg_acc, a.partials, lb);
 }
 
-// ---------------------------------------------------------------------------
-// Fallback sweep for segments longer than 64 cycles: one wave per edge, several
-// passes over the segment; w_new doubles as scratch (each lane re-reads only what
-// it wrote itself).
-// ---------------------------------------------------------------------------
+// Segments longer than 64 cycles: one wave per edge, several passes over the segment;
+// w_new doubles as scratch (each lane re-reads only what it wrote itself).
 template <int STEP>
 __global__ __launch_bounds__(256) void k_sweep_big(SweepArgs a) {
     if (a.state->stop) return;
@@ -203,7 +256,7 @@ __global__ __launch_bounds__(256) void k_sweep_big(SweepArgs a) {
         for (int t = lane; t < cnt; t += 64) {
             const int64_t c = (int64_t)base + t;
             const double g = a.w_new[c] - dot * nv;
-            a.w_new[c] = apply_step<STEP>(a, a.w_old[c], g, c);
+            a.w_new[c] = apply_step<STEP>(a.st, a.w_old[c], g, c);
         }
         double T = -INFINITY;
         int prev_n = -1;
@@ -233,49 +286,7 @@ __global__ __launch_bounds__(256) void k_sweep_big(SweepArgs a) {
             a.S_new[e] = snew;
         }
     }
-    obj_acc = group_sum<64>(obj_acc);
-    chg_acc = group_sum<64>(chg_acc);
-    __shared__ double sh[8];
-    if (lane == 0) { sh[wv] = obj_acc; sh[4 + wv] = chg_acc; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        a.partials[2 * lb] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-        a.partials[2 * lb + 1] = (sh[4] + sh[5]) + (sh[6] + sh[7]);
-    }
-}
-
-// Sum the block partials in a fixed order, record the traces and run the early-stop
-// rule of DESC_PGD.m:243-256 for the iteration whose objective just became known.
-// t = 1-based index of the sweep that produced the partials.
-__global__ __launch_bounds__(256) void k_finalize(const double* partials, int nparts, DevState* st,
-                                                  double* obj_trace, double* avg_trace, int t, int64_t m,
-                                                  int patience, double stop_tol, int last_only) {
-    if (st->stop) return;
-    __shared__ double sh[2][256];
-    double o = 0.0, ch = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += 256) { o += partials[2 * i]; ch += partials[2 * i + 1]; }
-    sh[0][threadIdx.x] = o; sh[1][threadIdx.x] = ch;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) { sh[0][threadIdx.x] += sh[0][threadIdx.x + s]; sh[1][threadIdx.x] += sh[1][threadIdx.x + s]; }
-        __syncthreads();
-    }
-    if (threadIdx.x != 0) return;
-    // last_only: the partials come from k_objective after the final sweep t: they
-    // hold obj(t).  Otherwise they come from sweep t: obj(t-1) and sum|dS| of sweep t.
-    const int it = last_only ? t : t - 1;          // iteration whose objective is sh[0][0]
-    if (!last_only) avg_trace[t - 1] = sh[1][0] / (double)m;                          // :232
-    if (it >= 1) {
-        obj_trace[it - 1] = sh[0][0];                                                 // :233
-        if (it > 1 && obj_trace[it - 2] - obj_trace[it - 1] < stop_tol) {             // :243
-            st->misses += 1;
-            if (st->misses >= patience) {                                             // :245-246
-                st->stop = 1; st->iters_run = it; st->final_parity = it & 1;
-            }
-        } else {
-            st->misses = 0;                                                           // :255
-        }
-    }
+    block_partials(obj_acc, chg_acc, a.partials, lb);
 }
 
 __global__ __launch_bounds__(256) void k_objective(const double* w, const double* S, const int32_t* e_jk,
@@ -285,15 +296,7 @@ __global__ __launch_bounds__(256) void k_objective(const double* w, const double
     double acc = 0.0;
     for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < m_cycle; c += (int64_t)gridDim.x * 256)
         acc += w[c] * (S[e_jk[c]] + S[e_ki[c]]);
-    acc = group_sum<64>(acc);
-    __shared__ double sh[4];
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]); partials[2 * blockIdx.x + 1] = 0.0; }
-}
-
-__global__ void k_fill(double* p, int64_t n, double v) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+    block_partials(acc, 0.0, partials, blockIdx.x);
 }
 
 // wijk = 1/cnt, S_vec(IJ) = wijk_seg * S0_seg'  (DESC_PGD.m:151-157); one wave per edge
@@ -314,8 +317,7 @@ __global__ __launch_bounds__(256) void k_init(const int32_t* cum, const int32_t*
 
 // Cycle inconsistency (DESC_PGD.m:129-147): one wave per edge, lanes over its cycles.
 // R_jk = RijMat4d(:,:,j,k) is the stored block of edge {j,k} if j<k, its transpose
-// otherwise; likewise R_ki (:65-66,89-91).  Products are accumulated in the
-// reference's order (sum over the middle index 1..3 starting from zero).
+// otherwise; likewise R_ki (:65-66,89-91).
 __global__ __launch_bounds__(256) void k_cycle_d(const int32_t* cum, const int32_t* pos_edge, const int32_t* ind_i,
                                                  const int32_t* ind_j, const int32_t* kk, const int32_t* e_jk,
                                                  const int32_t* e_ki, const double* rij, double* S0, int m_pos) {
@@ -330,34 +332,264 @@ __global__ __launch_bounds__(256) void k_cycle_d(const int32_t* cum, const int32
         for (int q = lane; q < cnt; q += 64) {
             const int64_t c = (int64_t)base + q;
             const int k = kk[c];
-            const double* pb = rij + 9 * (int64_t)e_jk[c];
-            const double* pc = rij + 9 * (int64_t)e_ki[c];
-            double B[9], C[9];
-            const bool tb = !(j < k), tc = !(k < i);
-            for (int r = 0; r < 3; ++r)
-                for (int s = 0; s < 3; ++s) {
-                    B[r + 3 * s] = tb ? pb[s + 3 * r] : pb[r + 3 * s];
-                    C[r + 3 * s] = tc ? pc[s + 3 * r] : pc[r + 3 * s];
-                }
-            double tr = 0.0;
-            for (int r = 0; r < 3; ++r) {
-                // row r of P = A*B, then (P*C)(r,r)
-                double P[3];
-                for (int s = 0; s < 3; ++s) {
-                    double acc = 0.0;
-                    for (int u = 0; u < 3; ++u) acc = acc + A[r + 3 * u] * B[u + 3 * s];
-                    P[s] = acc;
-                }
-                double acc = 0.0;
-                for (int u = 0; u < 3; ++u) acc = acc + P[u] * C[u + 3 * r];
-                tr = tr + acc;
-            }
+            const double tr = cycle_trace(A, rij + 9 * (int64_t)e_jk[c], !(j < k), rij + 9 * (int64_t)e_ki[c], !(k < i));
             S0[c] = abs_acos_ext((tr - 1.0) / 2.0) / M_PI;
         }
     }
 }
 
-// self-test kernel for the group reductions (tests/test_gpu_primitives.py)
+// ===========================================================================
+// NODE variant
+// ===========================================================================
+// per edge-with-cycles, in device (band-major) order
+struct EdgeInfo {
+    int32_t rb_i;     // rowptr[i]
+    int32_t rb_j;     // rowptr[j]
+    int32_t slot_a;   // rowptr[i] + idx_i(j): this edge's slot in row i of Sfull / Tfull
+    int32_t slot_b;   // rowptr[j] + idx_j(i): this edge's slot in row j
+};
+// packed per-cycle word: bits 0-14 idx_i(k), bit 15 cycle (ik;j) sampled (IKJ_appears, :113),
+//                        bits 16-30 idx_j(k), bit 31 cycle (jk;i) sampled (JKI_appears, :124)
+
+struct NodeSweepArgs {
+    const int32_t* cum;        // m_pos+1, device order
+    const EdgeInfo* einfo;     // m_pos
+    const uint32_t* pk;        // m_cycle
+    const double* S0;
+    const double* w_old;
+    double* w_new;
+    const double* S_old;       // Sfull, 2m
+    double* S_new;
+    const double* Tfull;       // 2m: Tfull[rowptr[v]+t] = sum_k w(v,k; nbr_t), masked
+    const double* nv_tab;
+    double* partials;
+    const DevState* state;
+    StepArgs st;
+    int32_t m_pos;
+    int32_t ablate;
+};
+
+template <int G, int STEP>
+__global__ __launch_bounds__(256) void k_sweep_node(NodeSweepArgs a) {
+    if (a.state->stop) return;
+    constexpr int EPW = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int sub = lane / G, gl = lane % G;
+    const int nb = gridDim.x;
+    const int lb = xcd_logical_block(blockIdx.x, nb);
+    const int per_block = (a.m_pos + nb - 1) / nb;
+    const int lo_edge = lb * per_block;
+    const int hi_edge = min(a.m_pos, lo_edge + per_block);
+
+    double obj_acc = 0.0, chg_acc = 0.0;
+    for (int l0 = lo_edge + wv * EPW; l0 < hi_edge; l0 += 4 * EPW) {
+        const int l = l0 + sub;
+        const bool edge_ok = l < hi_edge;
+        int base = 0, cnt = 0;
+        EdgeInfo ei{0, 0, 0, 0};
+        double T1 = 0.0, T2 = 0.0;
+        if (edge_ok) {
+            base = a.cum[l]; cnt = a.cum[l + 1] - base;
+            ei = a.einfo[l];
+            T1 = a.Tfull[ei.slot_a];            // column j of node i  = sum(wijk(IKJ(mask)))  (:189)
+            T2 = a.Tfull[ei.slot_b];            // column i of node j  = sum(wijk(JKI(mask)))  (:190)
+        }
+        const bool act0 = gl < cnt;
+        const int64_t c = (int64_t)base + gl;
+        double w = 0.0, d = 0.0, ssum = 0.0;
+        uint32_t p = 0;
+        if (act0) {
+            p = a.pk[c];
+            w = a.w_old[c]; d = a.S0[c];
+            const int si = ei.rb_i + (int)(p & 0x7FFFu), sj = ei.rb_j + (int)((p >> 16) & 0x7FFFu);
+            ssum = (a.ablate & 1) ? 1.0 + 1e-9 * (double)(si + sj) : a.S_old[sj] + a.S_old[si];   // S(jk)+S(ki)
+        }
+        obj_acc += w * ssum;
+        double g = ssum + (((p & 0x8000u) ? T1 : 0.0) + ((p & 0x80000000u) ? T2 : 0.0)) * d;     // :193
+        const double nv = act0 ? a.nv_tab[cnt] : 0.0;
+        const double dot = group_sum<G>(act0 ? g * nv : 0.0);                                    // :199-201
+        g = g - dot * nv;
+        const double ws = act0 ? apply_step<STEP>(a.st, w, g, c) : 0.0;                          // :207
+        const double T = simplex_threshold<G>(ws, act0, lane, a.ablate & 4);                     // :215-223
+        const double wn = act0 ? fmax(ws - T, 0.0) : 0.0;                                        // :224
+        const double snew = group_sum<G>(wn * d);                                                // :229
+        if (act0) a.w_new[c] = wn;
+        if (edge_ok && gl == 0) {
+            chg_acc += fabs(snew - a.S_old[ei.slot_a]);                                          // :232
+            a.S_new[ei.slot_a] = snew;
+            a.S_new[ei.slot_b] = snew;
+        }
+    }
+    block_partials(obj_acc, chg_acc, a.partials, lb);
+}
+
+// Mirror-weight column sums (DESC_PGD.m:185-191 in node form).  One workgroup per node
+// v: for every incident edge {v,u} (CSR order) stream its segment; a cycle with third
+// vertex t adds its weight to column idx_v(t) if the reverse cycle ({v,t};u) was sampled.
+// Each wave owns a private copy of the columns in LDS (segments are assigned to waves
+// round-robin, third vertices inside a segment are distinct), copies are added in a
+// fixed order at the end.
+__global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, const int32_t* adj_pos, const int32_t* cum,
+                                                     const EdgeInfo* einfo, const uint32_t* pk, const double* w,
+                                                     double* Tfull, int n, int stride_cols, const DevState* st) {
+    if (st->stop) return;
+    extern __shared__ double acc[];      // [4][stride_cols]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int v = blockIdx.x; v < n; v += gridDim.x) {
+        const int r0 = rowptr[v], deg = rowptr[v + 1] - r0;
+        for (int t = threadIdx.x; t < 4 * stride_cols; t += 256) acc[t] = 0.0;
+        __syncthreads();
+        double* mine = acc + wv * stride_cols;
+        for (int t = wv; t < deg; t += 4) {
+            const int l = adj_pos[r0 + t];
+            if (l < 0) continue;                       // edge without cycles (wave-uniform)
+            const int base = cum[l], cnt = cum[l + 1] - base;
+            const bool v_is_i = einfo[l].rb_i == r0;
+            for (int q = lane; q < cnt; q += 64) {
+                const uint32_t p = pk[(int64_t)base + q];
+                const uint32_t half = v_is_i ? (p & 0xFFFFu) : (p >> 16);
+                if (half & 0x8000u) mine[half & 0x7FFFu] += w[(int64_t)base + q];
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < deg; t += 256)
+            Tfull[r0 + t] = (acc[t] + acc[stride_cols + t]) + (acc[2 * stride_cols + t] + acc[3 * stride_cols + t]);
+        __syncthreads();
+    }
+}
+
+// Setup of the node layout: copies one natural-order segment into its band-major slot,
+// packs idx_i(k) / idx_j(k) / mirror bits and evaluates the cycle inconsistency.
+// kf = k | (ikj>=0)<<30 | (jki>=0)<<31 in natural order.
+__global__ __launch_bounds__(256) void k_layout_node(const int32_t* cum, const int32_t* src_start, const int32_t* pos_edge,
+                                                     const int32_t* ind_i, const int32_t* ind_j, const uint32_t* kf,
+                                                     const int32_t* rowptr, const int32_t* adj, const int32_t* adj_eid,
+                                                     const double* rij, uint32_t* pk, double* S0, int m_pos) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t l = wid; l < m_pos; l += nw) {
+        const int base = cum[l], cnt = cum[l + 1] - base, src = src_start[l];
+        const int e = pos_edge[l], i = ind_i[e], j = ind_j[e];
+        const int ri = rowptr[i], di = rowptr[i + 1] - ri, rj = rowptr[j], dj = rowptr[j + 1] - rj;
+        double A[9];
+        for (int t = 0; t < 9; ++t) A[t] = rij[9 * (int64_t)e + t];
+        for (int q = lane; q < cnt; q += 64) {
+            const uint32_t x = kf[(int64_t)src + q];
+            const int k = (int)(x & 0x3FFFFFFFu);
+            int lo = 0, hi = di;                                  // idx_i(k): position of k in row i
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (adj[ri + mid] < k) lo = mid + 1; else hi = mid; }
+            const int xi = min(lo, max(di - 1, 0));               // clamp: memory-safe even for a bogus imported structure
+            lo = 0; hi = dj;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (adj[rj + mid] < k) lo = mid + 1; else hi = mid; }
+            const int xj = min(lo, max(dj - 1, 0));
+            pk[(int64_t)base + q] = (uint32_t)xi | ((x >> 30) & 1u) << 15 | (uint32_t)xj << 16 | ((x >> 31) & 1u) << 31;
+            const double tr = cycle_trace(A, rij + 9 * (int64_t)adj_eid[rj + xj], !(j < k), rij + 9 * (int64_t)adj_eid[ri + xi], !(k < i));
+            S0[(int64_t)base + q] = abs_acos_ext((tr - 1.0) / 2.0) / M_PI;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_init_node(const int32_t* cum, const EdgeInfo* einfo, const double* S0,
+                                                   double* w, double* S_a, double* S_b, int m_pos) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t l = wid; l < m_pos; l += nw) {
+        const int base = cum[l], cnt = cum[l + 1] - base;
+        const double w0 = 1.0 / (double)cnt;
+        double s = 0.0;
+        for (int t = lane; t < cnt; t += 64) { w[(int64_t)base + t] = w0; s += w0 * S0[(int64_t)base + t]; }
+        s = group_sum<64>(s);
+        if (lane == 0) {
+            const EdgeInfo ei = einfo[l];
+            S_a[ei.slot_a] = s; S_a[ei.slot_b] = s; S_b[ei.slot_a] = s; S_b[ei.slot_b] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_objective_node(const int32_t* cum, const EdgeInfo* einfo, const uint32_t* pk,
+                                                        const double* w, const double* S, int m_pos, double* partials,
+                                                        const DevState* st) {
+    if (st->stop) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * 256) >> 6;
+    double acc = 0.0;
+    for (int64_t l = wid; l < m_pos; l += nw) {
+        const int base = cum[l], cnt = cum[l + 1] - base;
+        const EdgeInfo ei = einfo[l];
+        for (int t = lane; t < cnt; t += 64) {
+            const uint32_t p = pk[(int64_t)base + t];
+            acc += w[(int64_t)base + t] * (S[ei.rb_j + (int)((p >> 16) & 0x7FFFu)] + S[ei.rb_i + (int)(p & 0x7FFFu)]);
+        }
+    }
+    block_partials(acc, 0.0, partials, blockIdx.x);
+}
+
+// S_vec in the caller's edge order from the CSR-aligned copy
+__global__ void k_extract_S(const double* Sfull, const int32_t* eslot, double* S_vec, int64_t m) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < m; e += (int64_t)gridDim.x * blockDim.x)
+        S_vec[e] = Sfull[eslot[e]];
+}
+// per-cycle vector between natural order and device order (dir 0: natural -> device, 1: device -> natural)
+__global__ __launch_bounds__(256) void k_reorder_cycles(const int32_t* cum, const int32_t* src_start, const double* in,
+                                                        double* out, int m_pos, int dir) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t l = wid; l < m_pos; l += nw) {
+        const int base = cum[l], cnt = cum[l + 1] - base, src = src_start[l];
+        for (int t = lane; t < cnt; t += 64) {
+            if (dir == 0) out[(int64_t)base + t] = in[(int64_t)src + t];
+            else out[(int64_t)src + t] = in[(int64_t)base + t];
+        }
+    }
+}
+
+// ===========================================================================
+// shared small kernels
+// ===========================================================================
+// Sum the block partials in a fixed order, record the traces and run the early-stop
+// rule of DESC_PGD.m:243-256 for the iteration whose objective just became known.
+// t = 1-based index of the sweep that produced the partials.
+__global__ __launch_bounds__(256) void k_finalize(const double* partials, int nparts, DevState* st,
+                                                  double* obj_trace, double* avg_trace, int t, int64_t m,
+                                                  int patience, double stop_tol, int last_only) {
+    if (st->stop) return;
+    __shared__ double sh[2][256];
+    double o = 0.0, ch = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) { o += partials[2 * i]; ch += partials[2 * i + 1]; }
+    sh[0][threadIdx.x] = o; sh[1][threadIdx.x] = ch;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sh[0][threadIdx.x] += sh[0][threadIdx.x + s]; sh[1][threadIdx.x] += sh[1][threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    // last_only: the partials come from the objective kernel after the final sweep t and
+    // hold obj(t).  Otherwise they come from sweep t: obj(t-1) and sum|dS| of sweep t.
+    const int it = last_only ? t : t - 1;          // iteration whose objective is sh[0][0]
+    if (!last_only) avg_trace[t - 1] = sh[1][0] / (double)m;                          // :232
+    if (it >= 1) {
+        obj_trace[it - 1] = sh[0][0];                                                 // :233
+        if (it > 1 && obj_trace[it - 2] - obj_trace[it - 1] < stop_tol) {             // :243
+            st->misses += 1;
+            if (st->misses >= patience) {                                             // :245-246
+                st->stop = 1; st->iters_run = it; st->final_parity = it & 1;
+            }
+        } else {
+            st->misses = 0;                                                           // :255
+        }
+    }
+}
+
+__global__ void k_fill(double* p, int64_t n, double v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// self-test kernel for the group reductions (tests/test_gpu_parity.py)
 __global__ void k_selftest_group_sum(const double* in, double* out, int G) {
     const int t = threadIdx.x + blockIdx.x * blockDim.x;
     const double v = in[t];
@@ -369,20 +601,33 @@ __global__ void k_selftest_group_sum(const double* in, double* out, int G) {
 using namespace desc;
 
 // ------------------------------------------------------------------- handle --
+enum { VARIANT_GATHER = 1, VARIANT_NODE = 2 };
+
 struct desc_pgd {
     int device = 0;
     hipStream_t stream = nullptr;
     int64_t n = 0, m = 0, m_pos = 0, m_cycle = 0;
-    int32_t max_cnt = 0, n_sample = 0;
-    int G = 64;                 // lanes per segment; 0 = big fallback
+    int32_t max_cnt = 0, n_sample = 0, max_deg = 0;
+    int variant = VARIANT_GATHER;
+    int G = 64;                 // lanes per segment; 0 = big fallback (gather variant only)
     int grid = 0;               // sweep grid (multiple of 8)
     int obj_grid = 0;
-    // device buffers
-    int32_t *d_cum = nullptr, *d_pos_edge = nullptr, *d_ejk = nullptr, *d_eki = nullptr, *d_ikj = nullptr, *d_jki = nullptr;
+    int colsum_grid = 0, colsum_stride = 0;
+    int band = 0;
+    std::vector<void*> allocs;
+    // common
+    int32_t* d_cum = nullptr;
     double *d_S0 = nullptr, *d_w[2] = {nullptr, nullptr}, *d_S[2] = {nullptr, nullptr};
     double *d_adam_m = nullptr, *d_adam_v = nullptr, *d_nv = nullptr, *d_partials = nullptr;
-    double *d_obj = nullptr, *d_avg = nullptr;
+    double *d_obj = nullptr, *d_avg = nullptr, *d_scratch = nullptr;
     DevState* d_state = nullptr;
+    // gather variant
+    int32_t *d_pos_edge = nullptr, *d_ejk = nullptr, *d_eki = nullptr, *d_ikj = nullptr, *d_jki = nullptr;
+    // node variant
+    EdgeInfo* d_einfo = nullptr;
+    uint32_t* d_pk = nullptr;
+    int32_t *d_rowptr = nullptr, *d_adj_pos = nullptr, *d_src_start = nullptr, *d_eslot = nullptr;
+    double *d_T = nullptr, *d_Svec = nullptr;
     int trace_cap = 0;
     // run state
     desc_params p{};
@@ -390,16 +635,25 @@ struct desc_pgd {
     int t_done = 0;             // sweeps enqueued since reset
     int t_plugin = 0;           // plugin counter (PiecewiseStepSize.t / HybridGradient.t)
     double ms_upload = 0, ms_cycle_d = 0, ms_pgd = 0;
+    int ablate = 0;             // diagnostics (DESC_DEBUG_ABLATE)
     std::string kname;
 };
 
 namespace {
 
 template <class T>
-int dmalloc(T** p, size_t count) {
+int dalloc(desc_pgd* h, T** p, size_t count) {
     *p = nullptr;
-    DESC_HIP(hipMalloc((void**)p, sizeof(T) * (count > 0 ? count : 1)));
+    void* q = nullptr;
+    DESC_HIP(hipMalloc(&q, sizeof(T) * (count > 0 ? count : 1)));
+    h->allocs.push_back(q);
+    *p = (T*)q;
     return DESC_OK;
+}
+void dfree(desc_pgd* h, void* q) {
+    if (!q) return;
+    for (auto& x : h->allocs) if (x == q) { x = nullptr; break; }
+    (void)hipFree(q);
 }
 
 int set_device(const desc_pgd* h) { DESC_HIP(hipSetDevice(h->device)); return DESC_OK; }
@@ -407,15 +661,57 @@ int set_device(const desc_pgd* h) { DESC_HIP(hipSetDevice(h->device)); return DE
 void free_all(desc_pgd* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void* ptrs[] = {h->d_cum, h->d_pos_edge, h->d_ejk, h->d_eki, h->d_ikj, h->d_jki, h->d_S0, h->d_w[0], h->d_w[1],
-                    h->d_S[0], h->d_S[1], h->d_adam_m, h->d_adam_v, h->d_nv, h->d_partials, h->d_obj, h->d_avg, h->d_state};
-    for (void* q : ptrs) if (q) (void)hipFree(q);
+    for (void* q : h->allocs) if (q) (void)hipFree(q);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
+template <class T>
+int upload(desc_pgd* h, T* dst, const T* src, size_t count) {
+    if (count) DESC_HIP(hipMemcpyAsync(dst, src, sizeof(T) * count, hipMemcpyHostToDevice, h->stream));
+    return DESC_OK;
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
+}
+
+template <class F>
+void host_parallel(int64_t count, F&& body) {
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)std::min<int64_t>(std::max(1u, std::min(hw, 16u)), std::max<int64_t>(1, count / 65536));
+    if (nt <= 1) { body(0, count); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back([=, &body]() { body(count * t / nt, count * (t + 1) / nt); });
+    for (auto& x : th) x.join();
+}
+
+StepArgs make_step(desc_pgd* h, bool* adam) {
+    const desc_params& p = h->p;
+    StepArgs s{};
+    s.adam_m = h->d_adam_m; s.adam_v = h->d_adam_v;
+    // one GetStep call per iteration (DESC_PGD.m:207): the plugin counter advances first
+    const int tp = ++h->t_plugin;
+    s.lr = p.lr; s.beta1 = p.beta1; s.beta2 = p.beta2; s.bc1 = 1.0; s.bc2 = 1.0;
+    s.step = p.lr;
+    *adam = false;
+    if (p.step_kind == DESC_STEP_PIECEWISE) {
+        s.step = p.lr / (std::trunc((double)tp / p.decay_interval) + 1.0);            // PiecewiseStepSize.m:16
+    } else if (p.step_kind == DESC_STEP_HYBRID) {
+        if (p.hybrid_strategy == 0) {
+            *adam = true;
+            s.bc1 = 1.0 - std::pow(p.beta1, (double)tp);                             // HybridGradient.m:32-33
+            s.bc2 = 1.0 - std::pow(p.beta2, (double)tp);
+        } else {
+            s.step = 100.0 * (p.lr / (std::trunc((double)tp / p.decay_interval) + 1.0));   // HybridGradient.m:39
+        }
+    }
+    return s;
+}
+
 template <int STEP>
-void launch_sweep(desc_pgd* h, const SweepArgs& a) {
+void launch_gather(desc_pgd* h, const SweepArgs& a) {
     dim3 grid(h->grid), block(256);
     switch (h->G) {
         case 16: hipLaunchKernelGGL((k_sweep<16, STEP>), grid, block, 0, h->stream, a); break;
@@ -424,39 +720,267 @@ void launch_sweep(desc_pgd* h, const SweepArgs& a) {
         default: hipLaunchKernelGGL((k_sweep_big<STEP>), grid, block, 0, h->stream, a); break;
     }
 }
+template <int STEP>
+void launch_node(desc_pgd* h, const NodeSweepArgs& a) {
+    dim3 grid(h->grid), block(256);
+    switch (h->G) {
+        case 16: hipLaunchKernelGGL((k_sweep_node<16, STEP>), grid, block, 0, h->stream, a); break;
+        case 32: hipLaunchKernelGGL((k_sweep_node<32, STEP>), grid, block, 0, h->stream, a); break;
+        default: hipLaunchKernelGGL((k_sweep_node<64, STEP>), grid, block, 0, h->stream, a); break;
+    }
+}
 
-// enqueue sweep number t (1-based) and its finalize
+// enqueue sweep number t (1-based) and its finalize; ev0/ev1 bracket the kernels of the sweep proper
 int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     const desc_params& p = h->p;
     const int rd = (t - 1) & 1, wr = t & 1;
-    SweepArgs a{};
-    a.cum = h->d_cum; a.pos_edge = h->d_pos_edge; a.e_jk = h->d_ejk; a.e_ki = h->d_eki; a.ikj = h->d_ikj; a.jki = h->d_jki;
-    a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr]; a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr];
-    a.adam_m = h->d_adam_m; a.adam_v = h->d_adam_v; a.nv_tab = h->d_nv; a.partials = h->d_partials; a.state = h->d_state;
-    a.m_pos = (int32_t)h->m_pos;
-    // one GetStep call per iteration (DESC_PGD.m:207): the plugin counter advances first
-    const int tp = ++h->t_plugin;
-    a.lr = p.lr; a.beta1 = p.beta1; a.beta2 = p.beta2; a.bc1 = 1.0; a.bc2 = 1.0;
-    a.step = p.lr;
     bool adam = false;
-    if (p.step_kind == DESC_STEP_PIECEWISE) {
-        a.step = p.lr / (std::trunc((double)tp / p.decay_interval) + 1.0);            // PiecewiseStepSize.m:16
-    } else if (p.step_kind == DESC_STEP_HYBRID) {
-        if (p.hybrid_strategy == 0) {
-            adam = true;
-            a.bc1 = 1.0 - std::pow(p.beta1, (double)tp);                             // HybridGradient.m:32-33
-            a.bc2 = 1.0 - std::pow(p.beta2, (double)tp);
-        } else {
-            a.step = 100.0 * (p.lr / (std::trunc((double)tp / p.decay_interval) + 1.0));   // HybridGradient.m:39
-        }
-    }
+    const StepArgs st = make_step(h, &adam);
     if (ev0) (void)hipEventRecord(ev0, h->stream);
-    if (adam) launch_sweep<DESC_STEP_HYBRID>(h, a); else launch_sweep<DESC_STEP_CONSTANT>(h, a);
+    if (h->variant == VARIANT_NODE) {
+        hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid), dim3(256), sizeof(double) * 4 * h->colsum_stride, h->stream,
+                           h->d_rowptr, h->d_adj_pos, h->d_cum, h->d_einfo, h->d_pk, h->d_w[rd], h->d_T, (int)h->n,
+                           h->colsum_stride, h->d_state);
+        NodeSweepArgs a{};
+        a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
+        a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->d_T; a.nv_tab = h->d_nv; a.partials = h->d_partials;
+        a.state = h->d_state; a.st = st; a.m_pos = (int32_t)h->m_pos; a.ablate = h->ablate;
+        if (adam) launch_node<DESC_STEP_HYBRID>(h, a); else launch_node<DESC_STEP_CONSTANT>(h, a);
+    } else {
+        SweepArgs a{};
+        a.cum = h->d_cum; a.pos_edge = h->d_pos_edge; a.e_jk = h->d_ejk; a.e_ki = h->d_eki; a.ikj = h->d_ikj; a.jki = h->d_jki;
+        a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr]; a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr];
+        a.nv_tab = h->d_nv; a.partials = h->d_partials; a.state = h->d_state; a.st = st;
+        a.m_pos = (int32_t)h->m_pos; a.ablate = h->ablate;
+        if (adam) launch_gather<DESC_STEP_HYBRID>(h, a); else launch_gather<DESC_STEP_CONSTANT>(h, a);
+    }
     if (ev1) (void)hipEventRecord(ev1, h->stream);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, h->d_partials, h->grid, h->d_state, h->d_obj,
                        h->d_avg, t, h->m, p.patience, p.stop_tol, 0);
     DESC_HIP(hipGetLastError());
     return DESC_OK;
+}
+
+int choose_grid(desc_pgd* h) {
+    const int epw = h->G ? 64 / h->G : 1;
+    int64_t want = (h->m_pos + 4 * epw - 1) / (4 * epw);
+    want = std::min<int64_t>(want, 2048);
+    want = std::max<int64_t>(want, 8);
+    h->grid = (int)((want + 7) / 8 * 8);
+    return DESC_OK;
+}
+
+// ---------------------------------------------------------------- GATHER setup
+int setup_gather(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
+    const int64_t m = h->m, mp = h->m_pos, mc = h->m_cycle;
+    int rc;
+    if ((rc = dalloc(h, &h->d_pos_edge, mp))) return rc;
+    if ((rc = dalloc(h, &h->d_ejk, mc))) return rc;
+    if ((rc = dalloc(h, &h->d_eki, mc))) return rc;
+    if ((rc = dalloc(h, &h->d_ikj, mc))) return rc;
+    if ((rc = dalloc(h, &h->d_jki, mc))) return rc;
+    if ((rc = dalloc(h, &h->d_S[0], m))) return rc;
+    if ((rc = dalloc(h, &h->d_S[1], m))) return rc;
+    h->G = h->max_cnt <= 16 ? 16 : h->max_cnt <= 32 ? 32 : h->max_cnt <= 64 ? 64 : 0;
+    choose_grid(h);
+    h->obj_grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (mc + 255) / 256));
+    char nm[64];
+    if (h->G) snprintf(nm, sizeof nm, "k_sweep<%d,", h->G); else snprintf(nm, sizeof nm, "k_sweep_big<");
+    h->kname = nm;
+
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<int32_t> cum32((size_t)mp + 1);
+    for (int64_t l = 0; l <= mp; ++l) cum32[l] = (int32_t)s->cum_ind[l];
+    int32_t *d_k = nullptr, *d_ii = nullptr, *d_jj = nullptr; double* d_rij = nullptr;
+    if ((rc = dalloc(h, &d_k, mc))) return rc;
+    if ((rc = dalloc(h, &d_ii, m))) return rc;
+    if ((rc = dalloc(h, &d_jj, m))) return rc;
+    if ((rc = dalloc(h, &d_rij, 9 * (size_t)m))) return rc;
+    if ((rc = upload(h, h->d_cum, cum32.data(), (size_t)mp + 1))) return rc;
+    if ((rc = upload(h, h->d_pos_edge, s->pos_edge.data(), (size_t)mp))) return rc;
+    if ((rc = upload(h, h->d_ejk, s->e_jk.data(), (size_t)mc))) return rc;
+    if ((rc = upload(h, h->d_eki, s->e_ki.data(), (size_t)mc))) return rc;
+    if ((rc = upload(h, h->d_ikj, s->ikj.data(), (size_t)mc))) return rc;
+    if ((rc = upload(h, h->d_jki, s->jki.data(), (size_t)mc))) return rc;
+    if ((rc = upload(h, d_k, s->k.data(), (size_t)mc))) return rc;
+    if ((rc = upload(h, d_ii, prob->ind_i, (size_t)m))) return rc;
+    if ((rc = upload(h, d_jj, prob->ind_j, (size_t)m))) return rc;
+    if ((rc = upload(h, d_rij, prob->rij, 9 * (size_t)m))) return rc;
+    DESC_HIP(hipStreamSynchronize(h->stream));
+    h->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+    hipEvent_t e0, e1;
+    DESC_HIP(hipEventCreate(&e0)); DESC_HIP(hipEventCreate(&e1));
+    (void)hipEventRecord(e0, h->stream);
+    if (mp > 0) {
+        int g = (int)std::min<int64_t>(4096, (mp + 3) / 4);
+        hipLaunchKernelGGL(k_cycle_d, dim3(g), dim3(256), 0, h->stream, h->d_cum, h->d_pos_edge, d_ii, d_jj, d_k,
+                           h->d_ejk, h->d_eki, d_rij, h->d_S0, (int)mp);
+    }
+    (void)hipEventRecord(e1, h->stream);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    h->ms_cycle_d = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    dfree(h, d_k); dfree(h, d_ii); dfree(h, d_jj); dfree(h, d_rij);
+    if (e != hipSuccess) return fail(DESC_ERR_HIP, "k_cycle_d: %s", hipGetErrorString(e));
+    return DESC_OK;
+}
+
+// ------------------------------------------------------------------ NODE setup
+int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
+    const int64_t n = h->n, m = h->m, mp = h->m_pos, mc = h->m_cycle;
+    auto t0 = std::chrono::steady_clock::now();
+    // CSR adjacency (neighbours ascending; single pass because Ind is sorted by (i,j))
+    std::vector<int32_t> rowptr((size_t)n + 1, 0), adj((size_t)2 * m), adj_eid((size_t)2 * m);
+    for (int64_t e = 0; e < m; ++e) { rowptr[prob->ind_i[e] + 1]++; rowptr[prob->ind_j[e] + 1]++; }
+    for (int64_t v = 0; v < n; ++v) rowptr[v + 1] += rowptr[v];
+    {
+        std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
+        for (int64_t e = 0; e < m; ++e) {
+            const int32_t i = prob->ind_i[e], j = prob->ind_j[e];
+            adj[fill[i]] = j; adj_eid[fill[i]++] = (int32_t)e;
+            adj[fill[j]] = i; adj_eid[fill[j]++] = (int32_t)e;
+        }
+    }
+    auto idx_in_row = [&](int32_t v, int32_t u) {
+        const int32_t* b = adj.data() + rowptr[v];
+        const int32_t* e = adj.data() + rowptr[v + 1];
+        return (int32_t)(std::lower_bound(b, e, u) - b);
+    };
+    // slot of every edge in its smaller endpoint's row (for S_vec extraction)
+    std::vector<int32_t> eslot((size_t)m);
+    host_parallel(m, [&](int64_t a, int64_t b) {
+        for (int64_t e = a; e < b; ++e) eslot[e] = rowptr[prob->ind_i[e]] + idx_in_row(prob->ind_i[e], prob->ind_j[e]);
+    });
+    // band-major order of the edges with cycles: (band(i), j, i)
+    int band = env_int("DESC_DEBUG_BAND", 0);
+    if (band <= 0) {
+        // rows of one band should stay in an XCD's 4 MiB L2 next to the streamed arrays: ~1 MiB
+        band = (int)std::max<int64_t>(8, std::min<int64_t>(512, (1 << 20) / (8 * (int64_t)std::max(1, h->max_deg))));
+    }
+    h->band = band;
+    std::vector<int32_t> order((size_t)mp);
+    for (int64_t l = 0; l < mp; ++l) order[l] = (int32_t)l;
+    {
+        const int32_t* ii = prob->ind_i; const int32_t* jj = prob->ind_j; const int32_t* pe = s->pos_edge.data();
+        std::sort(order.begin(), order.end(), [=](int32_t x, int32_t y) {
+            const int32_t ex = pe[x], ey = pe[y];
+            const int32_t bx = ii[ex] / band, by = ii[ey] / band;
+            if (bx != by) return bx < by;
+            if (jj[ex] != jj[ey]) return jj[ex] < jj[ey];
+            return ii[ex] < ii[ey];
+        });
+    }
+    std::vector<int32_t> cum2((size_t)mp + 1, 0), src_start((size_t)mp), pos_edge2((size_t)mp), devpos((size_t)m, -1);
+    std::vector<EdgeInfo> einfo((size_t)mp);
+    for (int64_t q = 0; q < mp; ++q) {
+        const int32_t l = order[q], e = s->pos_edge[l];
+        cum2[q + 1] = cum2[q] + (int32_t)(s->cum_ind[l + 1] - s->cum_ind[l]);
+        src_start[q] = (int32_t)s->cum_ind[l];
+        pos_edge2[q] = e; devpos[e] = (int32_t)q;
+    }
+    host_parallel(mp, [&](int64_t a, int64_t b) {
+        for (int64_t q = a; q < b; ++q) {
+            const int32_t e = pos_edge2[q], i = prob->ind_i[e], j = prob->ind_j[e];
+            einfo[q] = EdgeInfo{rowptr[i], rowptr[j], eslot[e], rowptr[j] + idx_in_row(j, i)};
+        }
+    });
+    std::vector<int32_t> adj_pos((size_t)2 * m);
+    host_parallel(2 * m, [&](int64_t a, int64_t b) { for (int64_t t = a; t < b; ++t) adj_pos[t] = devpos[adj_eid[t]]; });
+    // k with the two mirror-present bits, natural order
+    std::vector<uint32_t> kf((size_t)mc);
+    host_parallel(mc, [&](int64_t a, int64_t b) {
+        for (int64_t c = a; c < b; ++c)
+            kf[c] = (uint32_t)s->k[c] | (s->ikj[c] >= 0 ? 1u << 30 : 0u) | (s->jki[c] >= 0 ? 1u << 31 : 0u);
+    });
+
+    int rc;
+    if ((rc = dalloc(h, &h->d_einfo, mp))) return rc;
+    if ((rc = dalloc(h, &h->d_pk, mc))) return rc;
+    if ((rc = dalloc(h, &h->d_rowptr, n + 1))) return rc;
+    if ((rc = dalloc(h, &h->d_adj_pos, 2 * m))) return rc;
+    if ((rc = dalloc(h, &h->d_src_start, mp))) return rc;
+    if ((rc = dalloc(h, &h->d_eslot, m))) return rc;
+    if ((rc = dalloc(h, &h->d_S[0], 2 * m))) return rc;
+    if ((rc = dalloc(h, &h->d_S[1], 2 * m))) return rc;
+    if ((rc = dalloc(h, &h->d_T, 2 * m))) return rc;
+    if ((rc = dalloc(h, &h->d_Svec, m))) return rc;
+    int32_t *d_ii = nullptr, *d_jj = nullptr, *d_adj = nullptr, *d_adj_eid = nullptr, *d_pos_edge2 = nullptr;
+    uint32_t* d_kf = nullptr; double* d_rij = nullptr;
+    if ((rc = dalloc(h, &d_ii, m))) return rc;
+    if ((rc = dalloc(h, &d_jj, m))) return rc;
+    if ((rc = dalloc(h, &d_adj, 2 * m))) return rc;
+    if ((rc = dalloc(h, &d_adj_eid, 2 * m))) return rc;
+    if ((rc = dalloc(h, &d_pos_edge2, mp))) return rc;
+    if ((rc = dalloc(h, &d_kf, mc))) return rc;
+    if ((rc = dalloc(h, &d_rij, 9 * (size_t)m))) return rc;
+    if ((rc = upload(h, h->d_cum, cum2.data(), (size_t)mp + 1))) return rc;
+    if ((rc = upload(h, h->d_einfo, einfo.data(), (size_t)mp))) return rc;
+    if ((rc = upload(h, h->d_rowptr, rowptr.data(), (size_t)n + 1))) return rc;
+    if ((rc = upload(h, h->d_adj_pos, adj_pos.data(), (size_t)2 * m))) return rc;
+    if ((rc = upload(h, h->d_src_start, src_start.data(), (size_t)mp))) return rc;
+    if ((rc = upload(h, h->d_eslot, eslot.data(), (size_t)m))) return rc;
+    if ((rc = upload(h, d_ii, prob->ind_i, (size_t)m))) return rc;
+    if ((rc = upload(h, d_jj, prob->ind_j, (size_t)m))) return rc;
+    if ((rc = upload(h, d_adj, adj.data(), (size_t)2 * m))) return rc;
+    if ((rc = upload(h, d_adj_eid, adj_eid.data(), (size_t)2 * m))) return rc;
+    if ((rc = upload(h, d_pos_edge2, pos_edge2.data(), (size_t)mp))) return rc;
+    if ((rc = upload(h, d_kf, kf.data(), (size_t)mc))) return rc;
+    if ((rc = upload(h, d_rij, prob->rij, 9 * (size_t)m))) return rc;
+    DESC_HIP(hipStreamSynchronize(h->stream));
+    h->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+    h->G = h->max_cnt <= 16 ? 16 : h->max_cnt <= 32 ? 32 : 64;
+    choose_grid(h);
+    h->obj_grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (mp + 3) / 4));
+    h->colsum_stride = (h->max_deg + 1) | 1;                 // odd stride: the 4 copies start on different banks
+    h->colsum_grid = (int)std::min<int64_t>(n, 256 * 8);
+    char nm[64];
+    snprintf(nm, sizeof nm, "k_sweep_node<%d,", h->G);
+    h->kname = nm;
+
+    hipEvent_t e0, e1;
+    DESC_HIP(hipEventCreate(&e0)); DESC_HIP(hipEventCreate(&e1));
+    (void)hipEventRecord(e0, h->stream);
+    if (mp > 0) {
+        int g = (int)std::min<int64_t>(4096, (mp + 3) / 4);
+        hipLaunchKernelGGL(k_layout_node, dim3(g), dim3(256), 0, h->stream, h->d_cum, h->d_src_start, d_pos_edge2, d_ii, d_jj,
+                           d_kf, h->d_rowptr, d_adj, d_adj_eid, d_rij, h->d_pk, h->d_S0, (int)mp);
+    }
+    (void)hipEventRecord(e1, h->stream);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    h->ms_cycle_d = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    dfree(h, d_ii); dfree(h, d_jj); dfree(h, d_adj); dfree(h, d_adj_eid); dfree(h, d_pos_edge2); dfree(h, d_kf); dfree(h, d_rij);
+    if (e != hipSuccess) return fail(DESC_ERR_HIP, "k_layout_node: %s", hipGetErrorString(e));
+    return DESC_OK;
+}
+
+// per-cycle host vector <-> device (handles the node layout's segment permutation)
+int cycles_to_device(desc_pgd* h, const double* host, double* dev) {
+    if (h->m_cycle == 0) return DESC_OK;
+    if (h->variant != VARIANT_NODE) { DESC_HIP(hipMemcpyAsync(dev, host, sizeof(double) * h->m_cycle, hipMemcpyHostToDevice, h->stream)); return DESC_OK; }
+    DESC_HIP(hipMemcpyAsync(h->d_scratch, host, sizeof(double) * h->m_cycle, hipMemcpyHostToDevice, h->stream));
+    int g = (int)std::min<int64_t>(4096, (h->m_pos + 3) / 4);
+    hipLaunchKernelGGL(k_reorder_cycles, dim3(g), dim3(256), 0, h->stream, h->d_cum, h->d_src_start, h->d_scratch, dev, (int)h->m_pos, 0);
+    return DESC_OK;
+}
+int cycles_to_host(desc_pgd* h, const double* dev, double* host) {
+    if (h->m_cycle == 0) return DESC_OK;
+    if (h->variant != VARIANT_NODE) { DESC_HIP(hipMemcpy(host, dev, sizeof(double) * h->m_cycle, hipMemcpyDeviceToHost)); return DESC_OK; }
+    int g = (int)std::min<int64_t>(4096, (h->m_pos + 3) / 4);
+    hipLaunchKernelGGL(k_reorder_cycles, dim3(g), dim3(256), 0, h->stream, h->d_cum, h->d_src_start, dev, h->d_scratch, (int)h->m_pos, 1);
+    DESC_HIP(hipMemcpyAsync(host, h->d_scratch, sizeof(double) * h->m_cycle, hipMemcpyDeviceToHost, h->stream));
+    DESC_HIP(hipStreamSynchronize(h->stream));
+    return DESC_OK;
+}
+int ensure_scratch(desc_pgd* h) {
+    if (h->d_scratch || h->variant != VARIANT_NODE) return DESC_OK;
+    return dalloc(h, &h->d_scratch, h->m_cycle);
 }
 
 }  // namespace
@@ -476,6 +1000,7 @@ int desc_pgd_create(const desc_problem* prob, const desc_structure* s, int32_t d
     if (!prob || !s) return fail(DESC_ERR_INVALID, "NULL argument");
     if (prob->m != s->m) return fail(DESC_ERR_INVALID, "structure was built for m = %lld, problem has m = %lld", (long long)s->m, (long long)prob->m);
     if (prob->m > 0 && !prob->rij) return fail(DESC_ERR_INVALID, "rij is NULL");
+    if (prob->n < s->n) return fail(DESC_ERR_INVALID, "problem n smaller than structure n");
     int ndev = desc_device_count();
     if (ndev < 0) return ndev;
     if (ndev == 0) return fail(DESC_ERR_HIP, "no HIP device visible: the DESC_PGD hot path has no CPU fallback");
@@ -484,90 +1009,37 @@ int desc_pgd_create(const desc_problem* prob, const desc_structure* s, int32_t d
     desc_pgd* h = new (std::nothrow) desc_pgd();
     if (!h) return fail(DESC_ERR_INVALID, "out of host memory");
     h->device = device;
-    h->n = s->n; h->m = s->m; h->m_pos = s->m_pos; h->m_cycle = s->m_cycle; h->max_cnt = s->max_cnt; h->n_sample = s->n_sample;
+    h->n = prob->n; h->m = s->m; h->m_pos = s->m_pos; h->m_cycle = s->m_cycle; h->max_cnt = s->max_cnt; h->n_sample = s->n_sample;
+    {
+        std::vector<int32_t> deg((size_t)h->n, 0);
+        for (int64_t e = 0; e < h->m; ++e) { deg[prob->ind_i[e]]++; deg[prob->ind_j[e]]++; }
+        for (int32_t d : deg) h->max_deg = std::max(h->max_deg, d);
+    }
     int rc = DESC_OK;
-    auto t0 = std::chrono::steady_clock::now();
-#define TRY(x) do { rc = (x); if (rc) { free_all(h); return rc; } } while (0)
-#define TRYHIP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { rc = fail(DESC_ERR_HIP, "%s: %s", #x, hipGetErrorString(_e)); free_all(h); return rc; } } while (0)
-    TRYHIP(hipSetDevice(device));
-    TRYHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    const int64_t m = h->m, mp = h->m_pos, mc = h->m_cycle;
-    TRY(dmalloc(&h->d_cum, mp + 1)); TRY(dmalloc(&h->d_pos_edge, mp));
-    TRY(dmalloc(&h->d_ejk, mc)); TRY(dmalloc(&h->d_eki, mc)); TRY(dmalloc(&h->d_ikj, mc)); TRY(dmalloc(&h->d_jki, mc));
-    TRY(dmalloc(&h->d_S0, mc)); TRY(dmalloc(&h->d_w[0], mc)); TRY(dmalloc(&h->d_w[1], mc));
-    TRY(dmalloc(&h->d_S[0], m)); TRY(dmalloc(&h->d_S[1], m));
-    TRY(dmalloc(&h->d_nv, (size_t)h->max_cnt + 1));
-    TRY(dmalloc(&h->d_state, 1));
+    hipError_t he = hipSetDevice(device);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) { rc = fail(DESC_ERR_HIP, "device %d: %s", device, hipGetErrorString(he)); free_all(h); return rc; }
 
-    // lanes per segment and grid
-    h->G = h->max_cnt <= 16 ? 16 : h->max_cnt <= 32 ? 32 : h->max_cnt <= 64 ? 64 : 0;
-    const int epw = h->G ? 64 / h->G : 1;
-    int64_t want = (mp + 4 * epw - 1) / (4 * epw);
-    if (want > 2048) want = 2048;
-    if (want < 8) want = 8;
-    h->grid = (int)((want + 7) / 8 * 8);
-    h->obj_grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (mc + 255) / 256));
-    TRY(dmalloc(&h->d_partials, 2 * (size_t)std::max(h->grid, h->obj_grid)));
-    char nm[64];
-    if (h->G) snprintf(nm, sizeof nm, "k_sweep<%d,", h->G); else snprintf(nm, sizeof nm, "k_sweep_big<");
-    h->kname = nm;
+    // variant: NODE unless the packed per-cycle word or the LDS column copies do not fit
+    const int forced = env_int("DESC_DEBUG_VARIANT", 0);
+    const bool node_ok = h->max_deg < 32768 && (size_t)(h->max_deg + 2) * 4 * 8 <= 64 * 1024 && h->max_cnt <= 64 && h->m_pos > 0;
+    h->variant = (forced == VARIANT_GATHER || !node_ok) ? VARIANT_GATHER : VARIANT_NODE;
 
-    // uploads
-    {
-        std::vector<int32_t> cum32((size_t)mp + 1);
-        for (int64_t l = 0; l <= mp; ++l) cum32[l] = (int32_t)s->cum_ind[l];
-        TRYHIP(hipMemcpyAsync(h->d_cum, cum32.data(), sizeof(int32_t) * (mp + 1), hipMemcpyHostToDevice, h->stream));
-        TRYHIP(hipStreamSynchronize(h->stream));
-    }
-    int32_t *d_k = nullptr, *d_ii = nullptr, *d_jj = nullptr; double* d_rij = nullptr;
-    auto cleanup_tmp = [&]() { if (d_k) (void)hipFree(d_k); if (d_ii) (void)hipFree(d_ii); if (d_jj) (void)hipFree(d_jj); if (d_rij) (void)hipFree(d_rij); };
-#define TRY2(x) do { rc = (x); if (rc) { cleanup_tmp(); free_all(h); return rc; } } while (0)
-#define TRYHIP2(x) do { hipError_t _e = (x); if (_e != hipSuccess) { rc = fail(DESC_ERR_HIP, "%s: %s", #x, hipGetErrorString(_e)); cleanup_tmp(); free_all(h); return rc; } } while (0)
-    TRY2(dmalloc(&d_k, mc)); TRY2(dmalloc(&d_ii, m)); TRY2(dmalloc(&d_jj, m)); TRY2(dmalloc(&d_rij, 9 * (size_t)m));
-    if (mp > 0) TRYHIP2(hipMemcpyAsync(h->d_pos_edge, s->pos_edge.data(), sizeof(int32_t) * mp, hipMemcpyHostToDevice, h->stream));
-    if (mc > 0) {
-        TRYHIP2(hipMemcpyAsync(h->d_ejk, s->e_jk.data(), sizeof(int32_t) * mc, hipMemcpyHostToDevice, h->stream));
-        TRYHIP2(hipMemcpyAsync(h->d_eki, s->e_ki.data(), sizeof(int32_t) * mc, hipMemcpyHostToDevice, h->stream));
-        TRYHIP2(hipMemcpyAsync(h->d_ikj, s->ikj.data(), sizeof(int32_t) * mc, hipMemcpyHostToDevice, h->stream));
-        TRYHIP2(hipMemcpyAsync(h->d_jki, s->jki.data(), sizeof(int32_t) * mc, hipMemcpyHostToDevice, h->stream));
-        TRYHIP2(hipMemcpyAsync(d_k, s->k.data(), sizeof(int32_t) * mc, hipMemcpyHostToDevice, h->stream));
-    }
-    if (m > 0) {
-        TRYHIP2(hipMemcpyAsync(d_ii, prob->ind_i, sizeof(int32_t) * m, hipMemcpyHostToDevice, h->stream));
-        TRYHIP2(hipMemcpyAsync(d_jj, prob->ind_j, sizeof(int32_t) * m, hipMemcpyHostToDevice, h->stream));
-        TRYHIP2(hipMemcpyAsync(d_rij, prob->rij, sizeof(double) * 9 * m, hipMemcpyHostToDevice, h->stream));
-    }
-    {
+    const int64_t mp = h->m_pos, mc = h->m_cycle;
+    auto A = [&](int r) { if (!rc) rc = r; };
+    A(dalloc(h, &h->d_cum, mp + 1));
+    A(dalloc(h, &h->d_S0, mc)); A(dalloc(h, &h->d_w[0], mc)); A(dalloc(h, &h->d_w[1], mc));
+    A(dalloc(h, &h->d_nv, (size_t)h->max_cnt + 1));
+    A(dalloc(h, &h->d_state, 1));
+    if (!rc) {
         std::vector<double> nv((size_t)h->max_cnt + 1, 0.0);
         for (int c = 1; c <= h->max_cnt; ++c) nv[c] = 1.0 / std::pow((double)c, 0.5);   // ones/(nsample^0.5), DESC_PGD.m:199
-        TRYHIP2(hipMemcpyAsync(h->d_nv, nv.data(), sizeof(double) * nv.size(), hipMemcpyHostToDevice, h->stream));
-        TRYHIP2(hipStreamSynchronize(h->stream));
+        rc = upload(h, h->d_nv, nv.data(), nv.size());
+        if (!rc) { hipError_t e = hipStreamSynchronize(h->stream); if (e != hipSuccess) rc = fail(DESC_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
     }
-    h->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-
-    // a-4: cycle inconsistencies
-    {
-        hipEvent_t e0, e1;
-        TRYHIP2(hipEventCreate(&e0)); TRYHIP2(hipEventCreate(&e1));
-        (void)hipEventRecord(e0, h->stream);
-        if (mp > 0) {
-            int g = (int)std::min<int64_t>(4096, (mp + 3) / 4);
-            hipLaunchKernelGGL(k_cycle_d, dim3(g), dim3(256), 0, h->stream, h->d_cum, h->d_pos_edge, d_ii, d_jj, d_k,
-                               h->d_ejk, h->d_eki, d_rij, h->d_S0, (int)mp);
-        }
-        (void)hipEventRecord(e1, h->stream);
-        hipError_t e = hipStreamSynchronize(h->stream);
-        if (e == hipSuccess) e = hipGetLastError();
-        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
-        h->ms_cycle_d = ms;
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        if (e != hipSuccess) { rc = fail(DESC_ERR_HIP, "k_cycle_d: %s", hipGetErrorString(e)); cleanup_tmp(); free_all(h); return rc; }
-    }
-    cleanup_tmp();
-#undef TRY
-#undef TRYHIP
-#undef TRY2
-#undef TRYHIP2
+    if (!rc) rc = (h->variant == VARIANT_NODE) ? setup_node(h, prob, s) : setup_gather(h, prob, s);
+    if (!rc) rc = dalloc(h, &h->d_partials, 2 * (size_t)std::max(h->grid, h->obj_grid));
+    if (rc) { free_all(h); return rc; }
     *out = h;
     return DESC_OK;
 }
@@ -588,8 +1060,8 @@ const char* desc_pgd_kernel_name(const desc_pgd* h) { return h ? h->kname.c_str(
 int desc_pgd_get_s0(desc_pgd* h, double* s0) {
     if (!h || !s0) return fail(DESC_ERR_INVALID, "NULL argument");
     int rc = set_device(h); if (rc) return rc;
-    if (h->m_cycle > 0) DESC_HIP(hipMemcpy(s0, h->d_S0, sizeof(double) * h->m_cycle, hipMemcpyDeviceToHost));
-    return DESC_OK;
+    if ((rc = ensure_scratch(h))) return rc;
+    return cycles_to_host(h, h->d_S0, s0);
 }
 
 int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
@@ -601,19 +1073,27 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
     int rc = set_device(h); if (rc) return rc;
     h->p = *p;
     if (h->p.patience <= 0) h->p.patience = 30;
+    {   // diagnostics only: never set in production runs
+        h->ablate = env_int("DESC_DEBUG_ABLATE", 0);
+        const int gr = env_int("DESC_DEBUG_GRID", 0);
+        if (gr >= 8 && gr / 8 * 8 != h->grid) {
+            dfree(h, h->d_partials); h->d_partials = nullptr;
+            h->grid = gr / 8 * 8;
+            rc = dalloc(h, &h->d_partials, 2 * (size_t)std::max(h->grid, h->obj_grid)); if (rc) return rc;
+        }
+    }
     h->t_done = 0; h->t_plugin = p->t0; h->ms_pgd = 0;
     const int cap = std::max(1, p->iters);
     if (cap > h->trace_cap) {
-        if (h->d_obj) (void)hipFree(h->d_obj);
-        if (h->d_avg) (void)hipFree(h->d_avg);
+        dfree(h, h->d_obj); dfree(h, h->d_avg);
         h->d_obj = h->d_avg = nullptr; h->trace_cap = 0;
-        rc = dmalloc(&h->d_obj, cap); if (rc) return rc;
-        rc = dmalloc(&h->d_avg, cap); if (rc) return rc;
+        rc = dalloc(h, &h->d_obj, cap); if (rc) return rc;
+        rc = dalloc(h, &h->d_avg, cap); if (rc) return rc;
         h->trace_cap = cap;
     }
     if (p->step_kind == DESC_STEP_HYBRID && p->hybrid_strategy == 0 && !h->d_adam_m) {
-        rc = dmalloc(&h->d_adam_m, h->m_cycle); if (rc) return rc;
-        rc = dmalloc(&h->d_adam_v, h->m_cycle); if (rc) return rc;
+        rc = dalloc(h, &h->d_adam_m, h->m_cycle); if (rc) return rc;
+        rc = dalloc(h, &h->d_adam_v, h->m_cycle); if (rc) return rc;
     }
     DESC_HIP(hipMemsetAsync(h->d_state, 0, sizeof(DevState), h->stream));
     DESC_HIP(hipMemsetAsync(h->d_obj, 0, sizeof(double) * h->trace_cap, h->stream));
@@ -622,15 +1102,18 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
         DESC_HIP(hipMemsetAsync(h->d_adam_m, 0, sizeof(double) * std::max<int64_t>(1, h->m_cycle), h->stream));
         DESC_HIP(hipMemsetAsync(h->d_adam_v, 0, sizeof(double) * std::max<int64_t>(1, h->m_cycle), h->stream));
     }
-    if (h->m > 0) {                                                       // S_vec = ones(1,m)  (:148)
-        int g = (int)std::min<int64_t>(1024, (h->m + 255) / 256);
-        hipLaunchKernelGGL(k_fill, dim3(g), dim3(256), 0, h->stream, h->d_S[0], h->m, 1.0);
-        hipLaunchKernelGGL(k_fill, dim3(g), dim3(256), 0, h->stream, h->d_S[1], h->m, 1.0);
+    const int64_t slen = h->variant == VARIANT_NODE ? 2 * h->m : h->m;
+    if (slen > 0) {                                                       // S_vec = ones(1,m)  (:148)
+        int g = (int)std::min<int64_t>(1024, (slen + 255) / 256);
+        hipLaunchKernelGGL(k_fill, dim3(g), dim3(256), 0, h->stream, h->d_S[0], slen, 1.0);
+        hipLaunchKernelGGL(k_fill, dim3(g), dim3(256), 0, h->stream, h->d_S[1], slen, 1.0);
     }
     if (h->m_pos > 0) {
         int g = (int)std::min<int64_t>(4096, (h->m_pos + 3) / 4);
-        hipLaunchKernelGGL(k_init, dim3(g), dim3(256), 0, h->stream, h->d_cum, h->d_pos_edge, h->d_S0, h->d_w[0],
-                           h->d_S[0], h->d_S[1], (int)h->m_pos);
+        if (h->variant == VARIANT_NODE)
+            hipLaunchKernelGGL(k_init_node, dim3(g), dim3(256), 0, h->stream, h->d_cum, h->d_einfo, h->d_S0, h->d_w[0], h->d_S[0], h->d_S[1], (int)h->m_pos);
+        else
+            hipLaunchKernelGGL(k_init, dim3(g), dim3(256), 0, h->stream, h->d_cum, h->d_pos_edge, h->d_S0, h->d_w[0], h->d_S[0], h->d_S[1], (int)h->m_pos);
     }
     DESC_HIP(hipGetLastError());
     h->armed = true;
@@ -695,8 +1178,12 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
     const int T = h->t_done;
     // objective of the last sweep (DESC_PGD.m:233) and its stop test
     if (h->m_pos > 0 && T >= 1) {
-        hipLaunchKernelGGL(k_objective, dim3(h->obj_grid), dim3(256), 0, h->stream, h->d_w[T & 1], h->d_S[T & 1], h->d_ejk,
-                           h->d_eki, h->m_cycle, h->d_partials, h->d_state);
+        if (h->variant == VARIANT_NODE)
+            hipLaunchKernelGGL(k_objective_node, dim3(h->obj_grid), dim3(256), 0, h->stream, h->d_cum, h->d_einfo, h->d_pk,
+                               h->d_w[T & 1], h->d_S[T & 1], (int)h->m_pos, h->d_partials, h->d_state);
+        else
+            hipLaunchKernelGGL(k_objective, dim3(h->obj_grid), dim3(256), 0, h->stream, h->d_w[T & 1], h->d_S[T & 1], h->d_ejk,
+                               h->d_eki, h->m_cycle, h->d_partials, h->d_state);
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, h->d_partials, h->obj_grid, h->d_state, h->d_obj,
                            h->d_avg, T, h->m, h->p.patience, h->p.stop_tol, 1);
     }
@@ -714,8 +1201,18 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
     }
     r->iters_run = iters_run;
     r->t_end = h->p.t0 + iters_run;
-    if (h->m > 0) DESC_HIP(hipMemcpy(r->s_vec, h->d_S[par], sizeof(double) * h->m, hipMemcpyDeviceToHost));
-    if (r->w && h->m_cycle > 0) DESC_HIP(hipMemcpy(r->w, h->d_w[par], sizeof(double) * h->m_cycle, hipMemcpyDeviceToHost));
+    if (h->m > 0) {
+        if (h->variant == VARIANT_NODE) {
+            int g = (int)std::min<int64_t>(1024, (h->m + 255) / 256);
+            hipLaunchKernelGGL(k_extract_S, dim3(g), dim3(256), 0, h->stream, h->d_S[par], h->d_eslot, h->d_Svec, h->m);
+            DESC_HIP(hipMemcpyAsync(r->s_vec, h->d_Svec, sizeof(double) * h->m, hipMemcpyDeviceToHost, h->stream));
+            DESC_HIP(hipStreamSynchronize(h->stream));
+        } else {
+            DESC_HIP(hipMemcpy(r->s_vec, h->d_S[par], sizeof(double) * h->m, hipMemcpyDeviceToHost));
+        }
+    }
+    if (r->w || (h->d_adam_m && r->adam_m && r->adam_v)) { rc = ensure_scratch(h); if (rc) return rc; }
+    if (r->w) { rc = cycles_to_host(h, h->d_w[par], r->w); if (rc) return rc; }
     if (r->obj_trace && iters_run > 0) {
         if (h->m_pos > 0) DESC_HIP(hipMemcpy(r->obj_trace, h->d_obj, sizeof(double) * iters_run, hipMemcpyDeviceToHost));
         else std::memset(r->obj_trace, 0, sizeof(double) * iters_run);
@@ -724,9 +1221,9 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
         if (h->m_pos > 0) DESC_HIP(hipMemcpy(r->avg_change_trace, h->d_avg, sizeof(double) * iters_run, hipMemcpyDeviceToHost));
         else std::memset(r->avg_change_trace, 0, sizeof(double) * iters_run);
     }
-    if (h->d_adam_m && r->adam_m && r->adam_v && h->m_cycle > 0) {
-        DESC_HIP(hipMemcpy(r->adam_m, h->d_adam_m, sizeof(double) * h->m_cycle, hipMemcpyDeviceToHost));
-        DESC_HIP(hipMemcpy(r->adam_v, h->d_adam_v, sizeof(double) * h->m_cycle, hipMemcpyDeviceToHost));
+    if (h->d_adam_m && r->adam_m && r->adam_v) {
+        rc = cycles_to_host(h, h->d_adam_m, r->adam_m); if (rc) return rc;
+        rc = cycles_to_host(h, h->d_adam_v, r->adam_v); if (rc) return rc;
     }
     r->ms_upload = h->ms_upload; r->ms_cycle_d = h->ms_cycle_d; r->ms_pgd = h->ms_pgd;
     return DESC_OK;
@@ -738,8 +1235,11 @@ int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r) {
     int rc = desc_pgd_reset(h, p); if (rc) return rc;
     if (p->step_kind == DESC_STEP_HYBRID && p->hybrid_strategy == 0 && p->t0 > 0 && r->adam_m && r->adam_v && h->m_cycle > 0) {
         // HybridGradient keeps m_t / v_t between calls (handle object)
-        DESC_HIP(hipMemcpyAsync(h->d_adam_m, r->adam_m, sizeof(double) * h->m_cycle, hipMemcpyHostToDevice, h->stream));
-        DESC_HIP(hipMemcpyAsync(h->d_adam_v, r->adam_v, sizeof(double) * h->m_cycle, hipMemcpyHostToDevice, h->stream));
+        rc = ensure_scratch(h); if (rc) return rc;
+        rc = cycles_to_device(h, r->adam_m, h->d_adam_m); if (rc) return rc;
+        DESC_HIP(hipStreamSynchronize(h->stream));
+        rc = cycles_to_device(h, r->adam_v, h->d_adam_v); if (rc) return rc;
+        DESC_HIP(hipStreamSynchronize(h->stream));
     }
     const int chunk = p->check_every > 0 ? p->check_every : 32;
     int left = p->iters;

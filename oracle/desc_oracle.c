@@ -46,6 +46,14 @@ uint64_t oracle_sample_key(uint64_t seed, uint64_t edge, uint64_t k) {
     return mix64(a ^ ((k + 1) * 0xD1B54A32D192ED03ull));
 }
 
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -44,7 +44,15 @@ def lib():
         so = os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(so):
             build()
+        # a GPU box exposes every host thread but grants ~16 CPUs: an OpenMP team of
+        # 256 spinning threads is pathologically slow there
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         _LIB = C.CDLL(so)
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        _LIB.oracle_set_threads(int(os.environ.get("ORACLE_THREADS", min(16, avail))))
         _LIB.oracle_sample_key.restype = C.c_uint64
         _LIB.oracle_sample_key.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         _LIB.oracle_num_threads.restype = C.c_int
