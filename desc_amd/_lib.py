@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdesc_amd.so")
+LIB_PATH = os.environ.get("DESC_AMD_LIB", os.path.join(HERE, "libdesc_amd.so"))   # override: diagnostic builds only
 
 DESC_OK = 0
 STEP_CONSTANT, STEP_PIECEWISE, STEP_HYBRID = 0, 1, 2

@@ -15,13 +15,46 @@
 
 namespace desc {
 
-// One DPP-moved copy of a double (two 32-bit v_mov_b32_dpp).
+// One DPP-moved copy of a double (two 32-bit v_mov_b32_dpp).  All four controls used
+// here are permutations of the full wave, so every lane is written and no `old` value
+// has to be preserved (mov_dpp leaves it undefined: no extra register copy).
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov_i32(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+
+// sums over aligned groups of 8 lanes (half a DPP row); every lane gets its group's total
+__device__ __forceinline__ double group8_sum(double v) {
+    v += dpp_mov_f64<0xB1>(v);    // quad_perm:[1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);    // quad_perm:[2,3,0,1]
+    v += dpp_mov_f64<0x141>(v);   // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ int group8_sum(int v) {
+    v += dpp_mov_i32<0xB1>(v);
+    v += dpp_mov_i32<0x4E>(v);
+    v += dpp_mov_i32<0x141>(v);
+    return v;
+}
+// sums over one DPP row (16 lanes); every lane gets its row's total
+__device__ __forceinline__ double group16_sum(double v) {
+    v += dpp_mov_f64<0xB1>(v);
+    v += dpp_mov_f64<0x4E>(v);
+    v += dpp_mov_f64<0x141>(v);
+    v += dpp_mov_f64<0x140>(v);   // row_mirror
+    return v;
+}
+__device__ __forceinline__ int group16_sum(int v) {
+    v += dpp_mov_i32<0xB1>(v);
+    v += dpp_mov_i32<0x4E>(v);
+    v += dpp_mov_i32<0x141>(v);
+    v += dpp_mov_i32<0x140>(v);
+    return v;
 }
 // v_permlane16_swap: exchanges the odd 16-lane rows of the first operand with the
 // even rows of the second; with both operands = v the two results are
@@ -62,6 +95,14 @@ __device__ __forceinline__ int group_count(bool pred, int lane) {
     if (G == 64) return __popcll(mk);
     constexpr unsigned long long field = (G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull);
     return __popcll((mk >> ((lane / G) * G)) & field);
+}
+
+// Wave-uniform load through the scalar cache (s_load_dword, counted by lgkmcnt, not by
+// the in-order vmcnt the software pipelines rely on).  Only for tables that no kernel
+// writes while it runs; the index must be wave-uniform.
+__device__ __forceinline__ int uniform_load(const int32_t* p, int i) {
+    typedef const int32_t __attribute__((address_space(4)))* cptr_t;
+    return ((cptr_t)(unsigned long long)p)[i];
 }
 
 // Blocks b and b+8 share an XCD (round-robin dispatch, observed; speed only).

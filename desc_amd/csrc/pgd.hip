@@ -126,16 +126,19 @@ __device__ __forceinline__ double cycle_trace(const double* A, const double* pb,
     return tr;
 }
 
+// deterministic workgroup partials (blockDim 256 or 512)
 __device__ __forceinline__ void block_partials(double obj_acc, double chg_acc, double* partials, int lb) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     obj_acc = group_sum<64>(obj_acc);
     chg_acc = group_sum<64>(chg_acc);
-    __shared__ double sh[8];
-    if (lane == 0) { sh[wv] = obj_acc; sh[4 + wv] = chg_acc; }
+    __shared__ double sh[16];
+    if (lane == 0) { sh[wv] = obj_acc; sh[8 + wv] = chg_acc; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        partials[2 * lb] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-        partials[2 * lb + 1] = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+        double o = 0.0, c = 0.0;
+        for (int k = 0; k < nw; ++k) { o += sh[k]; c += sh[8 + k]; }
+        partials[2 * lb] = o;
+        partials[2 * lb + 1] = c;
     }
 }
 
@@ -351,6 +354,26 @@ struct EdgeInfo {
 // packed per-cycle word: bits 0-14 idx_i(k), bit 15 cycle (ik;j) sampled (IKJ_appears, :113),
 //                        bits 16-30 idx_j(k), bit 31 cycle (jk;i) sampled (JKI_appears, :124)
 
+// Diagnostic build only (-DDESC_STAMPS, tools/): per-phase s_memtime shares of the sweep,
+// written to a buffer of their own; no stamp executes in the production library.
+#ifdef DESC_STAMPS
+#define STAMP(slot)                                                                      \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        unsigned long long _t;                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        if (tid == 0) stamp_acc[slot] += _t - stamp_last;                                \
+        stamp_last = _t;                                                                 \
+    } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
+constexpr int CHUNK_LDS = 960;    // entries of the LDS image of a chunk
+constexpr int CHUNK_CAP = CHUNK_LDS - 4;   // cycles per chunk: the image starts up to 3 entries before the chunk (16-byte alignment)
+constexpr int CHUNK_SEG = 64;     // segments per chunk
+
 struct NodeSweepArgs {
     const int32_t* cum;        // m_pos+1, device order
     const EdgeInfo* einfo;     // m_pos
@@ -364,92 +387,319 @@ struct NodeSweepArgs {
     const double* nv_tab;
     double* partials;
     const DevState* state;
+    const int32_t* chunk_seg;  // nchunks+1: first segment of every chunk
+    const int32_t* chunk_c0;   // nchunks+1: first cycle of every chunk
     StepArgs st;
-    int32_t m_pos;
+    int32_t nchunks;
+    int32_t max_cnt;
     int32_t ablate;
+    unsigned long long* stamps;   // diagnostic build only: [grid][8] cycle sums per phase
 };
 
-template <int G, int STEP>
-__global__ __launch_bounds__(256) void k_sweep_node(NodeSweepArgs a) {
+// Per-chunk segment records in LDS
+struct SegRec {
+    int base[CHUNK_SEG + 1];                 // first cycle of each segment (+ end)
+    int rbi[CHUNK_SEG], rbj[CHUNK_SEG];      // rowptr[i], rowptr[j]
+    int sa[CHUNK_SEG], sb[CHUNK_SEG];        // slots of the edge in rows i and j
+    double T1[CHUNK_SEG], T2[CHUNK_SEG], So[CHUNK_SEG];
+};
+// LDS image of one chunk.  Entry q' = (cycle - a0) where a0 = c0 & ~3 is the chunk's first
+// cycle rounded down to a 16-byte boundary of the packed-word array, so that every
+// streaming load / store is a 16-byte access.
+struct alignas(16) ChunkBuf {
+    double w[CHUNK_LDS], d[CHUNK_LDS], ss[CHUNK_LDS];
+    uint32_t pk[CHUNK_LDS];
+};
+constexpr int SWEEP_THREADS = 512;
+
+struct StreamRegs { uint4 pk; double2 w, d; };   // one 16-byte vector of each streamed array
+
+// Sweep over chunks of consecutive segments (<= CHUNK_CAP cycles, <= CHUNK_SEG segments
+// per workgroup pass), software-pipelined with double-buffered LDS.  While chunk i is
+// computed out of LDS, the row gathers S(jk), S(ki) of chunk i+1 and the 16-byte streaming
+// loads of chunks i+2 and i+3 are in flight (two register sets, loop unrolled by two).
+// gfx950 retires loads AND stores through one in-order counter (vmcnt), so (1) loads are
+// issued in the order in which they are consumed, (2) every pipelined load is
+// unconditional (clamped index instead of a branch) so the compiler can count them and
+// emit exact vmcnt(N) waits, (3) the chunk's stores are the youngest memory operations of
+// an iteration.
+//   iteration i:
+//     1  [streaming registers of chunk i+1 landed] park pk, w, d in LDS buffer (i+1)&1;
+//        segment id of every cycle of chunk i+1
+//     2  issue its row gathers (2 per cycle) and its per-edge T1/T2/S_old loads
+//     3  issue segment-record loads of chunk i+2 and streaming loads of chunk i+3
+//     4  D(i): per-segment arithmetic out of LDS buffer i&1 -- 16 lanes per segment,
+//        E cycles per lane, 4 segments per wave pass; results stay in LDS
+//     5  16-byte stores of w_new, S_new of chunk i
+//     6  [gathers landed] S(jk)+S(ki) and T1/T2/S_old of chunk i+1 -> LDS; publish the
+//        segment records of chunk i+2
+template <int E, int STEP>
+__global__ __launch_bounds__(SWEEP_THREADS, 4) void k_sweep_node(NodeSweepArgs a) {
+    __shared__ ChunkBuf X[2];
+    __shared__ SegRec R[2];
+    __shared__ uint8_t c_seg[CHUNK_LDS];
+    __shared__ double s_nv[65];
     if (a.state->stop) return;
-    constexpr int EPW = 64 / G;
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    const int sub = lane / G, gl = lane % G;
+    constexpr int NT = SWEEP_THREADS, NW = NT / 64;
+    constexpr int U = (CHUNK_LDS + NT - 1) / NT;          // cycles per thread in the gather step
+    static_assert(CHUNK_LDS / 2 <= NT, "one 16-byte vector of w per thread");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int grp = lane >> 4, r16 = lane & 15;
     const int nb = gridDim.x;
     const int lb = xcd_logical_block(blockIdx.x, nb);
-    const int per_block = (a.m_pos + nb - 1) / nb;
-    const int lo_edge = lb * per_block;
-    const int hi_edge = min(a.m_pos, lo_edge + per_block);
-
+    const int per_block = (a.nchunks + nb - 1) / nb;
+    const int ch_lo = lb * per_block;
+    const int ch_hi = min(a.nchunks, ch_lo + per_block);
     double obj_acc = 0.0, chg_acc = 0.0;
-    for (int l0 = lo_edge + wv * EPW; l0 < hi_edge; l0 += 4 * EPW) {
-        const int l = l0 + sub;
-        const bool edge_ok = l < hi_edge;
-        int base = 0, cnt = 0;
-        EdgeInfo ei{0, 0, 0, 0};
-        double T1 = 0.0, T2 = 0.0;
-        if (edge_ok) {
-            base = a.cum[l]; cnt = a.cum[l + 1] - base;
-            ei = a.einfo[l];
-            T1 = a.Tfull[ei.slot_a];            // column j of node i  = sum(wijk(IKJ(mask)))  (:189)
-            T2 = a.Tfull[ei.slot_b];            // column i of node j  = sum(wijk(JKI(mask)))  (:190)
+    if (ch_lo >= ch_hi) { block_partials(obj_acc, chg_acc, a.partials, lb); return; }
+
+    if (tid <= 64) s_nv[tid] = tid <= a.max_cnt ? a.nv_tab[tid] : 0.0;
+    StreamRegs SA{}, SB{};                                   // chunks ch_lo+even -> SA, ch_lo+odd -> SB
+    double sjk[U], ski[U];
+    int r_base = 0; EdgeInfo r_ei{0, 0, 0, 0}; double r_T1 = 0.0, r_T2 = 0.0, r_So = 0.0;
+#ifdef DESC_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = 0;
+#endif
+
+    auto load_records = [&](int ch) {            // cum / einfo of chunk ch -> registers (clamped, unconditional)
+        const int l0 = uniform_load(a.chunk_seg, ch), ns = uniform_load(a.chunk_seg, ch + 1) - l0;
+        r_base = a.cum[l0 + min(tid, ns)];
+        r_ei = a.einfo[l0 + min(tid, ns - 1)];
+    };
+    auto publish_records = [&](int ch, SegRec& rr) {
+        const int ns = uniform_load(a.chunk_seg, ch + 1) - uniform_load(a.chunk_seg, ch);
+        if (tid <= ns) rr.base[tid] = r_base;
+        if (tid < ns) { rr.rbi[tid] = r_ei.rb_i; rr.rbj[tid] = r_ei.rb_j; rr.sa[tid] = r_ei.slot_a; rr.sb[tid] = r_ei.slot_b; }
+    };
+    // (register sets are passed and returned BY VALUE: a reference to a local struct would
+    //  push it to scratch memory)
+    auto load_stream = [&](int ch) -> StreamRegs {            // 16-byte loads; image entry 0 = cycle a0 = c0 & ~3
+        const int c0 = uniform_load(a.chunk_c0, ch), c1 = uniform_load(a.chunk_c0, ch + 1);
+        const int a0 = c0 & ~3, last = c1 - 1 - a0;          // last image entry that is needed
+        const int v2 = min(tid, last >> 1), v4 = min(tid, last >> 2);
+        StreamRegs sr;
+        sr.w = *reinterpret_cast<const double2*>(a.w_old + a0 + 2 * (int64_t)v2);
+        sr.d = *reinterpret_cast<const double2*>(a.S0 + a0 + 2 * (int64_t)v2);
+        sr.pk = *reinterpret_cast<const uint4*>(a.pk + a0 + 4 * (int64_t)v4);
+        return sr;
+    };
+    auto park_stream_and_fill = [&](int ch, const StreamRegs sr, const SegRec& rr, ChunkBuf& xb) {
+        const int c0 = uniform_load(a.chunk_c0, ch), c1 = uniform_load(a.chunk_c0, ch + 1);
+        const int a0 = c0 & ~3, last = c1 - 1 - a0, ns = uniform_load(a.chunk_seg, ch + 1) - uniform_load(a.chunk_seg, ch);
+        if (tid <= (last >> 1)) { *reinterpret_cast<double2*>(&xb.w[2 * tid]) = sr.w; *reinterpret_cast<double2*>(&xb.d[2 * tid]) = sr.d; }
+        if (tid <= (last >> 2)) *reinterpret_cast<uint4*>(&xb.pk[4 * tid]) = sr.pk;
+        for (int t = wv; t < ns; t += NW) {
+            const int b = rr.base[t] - a0, cnt = rr.base[t + 1] - rr.base[t];
+            for (int q = lane; q < cnt; q += 64) c_seg[b + q] = (uint8_t)t;
         }
-        const bool act0 = gl < cnt;
-        const int64_t c = (int64_t)base + gl;
-        double w = 0.0, d = 0.0, ssum = 0.0;
-        uint32_t p = 0;
-        if (act0) {
-            p = a.pk[c];
-            w = a.w_old[c]; d = a.S0[c];
-            const int si = ei.rb_i + (int)(p & 0x7FFFu), sj = ei.rb_j + (int)((p >> 16) & 0x7FFFu);
-            ssum = (a.ablate & 1) ? 1.0 + 1e-9 * (double)(si + sj) : a.S_old[sj] + a.S_old[si];   // S(jk)+S(ki)
+    };
+    auto issue_gathers = [&](int ch, const SegRec& rr, const ChunkBuf& xb) {
+        const int c0 = uniform_load(a.chunk_c0, ch), c1 = uniform_load(a.chunk_c0, ch + 1);
+        const int off = c0 & 3, hi = off + (c1 - c0) - 1, ns = uniform_load(a.chunk_seg, ch + 1) - uniform_load(a.chunk_seg, ch);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {          // all 2U gathers go out before any is consumed
+            const int q = min(max(tid + NT * u, off), hi);
+            const int sg = c_seg[q];
+            const uint32_t p = xb.pk[q];
+            int si = rr.rbi[sg] + (int)(p & 0x7FFFu), sj = rr.rbj[sg] + (int)((p >> 16) & 0x7FFFu);
+            if (a.ablate & 1) { si = lane; sj = lane; }     // diagnostics: gathers that always hit L1
+            sjk[u] = a.S_old[sj]; ski[u] = a.S_old[si];
         }
-        obj_acc += w * ssum;
-        double g = ssum + (((p & 0x8000u) ? T1 : 0.0) + ((p & 0x80000000u) ? T2 : 0.0)) * d;     // :193
-        const double nv = act0 ? a.nv_tab[cnt] : 0.0;
-        const double dot = group_sum<G>(act0 ? g * nv : 0.0);                                    // :199-201
-        g = g - dot * nv;
-        const double ws = act0 ? apply_step<STEP>(a.st, w, g, c) : 0.0;                          // :207
-        const double T = simplex_threshold<G>(ws, act0, lane, a.ablate & 4);                     // :215-223
-        const double wn = act0 ? fmax(ws - T, 0.0) : 0.0;                                        // :224
-        const double snew = group_sum<G>(wn * d);                                                // :229
-        if (act0) a.w_new[c] = wn;
-        if (edge_ok && gl == 0) {
-            chg_acc += fabs(snew - a.S_old[ei.slot_a]);                                          // :232
-            a.S_new[ei.slot_a] = snew;
-            a.S_new[ei.slot_b] = snew;
+        const int tt = min(tid, ns - 1);
+        const int sa = rr.sa[tt], sb = rr.sb[tt];
+        r_T1 = a.Tfull[sa];                     // column j of node i = sum(wijk(IKJ(mask)))  (:189)
+        r_T2 = a.Tfull[sb];                     // column i of node j = sum(wijk(JKI(mask)))  (:190)
+        r_So = a.S_old[sa];
+    };
+    auto park_gathers = [&](int ch, SegRec& rr, ChunkBuf& xb) {
+        const int c0 = uniform_load(a.chunk_c0, ch), c1 = uniform_load(a.chunk_c0, ch + 1);
+        const int off = c0 & 3, hi = off + (c1 - c0) - 1, ns = uniform_load(a.chunk_seg, ch + 1) - uniform_load(a.chunk_seg, ch);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = tid + NT * u;
+            if (q >= off && q <= hi) xb.ss[q] = sjk[u] + ski[u];                                     // S(jk)+S(ki)
         }
+        if (tid < ns) { rr.T1[tid] = r_T1; rr.T2[tid] = r_T2; rr.So[tid] = r_So; }
+    };
+
+    // one pipeline iteration; s1 = register set of chunk ch+1 (and, after parking, of chunk ch+3)
+    auto iterate = [&](int ch, StreamRegs s1) -> StreamRegs {
+        const bool has1 = ch + 1 < ch_hi, has2 = ch + 2 < ch_hi, has3 = ch + 3 < ch_hi;
+        SegRec& rc = R[ch & 1];
+        ChunkBuf& xc = X[ch & 1];
+        SegRec& rn = R[(ch + 1) & 1];
+        ChunkBuf& xn = X[(ch + 1) & 1];
+        STAMP(7);
+        __syncthreads();                                        // chunk ch staged, records of ch+1 visible
+        STAMP(0);
+        // ---- 1: chunk ch+1: park the streamed arrays, segment ids
+        if (has1) park_stream_and_fill(ch + 1, s1, rn, xn);
+        __syncthreads();
+        STAMP(1);
+        // ---- 2: its gathers
+        if (has1) issue_gathers(ch + 1, rn, xn);
+        STAMP(2);
+        // ---- 3: records of chunk ch+2, stream of chunk ch+3
+        if (has2) load_records(ch + 2);
+        if (has3) s1 = load_stream(ch + 3);
+        STAMP(3);
+        // ---- 4: D(ch)
+        const int c0 = uniform_load(a.chunk_c0, ch), c1 = uniform_load(a.chunk_c0, ch + 1), a0 = c0 & ~3;
+        const int nseg = uniform_load(a.chunk_seg, ch + 1) - uniform_load(a.chunk_seg, ch);
+        for (int t0 = wv * 4; t0 < ((a.ablate & 64) ? 0 : nseg); t0 += 4 * NW) {
+            const int t = t0 + grp;
+            const bool edge_ok = t < nseg;
+            int base = 0, cnt = 0;
+            double T1 = 0.0, T2 = 0.0, nv = 0.0;
+            if (edge_ok) { base = rc.base[t] - a0; cnt = rc.base[t + 1] - rc.base[t]; T1 = rc.T1[t]; T2 = rc.T2[t]; nv = s_nv[cnt]; }
+            double ws[E];                      // gradient, then stepped weight, of this lane's E cycles
+            uint32_t okm = 0;
+            double part = 0.0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int idx = r16 + 16 * e;
+                const bool ok = idx < cnt;
+                const int q = base + idx;
+                uint32_t p = 0; double w = 0.0, d = 0.0, ss = 0.0;
+                if (ok) { p = xc.pk[q]; w = xc.w[q]; d = xc.d[q]; ss = xc.ss[q]; okm |= 1u << e; }
+                obj_acc += w * ss;                                                                   // :233, one sweep late
+                const double g = ss + (((p & 0x8000u) ? T1 : 0.0) + ((p & 0x80000000u) ? T2 : 0.0)) * d;   // :193
+                ws[e] = g;
+                part += ok ? g * nv : 0.0;
+            }
+            const double dot = group16_sum(part);                                                    // :199-201
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int q = base + r16 + 16 * e;
+                const double g = ws[e] - dot * nv;
+                ws[e] = ((okm >> e) & 1u) ? apply_step<STEP>(a.st, xc.w[q], g, (int64_t)a0 + q) : 0.0;   // :207
+            }
+            // simplex projection threshold (:215-223), Michelot fixed point; the comparison
+            // ws*na > s-1 is ws > (s-1)/na without a division per pass
+            uint32_t act = okm;
+            double s1v = 0.0; int na = 1;
+            for (;;) {
+                double sp = 0.0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) sp += ((act >> e) & 1u) ? ws[e] : 0.0;
+                s1v = group16_sum(sp) - 1.0;
+                na = max(group16_sum((int)__popc(act)), 1);
+                const double nad = (double)na;
+                uint32_t keep = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) keep |= (((act >> e) & 1u) && ws[e] * nad > s1v) ? 1u << e : 0u;
+                const bool changed = keep != act;
+                act = keep;
+                if (!__any(changed) || (a.ablate & 4)) break;
+            }
+            const double T = s1v / (double)na;
+            double sn = 0.0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if ((okm >> e) & 1u) {
+                    const int q = base + r16 + 16 * e;
+                    const double wn = fmax(ws[e] - T, 0.0);                                          // :224
+                    xc.w[q] = wn;
+                    sn += wn * xc.d[q];
+                }
+            }
+            const double snew = group16_sum(sn);                                                     // :229
+            if (edge_ok && r16 == 0) {
+                chg_acc += fabs(snew - rc.So[t]);                                                    // :232
+                rc.T1[t] = snew;
+            }
+        }
+        STAMP(4);
+        __syncthreads();                                        // results of chunk ch complete in LDS
+        STAMP(5);
+        // ---- 5: stores of chunk ch: 16 bytes per lane, 8 at the two ragged ends
+        {
+            const int off = c0 - a0, hi = off + (c1 - c0) - 1;  // valid image entries [off, hi]
+            const int e0 = 2 * tid, e1 = 2 * tid + 1;
+            if (a.ablate & 128) {}
+            else if (e0 >= off && e1 <= hi) *reinterpret_cast<double2*>(a.w_new + a0 + e0) = *reinterpret_cast<const double2*>(&xc.w[e0]);
+            else if (e0 >= off && e0 <= hi) a.w_new[(int64_t)a0 + e0] = xc.w[e0];
+            else if (e1 >= off && e1 <= hi) a.w_new[(int64_t)a0 + e1] = xc.w[e1];
+        }
+        if (tid < nseg) { const double sv = rc.T1[tid]; a.S_new[rc.sa[tid]] = sv; a.S_new[rc.sb[tid]] = sv; }
+        STAMP(6);
+        // ---- 6: chunk ch+1 complete in LDS; records of chunk ch+2 published
+        if (has1) park_gathers(ch + 1, rn, xn);
+        if (has2) publish_records(ch + 2, rc);
+        return s1;
+    };
+
+    // ---- prologue: chunk ch_lo fully staged; ch_lo+1 and ch_lo+2 streaming
+    load_records(ch_lo);
+    SA = load_stream(ch_lo);
+    publish_records(ch_lo, R[ch_lo & 1]);
+    __syncthreads();
+    park_stream_and_fill(ch_lo, SA, R[ch_lo & 1], X[ch_lo & 1]);
+    __syncthreads();
+    issue_gathers(ch_lo, R[ch_lo & 1], X[ch_lo & 1]);
+    if (ch_lo + 1 < ch_hi) { load_records(ch_lo + 1); SB = load_stream(ch_lo + 1); }
+    if (ch_lo + 2 < ch_hi) SA = load_stream(ch_lo + 2);
+    park_gathers(ch_lo, R[ch_lo & 1], X[ch_lo & 1]);
+    if (ch_lo + 1 < ch_hi) publish_records(ch_lo + 1, R[(ch_lo + 1) & 1]);
+
+    for (int ch = ch_lo; ch < ch_hi; ch += 2) {
+        SB = iterate(ch, SB);                                   // chunk ch+1 (odd offset) lives in SB
+        if (ch + 1 < ch_hi) SA = iterate(ch + 1, SA);
     }
+#ifdef DESC_STAMPS
+    if (tid == 0 && a.stamps) for (int k = 0; k < 8; ++k) a.stamps[8 * lb + k] = stamp_acc[k];
+#endif
     block_partials(obj_acc, chg_acc, a.partials, lb);
 }
 
 // Mirror-weight column sums (DESC_PGD.m:185-191 in node form).  One workgroup per node
 // v: for every incident edge {v,u} (CSR order) stream its segment; a cycle with third
 // vertex t adds its weight to column idx_v(t) if the reverse cycle ({v,t};u) was sampled.
-// Each wave owns a private copy of the columns in LDS (segments are assigned to waves
-// round-robin, third vertices inside a segment are distinct), copies are added in a
-// fixed order at the end.
-__global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, const int32_t* adj_pos, const int32_t* cum,
-                                                     const EdgeInfo* einfo, const uint32_t* pk, const double* w,
+// Each wave owns a private copy of the columns in LDS (segments are dealt to waves
+// round-robin; third vertices inside a segment are distinct), copies are added in a
+// fixed order at the end -> bitwise reproducible.  Loads of COLSUM_U segments are in
+// flight per wave at once.
+constexpr int COLSUM_U = 16;
+__global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, const int2* adj_seg, const uint32_t* pk, const double* w,
                                                      double* Tfull, int n, int stride_cols, const DevState* st) {
     if (st->stop) return;
-    extern __shared__ double acc[];      // [4][stride_cols]
+    extern __shared__ double acc[];                   // [4][stride_cols] doubles, then 2 ints per incident edge
+    int* seg_base = (int*)(acc + 4 * stride_cols);
+    int* seg_cf = seg_base + stride_cols;             // cnt | (v is the smaller endpoint) << 31
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int v = blockIdx.x; v < n; v += gridDim.x) {
         const int r0 = rowptr[v], deg = rowptr[v + 1] - r0;
+        if (deg == 0) continue;
         for (int t = threadIdx.x; t < 4 * stride_cols; t += 256) acc[t] = 0.0;
+        for (int t = threadIdx.x; t < deg; t += 256) {     // CSR-aligned segment records: one coalesced load
+            const int2 rec = adj_seg[r0 + t];
+            seg_base[t] = rec.x; seg_cf[t] = rec.y;
+        }
         __syncthreads();
         double* mine = acc + wv * stride_cols;
-        for (int t = wv; t < deg; t += 4) {
-            const int l = adj_pos[r0 + t];
-            if (l < 0) continue;                       // edge without cycles (wave-uniform)
-            const int base = cum[l], cnt = cum[l + 1] - base;
-            const bool v_is_i = einfo[l].rb_i == r0;
-            for (int q = lane; q < cnt; q += 64) {
-                const uint32_t p = pk[(int64_t)base + q];
-                const uint32_t half = v_is_i ? (p & 0xFFFFu) : (p >> 16);
-                if (half & 0x8000u) mine[half & 0x7FFFu] += w[(int64_t)base + q];
+        for (int t = wv; t < deg; t += 4 * COLSUM_U) {
+            uint32_t pv[COLSUM_U]; double wvv[COLSUM_U]; uint32_t sh[COLSUM_U];
+            // issue every load of the batch before touching any result (no use between loads:
+            // the compiler would otherwise wait for each one)
+#pragma unroll
+            for (int u = 0; u < COLSUM_U; ++u) {
+                const int tt = t + 4 * u;
+                pv[u] = 0; wvv[u] = 0.0; sh[u] = 16;
+                if (tt < deg) {
+                    const uint32_t cf = (uint32_t)seg_cf[tt];
+                    sh[u] = (cf & 0x80000000u) ? 0u : 16u;
+                    if (lane < (int)(cf & 0x7FFFFFFFu)) {
+                        const int64_t c = (int64_t)seg_base[tt] + lane;
+                        pv[u] = pk[c];
+                        wvv[u] = w[c];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < COLSUM_U; ++u) {
+                const uint32_t half = (pv[u] >> sh[u]) & 0xFFFFu;
+                if (half & 0x8000u) unsafeAtomicAdd(&mine[half & 0x7FFFu], wvv[u]);   // ds_add_f64; same-wave adds stay in program order
             }
         }
         __syncthreads();
@@ -626,8 +876,11 @@ struct desc_pgd {
     // node variant
     EdgeInfo* d_einfo = nullptr;
     uint32_t* d_pk = nullptr;
-    int32_t *d_rowptr = nullptr, *d_adj_pos = nullptr, *d_src_start = nullptr, *d_eslot = nullptr;
+    int2* d_adj_seg = nullptr;   // per CSR slot: {first cycle of the incident edge's segment, cnt | (row node is the smaller endpoint) << 31}
+    int32_t *d_rowptr = nullptr, *d_src_start = nullptr, *d_eslot = nullptr, *d_chunk_seg = nullptr, *d_chunk_c0 = nullptr;
+    int nchunks = 0;
     double *d_T = nullptr, *d_Svec = nullptr;
+    unsigned long long* d_stamps = nullptr;
     int trace_cap = 0;
     // run state
     desc_params p{};
@@ -722,11 +975,11 @@ void launch_gather(desc_pgd* h, const SweepArgs& a) {
 }
 template <int STEP>
 void launch_node(desc_pgd* h, const NodeSweepArgs& a) {
-    dim3 grid(h->grid), block(256);
-    switch (h->G) {
-        case 16: hipLaunchKernelGGL((k_sweep_node<16, STEP>), grid, block, 0, h->stream, a); break;
-        case 32: hipLaunchKernelGGL((k_sweep_node<32, STEP>), grid, block, 0, h->stream, a); break;
-        default: hipLaunchKernelGGL((k_sweep_node<64, STEP>), grid, block, 0, h->stream, a); break;
+    dim3 grid(h->grid), block(SWEEP_THREADS);
+    switch (h->G) {              // G = cycles per lane (E) in the node variant
+        case 1: hipLaunchKernelGGL((k_sweep_node<1, STEP>), grid, block, 0, h->stream, a); break;
+        case 2: hipLaunchKernelGGL((k_sweep_node<2, STEP>), grid, block, 0, h->stream, a); break;
+        default: hipLaunchKernelGGL((k_sweep_node<4, STEP>), grid, block, 0, h->stream, a); break;
     }
 }
 
@@ -738,13 +991,13 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
     const StepArgs st = make_step(h, &adam);
     if (ev0) (void)hipEventRecord(ev0, h->stream);
     if (h->variant == VARIANT_NODE) {
-        hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid), dim3(256), sizeof(double) * 4 * h->colsum_stride, h->stream,
-                           h->d_rowptr, h->d_adj_pos, h->d_cum, h->d_einfo, h->d_pk, h->d_w[rd], h->d_T, (int)h->n,
+        hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 2 * sizeof(int)), h->stream,
+                           h->d_rowptr, h->d_adj_seg, h->d_pk, h->d_w[rd], h->d_T, (int)h->n,
                            h->colsum_stride, h->d_state);
         NodeSweepArgs a{};
         a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
         a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->d_T; a.nv_tab = h->d_nv; a.partials = h->d_partials;
-        a.state = h->d_state; a.st = st; a.m_pos = (int32_t)h->m_pos; a.ablate = h->ablate;
+        a.state = h->d_state; a.st = st; a.chunk_seg = h->d_chunk_seg; a.chunk_c0 = h->d_chunk_c0; a.nchunks = h->nchunks; a.max_cnt = h->max_cnt; a.ablate = h->ablate; a.stamps = h->d_stamps;
         if (adam) launch_node<DESC_STEP_HYBRID>(h, a); else launch_node<DESC_STEP_CONSTANT>(h, a);
     } else {
         SweepArgs a{};
@@ -887,8 +1140,16 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
             einfo[q] = EdgeInfo{rowptr[i], rowptr[j], eslot[e], rowptr[j] + idx_in_row(j, i)};
         }
     });
-    std::vector<int32_t> adj_pos((size_t)2 * m);
-    host_parallel(2 * m, [&](int64_t a, int64_t b) { for (int64_t t = a; t < b; ++t) adj_pos[t] = devpos[adj_eid[t]]; });
+    std::vector<int2> adj_seg((size_t)2 * m);
+    host_parallel(n, [&](int64_t a, int64_t b) {
+        for (int64_t v = a; v < b; ++v)
+            for (int32_t t = rowptr[v]; t < rowptr[v + 1]; ++t) {
+                const int32_t q = devpos[adj_eid[t]];
+                int2 rec{0, 0};
+                if (q >= 0) { rec.x = cum2[q]; rec.y = (int)((uint32_t)(cum2[q + 1] - cum2[q]) | (v < adj[t] ? 0x80000000u : 0u)); }
+                adj_seg[t] = rec;
+            }
+    });
     // k with the two mirror-present bits, natural order
     std::vector<uint32_t> kf((size_t)mc);
     host_parallel(mc, [&](int64_t a, int64_t b) {
@@ -898,9 +1159,9 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
 
     int rc;
     if ((rc = dalloc(h, &h->d_einfo, mp))) return rc;
-    if ((rc = dalloc(h, &h->d_pk, mc))) return rc;
+    if ((rc = dalloc(h, &h->d_pk, mc + 8))) return rc;
     if ((rc = dalloc(h, &h->d_rowptr, n + 1))) return rc;
-    if ((rc = dalloc(h, &h->d_adj_pos, 2 * m))) return rc;
+    if ((rc = dalloc(h, &h->d_adj_seg, 2 * m))) return rc;
     if ((rc = dalloc(h, &h->d_src_start, mp))) return rc;
     if ((rc = dalloc(h, &h->d_eslot, m))) return rc;
     if ((rc = dalloc(h, &h->d_S[0], 2 * m))) return rc;
@@ -919,7 +1180,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     if ((rc = upload(h, h->d_cum, cum2.data(), (size_t)mp + 1))) return rc;
     if ((rc = upload(h, h->d_einfo, einfo.data(), (size_t)mp))) return rc;
     if ((rc = upload(h, h->d_rowptr, rowptr.data(), (size_t)n + 1))) return rc;
-    if ((rc = upload(h, h->d_adj_pos, adj_pos.data(), (size_t)2 * m))) return rc;
+    if ((rc = upload(h, h->d_adj_seg, adj_seg.data(), (size_t)2 * m))) return rc;
     if ((rc = upload(h, h->d_src_start, src_start.data(), (size_t)mp))) return rc;
     if ((rc = upload(h, h->d_eslot, eslot.data(), (size_t)m))) return rc;
     if ((rc = upload(h, d_ii, prob->ind_i, (size_t)m))) return rc;
@@ -932,11 +1193,49 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     DESC_HIP(hipStreamSynchronize(h->stream));
     h->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
-    h->G = h->max_cnt <= 16 ? 16 : h->max_cnt <= 32 ? 32 : 64;
-    choose_grid(h);
+    h->G = h->max_cnt <= 16 ? 1 : h->max_cnt <= 32 ? 2 : 4;   // cycles per lane, 16 lanes per segment
+    {   // chunks of consecutive segments: <= CHUNK_CAP cycles and <= CHUNK_SEG segments each
+        std::vector<int32_t> chunk_seg;
+        chunk_seg.push_back(0);
+        int64_t q = 0;
+        while (q < mp) {
+            int64_t e = q;
+            while (e < mp && e - q < CHUNK_SEG && cum2[e + 1] - cum2[q] <= CHUNK_CAP) ++e;
+            q = e;                                       // max_cnt <= 64 <= CHUNK_CAP: always advances
+            chunk_seg.push_back((int32_t)q);
+        }
+        h->nchunks = (int)chunk_seg.size() - 1;
+        std::vector<int32_t> chunk_c0(chunk_seg.size() + 1);
+        for (size_t t = 0; t < chunk_seg.size(); ++t) chunk_c0[t] = cum2[chunk_seg[t]];
+        chunk_c0[chunk_seg.size()] = cum2[mp];               // pad: the kernel reads [ch+2] only when ch+1 exists
+        chunk_seg.push_back((int32_t)mp);
+        if ((rc = dalloc(h, &h->d_chunk_seg, chunk_seg.size()))) return rc;
+        if ((rc = upload(h, h->d_chunk_seg, chunk_seg.data(), chunk_seg.size()))) return rc;
+        if ((rc = dalloc(h, &h->d_chunk_c0, chunk_c0.size()))) return rc;
+        if ((rc = upload(h, h->d_chunk_c0, chunk_c0.data(), chunk_c0.size()))) return rc;
+        DESC_HIP(hipStreamSynchronize(h->stream));
+        // persistent grid: exactly the workgroups that are co-resident (registers / LDS decide)
+        int per_cu = 0, ncu = 256;
+        const void* kfn = h->G == 1 ? (const void*)k_sweep_node<1, DESC_STEP_CONSTANT> : h->G == 2 ? (const void*)k_sweep_node<2, DESC_STEP_CONSTANT>
+                        : (const void*)k_sweep_node<4, DESC_STEP_CONSTANT>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, SWEEP_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        int64_t want = std::min<int64_t>(h->nchunks, (int64_t)ncu * per_cu);
+        h->grid = (int)(std::max<int64_t>(want, 8) + 7) / 8 * 8;
+    }
+#ifdef DESC_STAMPS
+    if ((rc = dalloc(h, &h->d_stamps, 8 * (size_t)h->grid))) return rc;
+    DESC_HIP(hipMemset(h->d_stamps, 0, sizeof(unsigned long long) * 8 * (size_t)h->grid));
+#endif
     h->obj_grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (mp + 3) / 4));
     h->colsum_stride = (h->max_deg + 1) | 1;                 // odd stride: the 4 copies start on different banks
-    h->colsum_grid = (int)std::min<int64_t>(n, 256 * 8);
+    h->colsum_grid = (int)std::max<int64_t>(1, n);            // one node per workgroup: the dispatcher balances
+    {
+        const size_t lds = (size_t)h->colsum_stride * (4 * sizeof(double) + 2 * sizeof(int));
+        if (lds > 64 * 1024)
+            DESC_HIP(hipFuncSetAttribute((const void*)k_colsum_node, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     char nm[64];
     snprintf(nm, sizeof nm, "k_sweep_node<%d,", h->G);
     h->kname = nm;
@@ -1022,13 +1321,13 @@ int desc_pgd_create(const desc_problem* prob, const desc_structure* s, int32_t d
 
     // variant: NODE unless the packed per-cycle word or the LDS column copies do not fit
     const int forced = env_int("DESC_DEBUG_VARIANT", 0);
-    const bool node_ok = h->max_deg < 32768 && (size_t)(h->max_deg + 2) * 4 * 8 <= 64 * 1024 && h->max_cnt <= 64 && h->m_pos > 0;
+    const bool node_ok = h->max_deg < 32768 && (size_t)(h->max_deg + 2) * 40 <= 150 * 1024 && h->max_cnt <= 64 && h->m_pos > 0;
     h->variant = (forced == VARIANT_GATHER || !node_ok) ? VARIANT_GATHER : VARIANT_NODE;
 
     const int64_t mp = h->m_pos, mc = h->m_cycle;
     auto A = [&](int r) { if (!rc) rc = r; };
     A(dalloc(h, &h->d_cum, mp + 1));
-    A(dalloc(h, &h->d_S0, mc)); A(dalloc(h, &h->d_w[0], mc)); A(dalloc(h, &h->d_w[1], mc));
+    A(dalloc(h, &h->d_S0, mc + 8)); A(dalloc(h, &h->d_w[0], mc + 8)); A(dalloc(h, &h->d_w[1], mc + 8));   // +8: 16-byte tail reads
     A(dalloc(h, &h->d_nv, (size_t)h->max_cnt + 1));
     A(dalloc(h, &h->d_state, 1));
     if (!rc) {
@@ -1261,6 +1560,17 @@ int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r) {
     r->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return DESC_OK;
 }
+
+#ifdef DESC_STAMPS
+// diagnostic build: phase cycle sums of the last sweep, averaged over workgroups
+int desc_debug_stamps(desc_pgd* h, double* out8) {
+    if (!h || !out8 || !h->d_stamps) return fail(DESC_ERR_INVALID, "no stamps");
+    std::vector<unsigned long long> v(8 * (size_t)h->grid);
+    DESC_HIP(hipMemcpy(v.data(), h->d_stamps, sizeof(unsigned long long) * v.size(), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; ++k) { double a = 0; for (int b = 0; b < h->grid; ++b) a += (double)v[8 * b + k]; out8[k] = a / h->grid; }
+    return DESC_OK;
+}
+#endif
 
 // test hook: group_sum over a buffer of 64*k doubles
 int desc_selftest_group_sum(const double* in, double* out, int32_t count, int32_t G, int32_t device) {

@@ -27,6 +27,14 @@ def run(tag):
     p = _lib.default_params(); p.iters = 2 * args.steps + 10; p.patience = (1 << 31) - 1
     solver.reset(p); solver.iterate(3); solver.sync()
     ms, mk = solver.iterate_timed(args.steps, per_kernel=True)
+    if "stamps" in _lib.LIB_PATH:
+        import ctypes as C, numpy as np
+        out = np.zeros(8)
+        L = _lib.load(); L.desc_debug_stamps.argtypes = [C.c_void_p, _lib.F64P]
+        _lib.check(L.desc_debug_stamps(solver.handle, _lib.ptr(out, _lib.F64P)))
+        names = ["top_sync", "fill+sync", "gathers_issue+park", "issue_next", "D", "sync_afterD", "stores", "park_gathers+publish"]
+        tot = out.sum()
+        print("stamps (cycles per workgroup per sweep, share):", {n: (int(v), round(v / tot, 3)) for n, v in zip(names, out)}, flush=True)
     print(json.dumps(dict(variant=args.variant, band=args.band, kernel=solver.kernel_name(), tag=tag, kernel_ms=mk, step_ms=ms / args.steps, GBs=B / mk / 1e6, frac=B / mk / 1e6 / 8000)), flush=True)
 for ab in args.ablate.split(","):
     os.environ["DESC_DEBUG_ABLATE"] = ab
