@@ -16,7 +16,7 @@
  * PARITY UNPINNED: the reference has no tests / fixtures / golden vectors and
  * cannot be executed here (MATLAB only).  This file is pinned by hand-derived
  * known-answer cases and by agreement with the independent dense literal
- * restatement oracle/desc_pgd_literal.py (tests/test_oracle_*.py).
+ * restatement oracle/desc_pgd_literal.py (tests/test_oracle.py).
  *
  * All indices crossing this interface are 0-based.  rij is m x 9, block l holds
  * RijMat(:,:,l) in MATLAB (column-major) order: element (r,c) at rij[9*l+r+3*c].

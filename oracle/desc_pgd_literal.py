@@ -9,7 +9,7 @@ and its variable names so that each block can be read side by side with the
 PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors and no
 MATLAB/Octave interpreter exists in the build environment, so this restatement
 cannot be checked against an execution of the reference.  It is pinned only by
-(i) hand-derived known-answer cases (tests/test_oracle_kat.py), (ii) invariants
+(i) hand-derived known-answer cases (tests/test_oracle.py), (ii) invariants
 and a finite-difference gradient check, and (iii) agreement with the independent
 sparse C restatement in oracle/desc_oracle.c.
 
@@ -130,6 +130,20 @@ class HybridGradient:
 # --------------------------------------------------------------------------
 # The literal restatement
 # --------------------------------------------------------------------------
+def project_simplex_literal(w_new):
+    """DESC_PGD.m:215-224: sort, first i with sum(w(i:end)-w(i)) < 1, threshold T, clamp."""
+    w_new = np.asarray(w_new, dtype=np.float64)
+    nsample = w_new.shape[0]
+    w = np.sort(w_new)                               # :215
+    Ti = 0
+    for i in range(1, nsample + 1):                  # :217-222
+        if np.sum(w[i - 1:] - w[i - 1]) < 1:
+            Ti = i
+            break
+    T = w[Ti - 1] - (1 - np.sum(w[Ti - 1:] - w[Ti - 1])) / len(w[Ti - 1:])   # :223
+    return np.maximum(w_new - T, 0)                  # :224
+
+
 def default_sampler(rng):
     """datasample(CoInd_ij, n_sample, 'Replace', false) with a NumPy generator:
     a uniformly random subset in random order (DESC_PGD.m:84)."""
@@ -319,14 +333,7 @@ def desc_pgd_literal(Ind, RijMat, iters, Gradient, sampler=None, verbose=False,
             lo, hi = cum_ind[l - 1], cum_ind[l]
             w_new = wijk[lo:hi].copy()
             if proj == 1:
-                w = np.sort(w_new)                               # :215
-                Ti = 0
-                for i in range(1, nsample + 1):                  # :217-222
-                    if np.sum(w[i - 1:] - w[i - 1]) < 1:
-                        Ti = i
-                        break
-                T = w[Ti - 1] - (1 - np.sum(w[Ti - 1:] - w[Ti - 1])) / len(w[Ti - 1:])   # :223
-                wijk[lo:hi] = np.maximum(w_new - T, 0)           # :224
+                wijk[lo:hi] = project_simplex_literal(w_new)     # :215-224
             else:
                 wijk[lo:hi] = wijk[lo:hi] / np.sum(wijk[lo:hi])
             S_vec[IJ - 1] = wijk[lo:hi] @ S0_long[lo:hi]         # :229

@@ -147,3 +147,59 @@ def test_no_triangles_and_single_triangle(lib):
     assert np.abs(S - d).max() < 1e-14
     assert info["iters_run"] == 31
     assert np.allclose(info["obj"], 6 * d, rtol=1e-14)
+
+
+import glob as _glob
+
+_GOLDEN = sorted(_glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("variant", ["node", "gather"])
+@pytest.mark.parametrize("path", _GOLDEN, ids=[os.path.basename(p)[:-4] for p in _GOLDEN])
+def test_golden_fixtures(lib, path, variant):
+    """HIP path against the committed golden vectors (tests/golden/make_golden.py)."""
+    from desc_amd.algorithms import marshal_edges
+    g = np.load(path)
+    n, ii, jj, rij, perm = marshal_edges(g["Ind"], g["RijMat"])
+    step = g["step"]; kind = int(g["step_kind"])
+    kw = dict(lr=float(step[0]), step_kind=kind)
+    if kind == 1:
+        kw.update(decay_interval=float(step[1]))
+    if kind == 2:
+        kw.update(beta1=float(step[1]), beta2=float(step[2]), decay_interval=float(step[3]))
+    arrays, s0, out = run_gpu(lib, n, ii, jj, rij, c_params(int(g["iters"]), seed=int(g["sampling_seed"]), **kw), variant=variant)
+    for key in ("pos_edge", "cum_ind", "k", "e_jk", "e_ki", "ikj", "jki"):
+        assert np.array_equal(arrays[key], g[key]), key
+    assert np.abs(s0 - g["S0_long"]).max() <= 1e-14
+    assert out["iters_run"] == int(g["iters_run"])
+    tol = 1e-9 if kind == 2 else TOL
+    assert np.abs(out["S_vec"] - g["S_vec"]).max() <= tol
+    assert np.abs(out["w"] - g["wijk"]).max() <= tol
+    assert np.allclose(out["obj"], g["obj_vals"], rtol=1e-12, atol=1e-9)
+
+
+def test_desc_pgd_wrapper_unsorted_input_and_plugin_state(lib, oracle):
+    """The MATLAB-signature wrapper: unsorted Ind is sorted internally and S_vec comes back
+    in the caller's order; handle-object state (t, m_t, v_t) persists across calls."""
+    from desc_amd import DESC_PGD, HybridGradient, PiecewiseStepSize
+    mo, nn, ii, jj, rij = make_problem("uniform", n=50, p=0.5, q=0.2, sigma=0.1, seed=21)
+    st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=3, iters=30, lr=0.01)
+    perm = np.random.default_rng(1).permutation(mo.Ind.shape[0])
+    from desc_amd import ConstantStepSize
+    S = DESC_PGD(mo.Ind[perm], mo.RijMat[:, :, perm], dict(iters=30, Gradient=ConstantStepSize(0.01), seed=3, verbose=False))
+    assert np.abs(S - ref["S_vec"][perm]).max() <= TOL
+    # Piecewise: two calls of 10 iterations continue the counter t (handle semantics)
+    G = PiecewiseStepSize(0.05, 4)
+    DESC_PGD(mo.Ind, mo.RijMat, dict(iters=10, Gradient=G, seed=3, verbose=False))
+    assert G.t == 10
+    S2 = DESC_PGD(mo.Ind, mo.RijMat, dict(iters=10, Gradient=G, seed=3, verbose=False))
+    assert G.t == 20
+    ref2 = oracle.pgd_run(st, S0, 10, step_kind=1, lr=0.05, decay_interval=4, t0=10)
+    assert np.abs(S2 - ref2["S_vec"]).max() <= TOL
+    # Hybrid: state arrays come back, second call starts from them
+    H = HybridGradient(0.002, 0.9, 0.999, 10)
+    DESC_PGD(mo.Ind, mo.RijMat, dict(iters=5, Gradient=H, seed=3, verbose=False))
+    assert H.t == 5 and H.m_t.shape[0] == st["m_cycle"] and np.abs(H.v_t).max() > 0
+    am = np.zeros(st["m_cycle"]); av = np.zeros(st["m_cycle"])
+    r1 = oracle.pgd_run(st, S0, 5, step_kind=2, lr=0.002, beta1=0.9, beta2=0.999, decay_interval=10, adam_m=am, adam_v=av)
+    assert np.abs(H.m_t - am).max() < 1e-9 and np.abs(H.v_t - av).max() < 1e-9
