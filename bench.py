@@ -93,7 +93,7 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("DESC_FORCE_SHARDED") == "1":   # the env switch rehearses the N>1 code path on one GPU
         from desc_amd.sharded import bench_sharded
         return bench_sharded(args, WORKLOADS, describe, generate, cpu_baseline)
 

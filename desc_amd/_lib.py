@@ -25,6 +25,8 @@ EXPORTS = [
     "desc_pgd_create", "desc_pgd_destroy", "desc_pgd_run", "desc_pgd_reset", "desc_pgd_iterate",
     "desc_pgd_iterate_timed", "desc_pgd_sync", "desc_pgd_download", "desc_pgd_get_s0",
     "desc_pgd_sizes", "desc_pgd_kernel_name", "desc_pgd_solve", "desc_selftest_group_sum",
+    "desc_pgd_create_shard", "desc_pgd_shard_info", "desc_pgd_shard_bind", "desc_pgd_shard_colsum", "desc_pgd_shard_sweep",
+    "desc_pgd_shard_finish", "desc_pgd_shard_objective", "desc_pgd_stopped",
 ]
 
 I32P = C.POINTER(C.c_int32)
@@ -59,6 +61,12 @@ class Result(C.Structure):
                 ("ms_pgd", C.c_double), ("ms_total", C.c_double)]
 
 
+class ShardInfo(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("t_len", C.c_int64), ("slice_len", C.c_int64),
+                ("seg_lo", C.c_int64), ("seg_hi", C.c_int64), ("cyc_lo", C.c_int64), ("cyc_hi", C.c_int64),
+                ("m_pos", C.c_int64), ("m_cycle", C.c_int64)]
+
+
 class DescError(RuntimeError):
     pass
 
@@ -75,6 +83,11 @@ def load():
         raise DescError(
             f"{LIB_PATH} is missing: build it with `python -m desc_amd.build` (hipcc, gfx950). "
             "The DESC_PGD hot path has no CPU fallback.")
+    # PyTorch bundles a ROCm runtime with the same sonames as /opt/rocm; a process can hold only
+    # one copy and torch needs its own.  Callers that use torch next to this library (the
+    # multi-GPU driver) import torch first, or set DESC_AMD_PRELOAD_TORCH=1.
+    if os.environ.get("DESC_AMD_PRELOAD_TORCH") == "1":
+        import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.desc_last_error.restype = C.c_char_p
     L.desc_version.restype = C.c_char_p
@@ -103,6 +116,14 @@ def load():
     L.desc_pgd_get_s0.argtypes = [C.c_void_p, F64P]
     L.desc_pgd_sizes.argtypes = [C.c_void_p, I64P, I64P, I64P, I32P]
     L.desc_pgd_solve.argtypes = [C.POINTER(Problem), C.POINTER(Params), C.POINTER(Result)]
+    L.desc_pgd_create_shard.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.desc_pgd_shard_info.argtypes = [C.c_void_p, C.POINTER(ShardInfo)]
+    L.desc_pgd_shard_bind.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.desc_pgd_shard_colsum.argtypes = [C.c_void_p]
+    L.desc_pgd_shard_sweep.argtypes = [C.c_void_p]
+    L.desc_pgd_shard_finish.argtypes = [C.c_void_p, C.c_int32]
+    L.desc_pgd_shard_objective.argtypes = [C.c_void_p, C.c_int32]
+    L.desc_pgd_stopped.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     _lib = L
     return L
 
@@ -195,9 +216,9 @@ class Structure:
 class Solver:
     """Owner of a desc_pgd* (problem + structure resident in HBM)."""
 
-    def __init__(self, prob: ProblemArrays, structure: Structure, device=0):
+    def __init__(self, prob: ProblemArrays, structure: Structure, device=0, rank=0, world=1):
         h = C.c_void_p()
-        check(load().desc_pgd_create(C.byref(prob.c), structure.handle, device, C.byref(h)))
+        check(load().desc_pgd_create_shard(C.byref(prob.c), structure.handle, device, rank, world, C.byref(h)))
         self.handle = h
         m, mp, mc, mx = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
         check(load().desc_pgd_sizes(h, C.byref(m), C.byref(mp), C.byref(mc), C.byref(mx)))
@@ -261,6 +282,32 @@ class Solver:
         r, bufs = self._result(getattr(self, "_iters_cap", 1), want_w)
         check(load().desc_pgd_download(self.handle, C.byref(r)))
         return self._pack(r, bufs)
+
+    # ---- multi-GPU pieces (see desc_amd/sharded.py)
+    def shard_info(self):
+        info = ShardInfo()
+        check(load().desc_pgd_shard_info(self.handle, C.byref(info)))
+        return info
+
+    def shard_bind(self, t_ptr, sall_ptr, stream_ptr=None):
+        check(load().desc_pgd_shard_bind(self.handle, t_ptr, sall_ptr, stream_ptr))
+
+    def shard_colsum(self):
+        check(load().desc_pgd_shard_colsum(self.handle))
+
+    def shard_sweep(self):
+        check(load().desc_pgd_shard_sweep(self.handle))
+
+    def shard_finish(self, initial=0):
+        check(load().desc_pgd_shard_finish(self.handle, initial))
+
+    def shard_objective(self, phase):
+        check(load().desc_pgd_shard_objective(self.handle, phase))
+
+    def stopped(self):
+        f = C.c_int32()
+        check(load().desc_pgd_stopped(self.handle, C.byref(f)))
+        return bool(f.value)
 
     def destroy(self):
         if self.handle:

@@ -709,10 +709,10 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
     }
 }
 
-// Setup of the node layout: copies one natural-order segment into its band-major slot,
-// packs idx_i(k) / idx_j(k) / mirror bits and evaluates the cycle inconsistency.
-// kf = k | (ikj>=0)<<30 | (jki>=0)<<31 in natural order.
-__global__ __launch_bounds__(256) void k_layout_node(const int32_t* cum, const int32_t* src_start, const int32_t* pos_edge,
+// Setup of the node layout: packs idx_i(k) / idx_j(k) / mirror bits of every cycle and
+// evaluates its inconsistency.  kf = k | (ikj>=0)<<30 | (jki>=0)<<31, already in device
+// (band-major) order.
+__global__ __launch_bounds__(256) void k_layout_node(const int32_t* cum, const int32_t* pos_edge,
                                                      const int32_t* ind_i, const int32_t* ind_j, const uint32_t* kf,
                                                      const int32_t* rowptr, const int32_t* adj, const int32_t* adj_eid,
                                                      const double* rij, uint32_t* pk, double* S0, int m_pos) {
@@ -720,13 +720,13 @@ __global__ __launch_bounds__(256) void k_layout_node(const int32_t* cum, const i
     const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * 256) >> 6;
     for (int64_t l = wid; l < m_pos; l += nw) {
-        const int base = cum[l], cnt = cum[l + 1] - base, src = src_start[l];
+        const int base = cum[l], cnt = cum[l + 1] - base;
         const int e = pos_edge[l], i = ind_i[e], j = ind_j[e];
         const int ri = rowptr[i], di = rowptr[i + 1] - ri, rj = rowptr[j], dj = rowptr[j + 1] - rj;
         double A[9];
         for (int t = 0; t < 9; ++t) A[t] = rij[9 * (int64_t)e + t];
         for (int q = lane; q < cnt; q += 64) {
-            const uint32_t x = kf[(int64_t)src + q];
+            const uint32_t x = kf[(int64_t)base + q];
             const int k = (int)(x & 0x3FFFFFFFu);
             int lo = 0, hi = di;                                  // idx_i(k): position of k in row i
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (adj[ri + mid] < k) lo = mid + 1; else hi = mid; }
@@ -795,6 +795,49 @@ __global__ __launch_bounds__(256) void k_reorder_cycles(const int32_t* cum, cons
             if (dir == 0) out[(int64_t)base + t] = in[(int64_t)src + t];
             else out[(int64_t)src + t] = in[(int64_t)base + t];
         }
+    }
+}
+
+// ---- multi-GPU exchange helpers (node variant) --------------------------------
+// S of the local edges (+ this rank's two scalar partials) -> this rank's slice of the
+// exchange buffer
+__global__ __launch_bounds__(256) void k_pack_S(const EdgeInfo* einfo, const double* Sfull, const double* partials, int nparts,
+                                                double* slice, int seg_lo, int seg_hi, int64_t slice_len) {
+    const int nloc = seg_hi - seg_lo;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < nloc; t += gridDim.x * 256) slice[t] = Sfull[einfo[seg_lo + t].slot_a];
+    if (blockIdx.x == 0) {
+        __shared__ double sh[2][256];
+        double o = 0.0, ch = 0.0;
+        for (int i = threadIdx.x; i < nparts; i += 256) { o += partials[2 * i]; ch += partials[2 * i + 1]; }
+        sh[0][threadIdx.x] = o; sh[1][threadIdx.x] = ch;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) { sh[0][threadIdx.x] += sh[0][threadIdx.x + s]; sh[1][threadIdx.x] += sh[1][threadIdx.x + s]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { slice[slice_len - 2] = sh[0][0]; slice[slice_len - 1] = sh[1][0]; }
+    }
+}
+// gathered slices -> both CSR slots of every edge with cycles; scalar pairs -> contiguous
+__global__ __launch_bounds__(256) void k_unpack_S(const EdgeInfo* einfo, const int32_t* rank_seg, int world, const double* sall,
+                                                  int64_t slice_len, double* S_a, double* S_b, double* pairs) {
+    for (int r = 0; r < world; ++r) {
+        const int lo = rank_seg[r], hi = rank_seg[r + 1];
+        const double* sl = sall + (int64_t)r * slice_len;
+        for (int t = blockIdx.x * 256 + threadIdx.x; t < hi - lo; t += gridDim.x * 256) {
+            const EdgeInfo ei = einfo[lo + t];
+            const double v = sl[t];
+            S_a[ei.slot_a] = v; S_a[ei.slot_b] = v;
+            if (S_b) { S_b[ei.slot_a] = v; S_b[ei.slot_b] = v; }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { pairs[2 * r] = sl[slice_len - 2]; pairs[2 * r + 1] = sl[slice_len - 1]; }
+    }
+}
+
+__global__ void k_gather_pairs(const double* sall, int64_t slice_len, int world, double* pairs) {
+    for (int r = threadIdx.x; r < world; r += blockDim.x) {
+        pairs[2 * r] = sall[(int64_t)r * slice_len + slice_len - 2];
+        pairs[2 * r + 1] = sall[(int64_t)r * slice_len + slice_len - 1];
     }
 }
 
@@ -881,6 +924,18 @@ struct desc_pgd {
     int nchunks = 0;
     double *d_T = nullptr, *d_Svec = nullptr;
     unsigned long long* d_stamps = nullptr;
+    // sharding (world == 1: the whole problem)
+    int rank = 0, world = 1;
+    int64_t seg_lo = 0, seg_hi = 0;     // device-order range of segments owned by this rank
+    int64_t cyc_lo = 0, cyc_hi = 0;     // their cycles
+    int ch_lo = 0;                      // first chunk owned
+    int64_t slice_len = 0;              // doubles per rank in the S exchange buffer
+    std::vector<int64_t> rank_seg;      // world+1 segment boundaries
+    double* x_T = nullptr;              // caller-bound exchange buffers (device): column sums, 2m
+    double* x_sall = nullptr;           //   world * slice_len
+    double* d_pairs = nullptr;          // 2*world gathered scalars
+    bool borrowed_stream = false, objective_done = false;
+    int32_t* d_rank_seg = nullptr;
     int trace_cap = 0;
     // run state
     desc_params p{};
@@ -910,12 +965,13 @@ void dfree(desc_pgd* h, void* q) {
 }
 
 int set_device(const desc_pgd* h) { DESC_HIP(hipSetDevice(h->device)); return DESC_OK; }
+int64_t local_cycles(const desc_pgd* h) { return h->variant == VARIANT_NODE ? h->cyc_hi - h->cyc_lo : h->m_cycle; }
 
 void free_all(desc_pgd* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     for (void* q : h->allocs) if (q) (void)hipFree(q);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream && !h->borrowed_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -992,12 +1048,12 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
     if (ev0) (void)hipEventRecord(ev0, h->stream);
     if (h->variant == VARIANT_NODE) {
         hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 2 * sizeof(int)), h->stream,
-                           h->d_rowptr, h->d_adj_seg, h->d_pk, h->d_w[rd], h->d_T, (int)h->n,
+                           h->d_rowptr, h->d_adj_seg, h->d_pk, h->d_w[rd], h->x_T ? h->x_T : h->d_T, (int)h->n,
                            h->colsum_stride, h->d_state);
         NodeSweepArgs a{};
         a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
-        a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->d_T; a.nv_tab = h->d_nv; a.partials = h->d_partials;
-        a.state = h->d_state; a.st = st; a.chunk_seg = h->d_chunk_seg; a.chunk_c0 = h->d_chunk_c0; a.nchunks = h->nchunks; a.max_cnt = h->max_cnt; a.ablate = h->ablate; a.stamps = h->d_stamps;
+        a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_T ? h->x_T : h->d_T; a.nv_tab = h->d_nv; a.partials = h->d_partials;
+        a.state = h->d_state; a.st = st; a.chunk_seg = h->d_chunk_seg + h->ch_lo; a.chunk_c0 = h->d_chunk_c0 + h->ch_lo; a.nchunks = h->nchunks; a.max_cnt = h->max_cnt; a.ablate = h->ablate; a.stamps = h->d_stamps;
         if (adam) launch_node<DESC_STEP_HYBRID>(h, a); else launch_node<DESC_STEP_CONSTANT>(h, a);
     } else {
         SweepArgs a{};
@@ -1082,9 +1138,74 @@ int setup_gather(desc_pgd* h, const desc_problem* prob, const desc_structure* s)
 }
 
 // ------------------------------------------------------------------ NODE setup
+// Host-side plan of the node layout: band-major order of the edges with cycles, chunking,
+// and the chunk ranges of the `world` ranks (contiguous, equal numbers of chunks).
+struct NodePlan {
+    int band = 0;
+    std::vector<int32_t> order;       // device position -> index into s->pos_edge
+    std::vector<int32_t> cum2;        // m_pos+1, device order, global cycle numbering
+    std::vector<int32_t> chunk_seg;   // nchunks+1
+    std::vector<int64_t> rank_chunk;  // world+1
+};
+
+int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_deg, int world, NodePlan& P) {
+    const int64_t mp = s->m_pos;
+    int band = env_int("DESC_DEBUG_BAND", 0);
+    if (band <= 0)   // rows of one band should stay in an XCD's 4 MiB L2 next to the streamed arrays: ~1 MiB
+        band = (int)std::max<int64_t>(8, std::min<int64_t>(512, (1 << 20) / (8 * (int64_t)std::max(1, max_deg))));
+    P.band = band;
+    P.order.resize((size_t)mp);
+    for (int64_t l = 0; l < mp; ++l) P.order[l] = (int32_t)l;
+    {
+        const int32_t* ii = prob->ind_i; const int32_t* jj = prob->ind_j; const int32_t* pe = s->pos_edge.data();
+        std::sort(P.order.begin(), P.order.end(), [=](int32_t x, int32_t y) {      // (band(i), j, i)
+            const int32_t ex = pe[x], ey = pe[y];
+            const int32_t bx = ii[ex] / band, by = ii[ey] / band;
+            if (bx != by) return bx < by;
+            if (jj[ex] != jj[ey]) return jj[ex] < jj[ey];
+            return ii[ex] < ii[ey];
+        });
+    }
+    P.cum2.assign((size_t)mp + 1, 0);
+    for (int64_t q = 0; q < mp; ++q) {
+        const int32_t l = P.order[q];
+        P.cum2[q + 1] = P.cum2[q] + (int32_t)(s->cum_ind[l + 1] - s->cum_ind[l]);
+    }
+    P.chunk_seg.clear();
+    P.chunk_seg.push_back(0);
+    for (int64_t q = 0; q < mp;) {     // chunks: <= CHUNK_CAP cycles and <= CHUNK_SEG segments
+        int64_t e = q;
+        while (e < mp && e - q < CHUNK_SEG && P.cum2[e + 1] - P.cum2[q] <= CHUNK_CAP) ++e;
+        q = e;                          // max_cnt <= 64 <= CHUNK_CAP: always advances
+        P.chunk_seg.push_back((int32_t)q);
+    }
+    const int64_t nch = (int64_t)P.chunk_seg.size() - 1;
+    P.rank_chunk.assign((size_t)world + 1, 0);
+    for (int r = 0; r <= world; ++r) P.rank_chunk[r] = nch * r / world;
+    return DESC_OK;
+}
+
 int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
-    const int64_t n = h->n, m = h->m, mp = h->m_pos, mc = h->m_cycle;
+    const int64_t n = h->n, m = h->m, mp = h->m_pos;
     auto t0 = std::chrono::steady_clock::now();
+    int rc;
+    NodePlan P;
+    if ((rc = make_node_plan(prob, s, h->max_deg, h->world, P))) return rc;
+    h->band = P.band;
+    const std::vector<int32_t>& cum2 = P.cum2;
+    const int64_t nch_all = (int64_t)P.chunk_seg.size() - 1;
+    const int64_t ch_a = P.rank_chunk[h->rank], ch_b = P.rank_chunk[h->rank + 1];
+    h->ch_lo = (int)ch_a; h->nchunks = (int)(ch_b - ch_a);
+    h->seg_lo = P.chunk_seg[ch_a]; h->seg_hi = P.chunk_seg[ch_b];
+    h->cyc_lo = cum2[h->seg_lo]; h->cyc_hi = cum2[h->seg_hi];
+    h->rank_seg.assign((size_t)h->world + 1, 0);
+    int64_t max_local = 0;
+    for (int r = 0; r <= h->world; ++r) h->rank_seg[r] = P.chunk_seg[P.rank_chunk[r]];
+    for (int r = 0; r < h->world; ++r) max_local = std::max(max_local, h->rank_seg[r + 1] - h->rank_seg[r]);
+    h->slice_len = max_local + 2;
+    const int64_t mcl = h->cyc_hi - h->cyc_lo;            // local cycles
+    const int64_t nsl = h->seg_hi - h->seg_lo;            // local segments
+
     // CSR adjacency (neighbours ascending; single pass because Ind is sorted by (i,j))
     std::vector<int32_t> rowptr((size_t)n + 1, 0), adj((size_t)2 * m), adj_eid((size_t)2 * m);
     for (int64_t e = 0; e < m; ++e) { rowptr[prob->ind_i[e] + 1]++; rowptr[prob->ind_j[e] + 1]++; }
@@ -1107,30 +1228,11 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     host_parallel(m, [&](int64_t a, int64_t b) {
         for (int64_t e = a; e < b; ++e) eslot[e] = rowptr[prob->ind_i[e]] + idx_in_row(prob->ind_i[e], prob->ind_j[e]);
     });
-    // band-major order of the edges with cycles: (band(i), j, i)
-    int band = env_int("DESC_DEBUG_BAND", 0);
-    if (band <= 0) {
-        // rows of one band should stay in an XCD's 4 MiB L2 next to the streamed arrays: ~1 MiB
-        band = (int)std::max<int64_t>(8, std::min<int64_t>(512, (1 << 20) / (8 * (int64_t)std::max(1, h->max_deg))));
-    }
-    h->band = band;
-    std::vector<int32_t> order((size_t)mp);
-    for (int64_t l = 0; l < mp; ++l) order[l] = (int32_t)l;
-    {
-        const int32_t* ii = prob->ind_i; const int32_t* jj = prob->ind_j; const int32_t* pe = s->pos_edge.data();
-        std::sort(order.begin(), order.end(), [=](int32_t x, int32_t y) {
-            const int32_t ex = pe[x], ey = pe[y];
-            const int32_t bx = ii[ex] / band, by = ii[ey] / band;
-            if (bx != by) return bx < by;
-            if (jj[ex] != jj[ey]) return jj[ex] < jj[ey];
-            return ii[ex] < ii[ey];
-        });
-    }
-    std::vector<int32_t> cum2((size_t)mp + 1, 0), src_start((size_t)mp), pos_edge2((size_t)mp), devpos((size_t)m, -1);
+    std::vector<int32_t> cum_loc((size_t)mp + 1), src_start((size_t)mp), pos_edge2((size_t)mp), devpos((size_t)m, -1);
     std::vector<EdgeInfo> einfo((size_t)mp);
+    for (int64_t q = 0; q <= mp; ++q) cum_loc[q] = cum2[q] - (int32_t)h->cyc_lo;   // local cycle numbering (meaningful for owned segments)
     for (int64_t q = 0; q < mp; ++q) {
-        const int32_t l = order[q], e = s->pos_edge[l];
-        cum2[q + 1] = cum2[q] + (int32_t)(s->cum_ind[l + 1] - s->cum_ind[l]);
+        const int32_t l = P.order[q], e = s->pos_edge[l];
         src_start[q] = (int32_t)s->cum_ind[l];
         pos_edge2[q] = e; devpos[e] = (int32_t)q;
     }
@@ -1146,20 +1248,33 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
             for (int32_t t = rowptr[v]; t < rowptr[v + 1]; ++t) {
                 const int32_t q = devpos[adj_eid[t]];
                 int2 rec{0, 0};
-                if (q >= 0) { rec.x = cum2[q]; rec.y = (int)((uint32_t)(cum2[q + 1] - cum2[q]) | (v < adj[t] ? 0x80000000u : 0u)); }
+                if (q >= h->seg_lo && q < h->seg_hi) {       // only segments this rank owns
+                    rec.x = cum_loc[q];
+                    rec.y = (int)((uint32_t)(cum2[q + 1] - cum2[q]) | (v < adj[t] ? 0x80000000u : 0u));
+                }
                 adj_seg[t] = rec;
             }
     });
-    // k with the two mirror-present bits, natural order
-    std::vector<uint32_t> kf((size_t)mc);
-    host_parallel(mc, [&](int64_t a, int64_t b) {
-        for (int64_t c = a; c < b; ++c)
-            kf[c] = (uint32_t)s->k[c] | (s->ikj[c] >= 0 ? 1u << 30 : 0u) | (s->jki[c] >= 0 ? 1u << 31 : 0u);
+    // k with the two mirror-present bits of the owned cycles, device order
+    std::vector<uint32_t> kf((size_t)mcl);
+    host_parallel(nsl, [&](int64_t a, int64_t b) {
+        for (int64_t q = h->seg_lo + a; q < h->seg_lo + b; ++q) {
+            const int64_t src = src_start[q], dst = cum_loc[q], cnt = cum2[q + 1] - cum2[q];
+            for (int64_t t = 0; t < cnt; ++t)
+                kf[dst + t] = (uint32_t)s->k[src + t] | (s->ikj[src + t] >= 0 ? 1u << 30 : 0u) | (s->jki[src + t] >= 0 ? 1u << 31 : 0u);
+        }
     });
+    // chunk tables: all chunks, local cycle numbering
+    std::vector<int32_t> chunk_seg(P.chunk_seg), chunk_c0((size_t)nch_all + 2);
+    for (int64_t t = 0; t <= nch_all; ++t) chunk_c0[t] = cum_loc[chunk_seg[t]];
+    chunk_c0[nch_all + 1] = cum_loc[mp];                 // pad: the kernel reads [ch+2] only when ch+1 exists
+    chunk_seg.push_back((int32_t)mp);
 
-    int rc;
+    if ((rc = dalloc(h, &h->d_S0, mcl + 8))) return rc;   // +8: 16-byte tail reads
+    if ((rc = dalloc(h, &h->d_w[0], mcl + 8))) return rc;
+    if ((rc = dalloc(h, &h->d_w[1], mcl + 8))) return rc;
+    if ((rc = dalloc(h, &h->d_pk, mcl + 8))) return rc;
     if ((rc = dalloc(h, &h->d_einfo, mp))) return rc;
-    if ((rc = dalloc(h, &h->d_pk, mc + 8))) return rc;
     if ((rc = dalloc(h, &h->d_rowptr, n + 1))) return rc;
     if ((rc = dalloc(h, &h->d_adj_seg, 2 * m))) return rc;
     if ((rc = dalloc(h, &h->d_src_start, mp))) return rc;
@@ -1168,6 +1283,10 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     if ((rc = dalloc(h, &h->d_S[1], 2 * m))) return rc;
     if ((rc = dalloc(h, &h->d_T, 2 * m))) return rc;
     if ((rc = dalloc(h, &h->d_Svec, m))) return rc;
+    if ((rc = dalloc(h, &h->d_chunk_seg, chunk_seg.size()))) return rc;
+    if ((rc = dalloc(h, &h->d_chunk_c0, chunk_c0.size()))) return rc;
+    if ((rc = dalloc(h, &h->d_pairs, 2 * (size_t)h->world))) return rc;
+    if ((rc = dalloc(h, &h->d_rank_seg, (size_t)h->world + 1))) return rc;
     int32_t *d_ii = nullptr, *d_jj = nullptr, *d_adj = nullptr, *d_adj_eid = nullptr, *d_pos_edge2 = nullptr;
     uint32_t* d_kf = nullptr; double* d_rij = nullptr;
     if ((rc = dalloc(h, &d_ii, m))) return rc;
@@ -1175,60 +1294,44 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     if ((rc = dalloc(h, &d_adj, 2 * m))) return rc;
     if ((rc = dalloc(h, &d_adj_eid, 2 * m))) return rc;
     if ((rc = dalloc(h, &d_pos_edge2, mp))) return rc;
-    if ((rc = dalloc(h, &d_kf, mc))) return rc;
+    if ((rc = dalloc(h, &d_kf, mcl))) return rc;
     if ((rc = dalloc(h, &d_rij, 9 * (size_t)m))) return rc;
-    if ((rc = upload(h, h->d_cum, cum2.data(), (size_t)mp + 1))) return rc;
+    std::vector<int32_t> rank_seg32(h->rank_seg.begin(), h->rank_seg.end());
+    if ((rc = upload(h, h->d_cum, cum_loc.data(), (size_t)mp + 1))) return rc;
     if ((rc = upload(h, h->d_einfo, einfo.data(), (size_t)mp))) return rc;
     if ((rc = upload(h, h->d_rowptr, rowptr.data(), (size_t)n + 1))) return rc;
     if ((rc = upload(h, h->d_adj_seg, adj_seg.data(), (size_t)2 * m))) return rc;
     if ((rc = upload(h, h->d_src_start, src_start.data(), (size_t)mp))) return rc;
     if ((rc = upload(h, h->d_eslot, eslot.data(), (size_t)m))) return rc;
+    if ((rc = upload(h, h->d_chunk_seg, chunk_seg.data(), chunk_seg.size()))) return rc;
+    if ((rc = upload(h, h->d_chunk_c0, chunk_c0.data(), chunk_c0.size()))) return rc;
+    if ((rc = upload(h, h->d_rank_seg, rank_seg32.data(), rank_seg32.size()))) return rc;
     if ((rc = upload(h, d_ii, prob->ind_i, (size_t)m))) return rc;
     if ((rc = upload(h, d_jj, prob->ind_j, (size_t)m))) return rc;
     if ((rc = upload(h, d_adj, adj.data(), (size_t)2 * m))) return rc;
     if ((rc = upload(h, d_adj_eid, adj_eid.data(), (size_t)2 * m))) return rc;
     if ((rc = upload(h, d_pos_edge2, pos_edge2.data(), (size_t)mp))) return rc;
-    if ((rc = upload(h, d_kf, kf.data(), (size_t)mc))) return rc;
+    if ((rc = upload(h, d_kf, kf.data(), (size_t)mcl))) return rc;
     if ((rc = upload(h, d_rij, prob->rij, 9 * (size_t)m))) return rc;
     DESC_HIP(hipStreamSynchronize(h->stream));
     h->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
     h->G = h->max_cnt <= 16 ? 1 : h->max_cnt <= 32 ? 2 : 4;   // cycles per lane, 16 lanes per segment
-    {   // chunks of consecutive segments: <= CHUNK_CAP cycles and <= CHUNK_SEG segments each
-        std::vector<int32_t> chunk_seg;
-        chunk_seg.push_back(0);
-        int64_t q = 0;
-        while (q < mp) {
-            int64_t e = q;
-            while (e < mp && e - q < CHUNK_SEG && cum2[e + 1] - cum2[q] <= CHUNK_CAP) ++e;
-            q = e;                                       // max_cnt <= 64 <= CHUNK_CAP: always advances
-            chunk_seg.push_back((int32_t)q);
-        }
-        h->nchunks = (int)chunk_seg.size() - 1;
-        std::vector<int32_t> chunk_c0(chunk_seg.size() + 1);
-        for (size_t t = 0; t < chunk_seg.size(); ++t) chunk_c0[t] = cum2[chunk_seg[t]];
-        chunk_c0[chunk_seg.size()] = cum2[mp];               // pad: the kernel reads [ch+2] only when ch+1 exists
-        chunk_seg.push_back((int32_t)mp);
-        if ((rc = dalloc(h, &h->d_chunk_seg, chunk_seg.size()))) return rc;
-        if ((rc = upload(h, h->d_chunk_seg, chunk_seg.data(), chunk_seg.size()))) return rc;
-        if ((rc = dalloc(h, &h->d_chunk_c0, chunk_c0.size()))) return rc;
-        if ((rc = upload(h, h->d_chunk_c0, chunk_c0.data(), chunk_c0.size()))) return rc;
-        DESC_HIP(hipStreamSynchronize(h->stream));
-        // persistent grid: exactly the workgroups that are co-resident (registers / LDS decide)
+    {   // persistent grid: exactly the workgroups that are co-resident (registers / LDS decide)
         int per_cu = 0, ncu = 256;
         const void* kfn = h->G == 1 ? (const void*)k_sweep_node<1, DESC_STEP_CONSTANT> : h->G == 2 ? (const void*)k_sweep_node<2, DESC_STEP_CONSTANT>
                         : (const void*)k_sweep_node<4, DESC_STEP_CONSTANT>;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, SWEEP_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-        int64_t want = std::min<int64_t>(h->nchunks, (int64_t)ncu * per_cu);
+        int64_t want = std::min<int64_t>(std::max(h->nchunks, 1), (int64_t)ncu * per_cu);
         h->grid = (int)(std::max<int64_t>(want, 8) + 7) / 8 * 8;
     }
 #ifdef DESC_STAMPS
     if ((rc = dalloc(h, &h->d_stamps, 8 * (size_t)h->grid))) return rc;
     DESC_HIP(hipMemset(h->d_stamps, 0, sizeof(unsigned long long) * 8 * (size_t)h->grid));
 #endif
-    h->obj_grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (mp + 3) / 4));
+    h->obj_grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (nsl + 3) / 4));
     h->colsum_stride = (h->max_deg + 1) | 1;                 // odd stride: the 4 copies start on different banks
     h->colsum_grid = (int)std::max<int64_t>(1, n);            // one node per workgroup: the dispatcher balances
     {
@@ -1243,10 +1346,10 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     hipEvent_t e0, e1;
     DESC_HIP(hipEventCreate(&e0)); DESC_HIP(hipEventCreate(&e1));
     (void)hipEventRecord(e0, h->stream);
-    if (mp > 0) {
-        int g = (int)std::min<int64_t>(4096, (mp + 3) / 4);
-        hipLaunchKernelGGL(k_layout_node, dim3(g), dim3(256), 0, h->stream, h->d_cum, h->d_src_start, d_pos_edge2, d_ii, d_jj,
-                           d_kf, h->d_rowptr, d_adj, d_adj_eid, d_rij, h->d_pk, h->d_S0, (int)mp);
+    if (nsl > 0) {
+        int g = (int)std::min<int64_t>(4096, (nsl + 3) / 4);
+        hipLaunchKernelGGL(k_layout_node, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, d_pos_edge2 + h->seg_lo, d_ii, d_jj,
+                           d_kf, h->d_rowptr, d_adj, d_adj_eid, d_rij, h->d_pk, h->d_S0, (int)nsl);
     }
     (void)hipEventRecord(e1, h->stream);
     hipError_t e = hipStreamSynchronize(h->stream);
@@ -1265,14 +1368,14 @@ int cycles_to_device(desc_pgd* h, const double* host, double* dev) {
     if (h->variant != VARIANT_NODE) { DESC_HIP(hipMemcpyAsync(dev, host, sizeof(double) * h->m_cycle, hipMemcpyHostToDevice, h->stream)); return DESC_OK; }
     DESC_HIP(hipMemcpyAsync(h->d_scratch, host, sizeof(double) * h->m_cycle, hipMemcpyHostToDevice, h->stream));
     int g = (int)std::min<int64_t>(4096, (h->m_pos + 3) / 4);
-    hipLaunchKernelGGL(k_reorder_cycles, dim3(g), dim3(256), 0, h->stream, h->d_cum, h->d_src_start, h->d_scratch, dev, (int)h->m_pos, 0);
+    hipLaunchKernelGGL(k_reorder_cycles, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo, h->d_scratch, dev, (int)(h->seg_hi - h->seg_lo), 0);
     return DESC_OK;
 }
 int cycles_to_host(desc_pgd* h, const double* dev, double* host) {
     if (h->m_cycle == 0) return DESC_OK;
     if (h->variant != VARIANT_NODE) { DESC_HIP(hipMemcpy(host, dev, sizeof(double) * h->m_cycle, hipMemcpyDeviceToHost)); return DESC_OK; }
     int g = (int)std::min<int64_t>(4096, (h->m_pos + 3) / 4);
-    hipLaunchKernelGGL(k_reorder_cycles, dim3(g), dim3(256), 0, h->stream, h->d_cum, h->d_src_start, dev, h->d_scratch, (int)h->m_pos, 1);
+    hipLaunchKernelGGL(k_reorder_cycles, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo, dev, h->d_scratch, (int)(h->seg_hi - h->seg_lo), 1);
     DESC_HIP(hipMemcpyAsync(host, h->d_scratch, sizeof(double) * h->m_cycle, hipMemcpyDeviceToHost, h->stream));
     DESC_HIP(hipStreamSynchronize(h->stream));
     return DESC_OK;
@@ -1294,9 +1397,15 @@ int desc_device_count(void) {
 }
 
 int desc_pgd_create(const desc_problem* prob, const desc_structure* s, int32_t device, desc_pgd** out) {
+    return desc_pgd_create_shard(prob, s, device, 0, 1, out);
+}
+
+int desc_pgd_create_shard(const desc_problem* prob, const desc_structure* s, int32_t device, int32_t rank, int32_t world,
+                          desc_pgd** out) {
     if (!out) return fail(DESC_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!prob || !s) return fail(DESC_ERR_INVALID, "NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(DESC_ERR_INVALID, "rank %d / world %d", rank, world);
     if (prob->m != s->m) return fail(DESC_ERR_INVALID, "structure was built for m = %lld, problem has m = %lld", (long long)s->m, (long long)prob->m);
     if (prob->m > 0 && !prob->rij) return fail(DESC_ERR_INVALID, "rij is NULL");
     if (prob->n < s->n) return fail(DESC_ERR_INVALID, "problem n smaller than structure n");
@@ -1307,7 +1416,7 @@ int desc_pgd_create(const desc_problem* prob, const desc_structure* s, int32_t d
 
     desc_pgd* h = new (std::nothrow) desc_pgd();
     if (!h) return fail(DESC_ERR_INVALID, "out of host memory");
-    h->device = device;
+    h->device = device; h->rank = rank; h->world = world;
     h->n = prob->n; h->m = s->m; h->m_pos = s->m_pos; h->m_cycle = s->m_cycle; h->max_cnt = s->max_cnt; h->n_sample = s->n_sample;
     {
         std::vector<int32_t> deg((size_t)h->n, 0);
@@ -1323,11 +1432,15 @@ int desc_pgd_create(const desc_problem* prob, const desc_structure* s, int32_t d
     const int forced = env_int("DESC_DEBUG_VARIANT", 0);
     const bool node_ok = h->max_deg < 32768 && (size_t)(h->max_deg + 2) * 40 <= 150 * 1024 && h->max_cnt <= 64 && h->m_pos > 0;
     h->variant = (forced == VARIANT_GATHER || !node_ok) ? VARIANT_GATHER : VARIANT_NODE;
+    if (world > 1 && h->variant != VARIANT_NODE) {
+        rc = fail(DESC_ERR_INVALID, "multi-GPU sharding needs the node layout (max degree < 2^15, segments <= 64 cycles)");
+        free_all(h); return rc;
+    }
 
     const int64_t mp = h->m_pos, mc = h->m_cycle;
     auto A = [&](int r) { if (!rc) rc = r; };
     A(dalloc(h, &h->d_cum, mp + 1));
-    A(dalloc(h, &h->d_S0, mc + 8)); A(dalloc(h, &h->d_w[0], mc + 8)); A(dalloc(h, &h->d_w[1], mc + 8));   // +8: 16-byte tail reads
+    if (h->variant != VARIANT_NODE) { A(dalloc(h, &h->d_S0, mc)); A(dalloc(h, &h->d_w[0], mc)); A(dalloc(h, &h->d_w[1], mc)); }
     A(dalloc(h, &h->d_nv, (size_t)h->max_cnt + 1));
     A(dalloc(h, &h->d_state, 1));
     if (!rc) {
@@ -1381,7 +1494,7 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
             rc = dalloc(h, &h->d_partials, 2 * (size_t)std::max(h->grid, h->obj_grid)); if (rc) return rc;
         }
     }
-    h->t_done = 0; h->t_plugin = p->t0; h->ms_pgd = 0;
+    h->t_done = 0; h->t_plugin = p->t0; h->ms_pgd = 0; h->objective_done = false;
     const int cap = std::max(1, p->iters);
     if (cap > h->trace_cap) {
         dfree(h, h->d_obj); dfree(h, h->d_avg);
@@ -1391,15 +1504,15 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
         h->trace_cap = cap;
     }
     if (p->step_kind == DESC_STEP_HYBRID && p->hybrid_strategy == 0 && !h->d_adam_m) {
-        rc = dalloc(h, &h->d_adam_m, h->m_cycle); if (rc) return rc;
-        rc = dalloc(h, &h->d_adam_v, h->m_cycle); if (rc) return rc;
+        rc = dalloc(h, &h->d_adam_m, local_cycles(h)); if (rc) return rc;
+        rc = dalloc(h, &h->d_adam_v, local_cycles(h)); if (rc) return rc;
     }
     DESC_HIP(hipMemsetAsync(h->d_state, 0, sizeof(DevState), h->stream));
     DESC_HIP(hipMemsetAsync(h->d_obj, 0, sizeof(double) * h->trace_cap, h->stream));
     DESC_HIP(hipMemsetAsync(h->d_avg, 0, sizeof(double) * h->trace_cap, h->stream));
     if (h->d_adam_m) {
-        DESC_HIP(hipMemsetAsync(h->d_adam_m, 0, sizeof(double) * std::max<int64_t>(1, h->m_cycle), h->stream));
-        DESC_HIP(hipMemsetAsync(h->d_adam_v, 0, sizeof(double) * std::max<int64_t>(1, h->m_cycle), h->stream));
+        DESC_HIP(hipMemsetAsync(h->d_adam_m, 0, sizeof(double) * std::max<int64_t>(1, local_cycles(h)), h->stream));
+        DESC_HIP(hipMemsetAsync(h->d_adam_v, 0, sizeof(double) * std::max<int64_t>(1, local_cycles(h)), h->stream));
     }
     const int64_t slen = h->variant == VARIANT_NODE ? 2 * h->m : h->m;
     if (slen > 0) {                                                       // S_vec = ones(1,m)  (:148)
@@ -1408,9 +1521,9 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
         hipLaunchKernelGGL(k_fill, dim3(g), dim3(256), 0, h->stream, h->d_S[1], slen, 1.0);
     }
     if (h->m_pos > 0) {
-        int g = (int)std::min<int64_t>(4096, (h->m_pos + 3) / 4);
+        int g = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (h->m_pos + 3) / 4));
         if (h->variant == VARIANT_NODE)
-            hipLaunchKernelGGL(k_init_node, dim3(g), dim3(256), 0, h->stream, h->d_cum, h->d_einfo, h->d_S0, h->d_w[0], h->d_S[0], h->d_S[1], (int)h->m_pos);
+            hipLaunchKernelGGL(k_init_node, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_einfo + h->seg_lo, h->d_S0, h->d_w[0], h->d_S[0], h->d_S[1], (int)(h->seg_hi - h->seg_lo));
         else
             hipLaunchKernelGGL(k_init, dim3(g), dim3(256), 0, h->stream, h->d_cum, h->d_pos_edge, h->d_S0, h->d_w[0], h->d_S[0], h->d_S[1], (int)h->m_pos);
     }
@@ -1476,10 +1589,10 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
     int rc = set_device(h); if (rc) return rc;
     const int T = h->t_done;
     // objective of the last sweep (DESC_PGD.m:233) and its stop test
-    if (h->m_pos > 0 && T >= 1) {
+    if (h->m_pos > 0 && T >= 1 && h->world == 1) {
         if (h->variant == VARIANT_NODE)
-            hipLaunchKernelGGL(k_objective_node, dim3(h->obj_grid), dim3(256), 0, h->stream, h->d_cum, h->d_einfo, h->d_pk,
-                               h->d_w[T & 1], h->d_S[T & 1], (int)h->m_pos, h->d_partials, h->d_state);
+            hipLaunchKernelGGL(k_objective_node, dim3(h->obj_grid), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_einfo + h->seg_lo, h->d_pk,
+                               h->d_w[T & 1], h->d_S[T & 1], (int)(h->seg_hi - h->seg_lo), h->d_partials, h->d_state);
         else
             hipLaunchKernelGGL(k_objective, dim3(h->obj_grid), dim3(256), 0, h->stream, h->d_w[T & 1], h->d_S[T & 1], h->d_ejk,
                                h->d_eki, h->m_cycle, h->d_partials, h->d_state);
@@ -1510,6 +1623,8 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
             DESC_HIP(hipMemcpy(r->s_vec, h->d_S[par], sizeof(double) * h->m, hipMemcpyDeviceToHost));
         }
     }
+    if (h->world > 1 && (r->w || r->adam_m || r->adam_v))
+        return fail(DESC_ERR_INVALID, "per-cycle outputs (w, Adam state) are not gathered across ranks");
     if (r->w || (h->d_adam_m && r->adam_m && r->adam_v)) { rc = ensure_scratch(h); if (rc) return rc; }
     if (r->w) { rc = cycles_to_host(h, h->d_w[par], r->w); if (rc) return rc; }
     if (r->obj_trace && iters_run > 0) {
@@ -1558,6 +1673,121 @@ int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r) {
         for (int it = 1; it <= r->iters_run; ++it)                       // DESC_PGD.m:241
             printf("iter %d: average change in S_vec %f, objective value: %f\n", it, r->avg_change_trace[it - 1], r->obj_trace[it - 1]);
     r->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return DESC_OK;
+}
+
+// ------------------------------------------------------------- multi-GPU pieces --
+int desc_pgd_shard_info(const desc_pgd* h, desc_shard_info* info) {
+    if (!h || !info) return fail(DESC_ERR_INVALID, "NULL argument");
+    info->rank = h->rank; info->world = h->world;
+    info->t_len = 2 * h->m; info->slice_len = h->slice_len;
+    info->seg_lo = h->seg_lo; info->seg_hi = h->seg_hi; info->cyc_lo = h->cyc_lo; info->cyc_hi = h->cyc_hi;
+    info->m_pos = h->m_pos; info->m_cycle = h->m_cycle;
+    return DESC_OK;
+}
+
+int desc_pgd_shard_bind(desc_pgd* h, double* T, double* sall, void* hip_stream) {
+    if (!h) return fail(DESC_ERR_INVALID, "NULL handle");
+    if (h->variant != VARIANT_NODE) return fail(DESC_ERR_STATE, "sharding needs the node layout");
+    if (!T || !sall) return fail(DESC_ERR_INVALID, "NULL exchange buffer");
+    int rc = set_device(h); if (rc) return rc;
+    DESC_HIP(hipStreamSynchronize(h->stream));
+    h->x_T = T; h->x_sall = sall;
+    if (hip_stream) {          // run on the caller's stream so collectives and kernels are ordered
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+        h->stream = (hipStream_t)hip_stream;
+        h->borrowed_stream = true;
+    }
+    return DESC_OK;
+}
+
+// step 1 of an iteration: partial column sums of the segments this rank owns -> T (then: all-reduce T)
+int desc_pgd_shard_colsum(desc_pgd* h) {
+    if (!h || !h->armed || !h->x_T) return fail(DESC_ERR_STATE, "shard not armed / bound");
+    int rc = set_device(h); if (rc) return rc;
+    const int rd = h->t_done & 1;
+    hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 2 * sizeof(int)), h->stream,
+                       h->d_rowptr, h->d_adj_seg, h->d_pk, h->d_w[rd], h->x_T, (int)h->n, h->colsum_stride, h->d_state);
+    DESC_HIP(hipGetLastError());
+    return DESC_OK;
+}
+
+// step 2: sweep the owned chunks (T now holds the global sums), then pack S of the owned
+// edges and this rank's scalar partials into its slice of sall (then: all-gather sall)
+int desc_pgd_shard_sweep(desc_pgd* h) {
+    if (!h || !h->armed || !h->x_T) return fail(DESC_ERR_STATE, "shard not armed / bound");
+    if (h->t_done + 1 > h->trace_cap) return fail(DESC_ERR_INVALID, "iterating past params.iters = %d", h->p.iters);
+    int rc = set_device(h); if (rc) return rc;
+    const int t = ++h->t_done, rd = (t - 1) & 1, wr = t & 1;
+    bool adam = false;
+    const StepArgs st = make_step(h, &adam);
+    NodeSweepArgs a{};
+    a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
+    a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_T; a.nv_tab = h->d_nv; a.partials = h->d_partials;
+    a.state = h->d_state; a.st = st; a.chunk_seg = h->d_chunk_seg + h->ch_lo; a.chunk_c0 = h->d_chunk_c0 + h->ch_lo; a.nchunks = h->nchunks;
+    a.max_cnt = h->max_cnt; a.ablate = 0; a.stamps = nullptr;
+    if (adam) launch_node<DESC_STEP_HYBRID>(h, a); else launch_node<DESC_STEP_CONSTANT>(h, a);
+    const int nloc = (int)(h->seg_hi - h->seg_lo);
+    hipLaunchKernelGGL(k_pack_S, dim3(std::max(1, std::min(1024, (nloc + 255) / 256))), dim3(256), 0, h->stream, h->d_einfo, h->d_S[wr],
+                       h->d_partials, h->grid, h->x_sall + (int64_t)h->rank * h->slice_len, (int)h->seg_lo, (int)h->seg_hi, h->slice_len);
+    DESC_HIP(hipGetLastError());
+    return DESC_OK;
+}
+
+// step 3: (sall gathered) scatter S of every edge into the CSR-aligned copy, add the
+// scalar partials in rank order, record traces, early-stop rule.
+// initial != 0: the exchange after desc_pgd_reset (distributes the initial S_vec, no traces).
+int desc_pgd_shard_finish(desc_pgd* h, int32_t initial) {
+    if (!h || !h->armed || !h->x_sall) return fail(DESC_ERR_STATE, "shard not armed / bound");
+    int rc = set_device(h); if (rc) return rc;
+    const int t = h->t_done, wr = t & 1;
+    const int g = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (h->slice_len + 255) / 256));
+    if (initial && t != 0) return fail(DESC_ERR_STATE, "initial exchange after iterations");
+    if (initial == 1) {
+        const int nloc = (int)(h->seg_hi - h->seg_lo);
+        hipLaunchKernelGGL(k_pack_S, dim3(std::max(1, std::min(1024, (nloc + 255) / 256))), dim3(256), 0, h->stream, h->d_einfo, h->d_S[0],
+                           h->d_partials, 0, h->x_sall + (int64_t)h->rank * h->slice_len, (int)h->seg_lo, (int)h->seg_hi, h->slice_len);
+        DESC_HIP(hipGetLastError());
+        return DESC_OK;        // caller all-gathers, then calls desc_pgd_shard_finish(h, 2)
+    }
+    hipLaunchKernelGGL(k_unpack_S, dim3(g), dim3(256), 0, h->stream, h->d_einfo, h->d_rank_seg, h->world, h->x_sall, h->slice_len,
+                       h->d_S[initial == 2 ? 0 : wr], initial == 2 ? h->d_S[1] : nullptr, h->d_pairs);
+    if (initial != 2)
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, h->d_pairs, h->world, h->d_state, h->d_obj, h->d_avg, t, h->m,
+                           h->p.patience, h->p.stop_tol, 0);
+    DESC_HIP(hipGetLastError());
+    return DESC_OK;
+}
+
+// final objective of a sharded run: local partial -> slice tail (then all-gather, then finish(3))
+int desc_pgd_shard_objective(desc_pgd* h, int32_t phase) {
+    if (!h || !h->armed || !h->x_sall) return fail(DESC_ERR_STATE, "shard not armed / bound");
+    int rc = set_device(h); if (rc) return rc;
+    const int T = h->t_done;
+    if (T < 1) return DESC_OK;
+    if (phase == 0) {
+        hipLaunchKernelGGL(k_objective_node, dim3(h->obj_grid), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_einfo + h->seg_lo, h->d_pk,
+                           h->d_w[T & 1], h->d_S[T & 1], (int)(h->seg_hi - h->seg_lo), h->d_partials, h->d_state);
+        hipLaunchKernelGGL(k_pack_S, dim3(1), dim3(256), 0, h->stream, h->d_einfo, h->d_S[T & 1], h->d_partials, h->obj_grid,
+                           h->x_sall + (int64_t)h->rank * h->slice_len, (int)h->seg_lo, (int)h->seg_lo, h->slice_len);
+    } else {
+        hipLaunchKernelGGL(k_gather_pairs, dim3(1), dim3(64), 0, h->stream, h->x_sall, h->slice_len, h->world, h->d_pairs);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, h->d_pairs, h->world, h->d_state, h->d_obj, h->d_avg, T, h->m,
+                           h->p.patience, h->p.stop_tol, 1);
+        h->objective_done = true;
+    }
+    DESC_HIP(hipGetLastError());
+    return DESC_OK;
+}
+
+// 1 once the device-side patience rule has fired (synchronises the handle's stream)
+int desc_pgd_stopped(desc_pgd* h, int32_t* stopped) {
+    if (!h || !stopped) return fail(DESC_ERR_INVALID, "NULL argument");
+    int rc = set_device(h); if (rc) return rc;
+    DevState st{};
+    DESC_HIP(hipMemcpyAsync(&st, h->d_state, sizeof st, hipMemcpyDeviceToHost, h->stream));
+    DESC_HIP(hipStreamSynchronize(h->stream));
+    *stopped = st.stop;
     return DESC_OK;
 }
 

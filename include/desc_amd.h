@@ -154,6 +154,41 @@ int desc_pgd_sizes(const desc_pgd* h, int64_t* m, int64_t* m_pos, int64_t* m_cyc
 /* name of the main-sweep kernel variant chosen for this handle (rocprof cross-reference) */
 const char* desc_pgd_kernel_name(const desc_pgd* h);
 
+/* ------------------------------------------------------------- multi-GPU -- */
+/* One process per GPU.  The edges with cycles (in the library's band-major order) are cut
+ * into `world` contiguous ranges of equal cycle count; rank r keeps the per-cycle state
+ * (weights, inconsistencies, packed indices) of its range only, and a full replica of the
+ * O(m) vectors.  One PGD iteration = desc_pgd_shard_colsum -> all-reduce(sum) of T ->
+ * desc_pgd_shard_sweep -> all-gather of sall -> desc_pgd_shard_finish.  The collectives are
+ * the caller's (torch.distributed over RCCL in desc_amd/sharded.py); T and sall are device
+ * buffers the caller allocates and binds.  All ranks take identical stop decisions because
+ * every rank adds the gathered scalar partials in rank order. */
+typedef struct desc_shard_info {
+    int32_t rank, world;
+    int64_t t_len;            /* doubles in T     = 2*m                                       */
+    int64_t slice_len;        /* doubles per rank in sall (owned edges + 2 scalars, padded)   */
+    int64_t seg_lo, seg_hi;   /* owned range of edges-with-cycles (library order)             */
+    int64_t cyc_lo, cyc_hi;   /* owned range of cycles                                        */
+    int64_t m_pos, m_cycle;   /* global counts                                                */
+} desc_shard_info;
+int desc_pgd_create_shard(const desc_problem* prob, const desc_structure* s, int32_t device,
+                          int32_t rank, int32_t world, desc_pgd** out);
+int desc_pgd_shard_info(const desc_pgd* h, desc_shard_info* info);
+/* T: t_len doubles, sall: world*slice_len doubles, both on `device`; hip_stream: the stream
+ * the caller's collectives are ordered on (NULL keeps the handle's own stream). */
+int desc_pgd_shard_bind(desc_pgd* h, double* T, double* sall, void* hip_stream);
+int desc_pgd_shard_colsum(desc_pgd* h);
+int desc_pgd_shard_sweep(desc_pgd* h);
+/* initial: 0 = after an iteration's all-gather; 1 = pack the initial S_vec (after reset,
+ * before the first all-gather); 2 = unpack the initial S_vec (after that all-gather). */
+int desc_pgd_shard_finish(desc_pgd* h, int32_t initial);
+/* objective of the last iterate: phase 0 packs this rank's partial (then all-gather sall),
+ * phase 1 adds the partials and runs the stop rule for the last iteration. */
+int desc_pgd_shard_objective(desc_pgd* h, int32_t phase);
+/* *stopped = 1 once the device-side patience rule (DESC_PGD.m:243-246) has fired; waits for
+ * the handle's stream. */
+int desc_pgd_stopped(desc_pgd* h, int32_t* stopped);
+
 /* One-shot: what the MEX shim calls.  Builds the structure (p->build_where),
  * uploads, runs, downloads, frees. */
 int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* r);

@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # PyTorch bundles its own ROCm runtime under the same sonames as /opt/rocm
+    # (libamdhip64.so.7, libhsa-runtime64.so.1).  One process can hold only one of them, and
+    # torch does not work on top of the system copy -- so when torch will be used next to
+    # libdesc_amd.so (the multi-GPU tests) it has to be imported first.
+    expr = config.getoption("-m", default="") or ""
+    if "gpu" in expr and "not gpu" not in expr:
+        import torch  # noqa: F401
 
 
 @pytest.fixture(scope="session")
