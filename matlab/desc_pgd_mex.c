@@ -1,0 +1,110 @@
+/* desc_pgd_mex.c -- thin MEX shim over the C ABI of libdesc_amd.so (include/desc_amd.h).
+ *
+ *   [S_sorted, info] = desc_pgd_mex(Ind0, RijMat, opt, adam_m, adam_v)
+ *     Ind0    m x 2 int32, 0-based, rows sorted by (i,j)
+ *     RijMat  3 x 3 x m double  -- passed through untouched: MATLAB's column-major layout of a
+ *             3x3xm array IS the library's m x 9 layout (element (r,c,l) at 9*l + r + 3*c)
+ *     opt     struct: iters, step_kind, lr, beta1, beta2, decay_interval, hybrid_strategy, t0,
+ *             seed, device, verbose
+ *     adam_m/adam_v   [] or 1 x m_cycle (HybridGradient.m_t / v_t carried between calls)
+ *   info: iters_run, t_end, obj_vals, avg_change, adam_m, adam_v, ms_structure, ms_pgd, ms_total
+ *
+ * Build (on a machine with MATLAB + ROCm; NOT possible in the build container: no mex.h):
+ *   mex -I../include desc_pgd_mex.c -L../desc_amd -ldesc_amd
+ * This file only marshals; every numerical statement lives behind desc_pgd_solve().  The same
+ * entry point is exercised from Python/ctypes by tests/ (desc_amd/_lib.py).
+ */
+#include <string.h>
+
+#include "mex.h"
+#include "desc_amd.h"
+
+static double field_or(const mxArray* s, const char* name, double dflt) {
+    const mxArray* f = mxGetField(s, 0, name);
+    return (f && !mxIsEmpty(f)) ? mxGetScalar(f) : dflt;
+}
+
+void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    if (nrhs < 3) mexErrMsgIdAndTxt("desc_amd:nargin", "usage: desc_pgd_mex(Ind0, RijMat, opt, adam_m, adam_v)");
+    if (!mxIsInt32(prhs[0]) || mxGetN(prhs[0]) != 2) mexErrMsgIdAndTxt("desc_amd:Ind", "Ind0 must be m x 2 int32");
+    const mwSize m = mxGetM(prhs[0]);
+    const mwSize* dims = mxGetDimensions(prhs[1]);
+    const mwSize nd = mxGetNumberOfDimensions(prhs[1]);
+    if (!mxIsDouble(prhs[1]) || mxIsComplex(prhs[1]) || dims[0] != 3 || dims[1] != 3 || (m > 1 ? (nd != 3 || dims[2] != m) : 0))
+        mexErrMsgIdAndTxt("desc_amd:RijMat", "RijMat must be a real double 3 x 3 x m array");
+    if (!mxIsStruct(prhs[2])) mexErrMsgIdAndTxt("desc_amd:opt", "opt must be a struct");
+
+    const int32_t* ind = (const int32_t*)mxGetData(prhs[0]);       /* column-major: [i(0..m-1), j(0..m-1)] */
+    desc_problem prob;
+    prob.m = (int64_t)m;
+    prob.ind_i = ind;
+    prob.ind_j = ind + m;
+    prob.rij = mxGetPr(prhs[1]);
+    int32_t nmax = -1;
+    for (mwSize e = 0; e < m; ++e) if (ind[m + e] > nmax) nmax = ind[m + e];
+    prob.n = (int64_t)nmax + 1;                                      /* n = max(Ind(:)), DESC_PGD.m:21 */
+
+    desc_params p;
+    desc_params_default(&p);
+    p.iters = (int32_t)field_or(prhs[2], "iters", 100);
+    p.step_kind = (int32_t)field_or(prhs[2], "step_kind", 0);
+    p.lr = field_or(prhs[2], "lr", 0.01);
+    p.beta1 = field_or(prhs[2], "beta1", 0.9);
+    p.beta2 = field_or(prhs[2], "beta2", 0.999);
+    p.decay_interval = field_or(prhs[2], "decay_interval", 25);
+    p.hybrid_strategy = (int32_t)field_or(prhs[2], "hybrid_strategy", 0);
+    p.t0 = (int32_t)field_or(prhs[2], "t0", 0);
+    p.seed = (uint64_t)field_or(prhs[2], "seed", 0);
+    p.device = (int32_t)field_or(prhs[2], "device", 0);
+    p.verbose = 0;                                                   /* the .m wrapper prints */
+
+    /* sizes of the per-cycle vectors are only known after the structure is built */
+    desc_structure* st = NULL;
+    if (desc_structure_build(&prob, p.n_sample_min, p.seed, p.build_where, p.device, &st) != DESC_OK)
+        mexErrMsgIdAndTxt("desc_amd:structure", "%s", desc_last_error());
+    desc_structure_view v;
+    desc_structure_get(st, &v);
+    const mwSize mc = (mwSize)v.m_cycle;
+
+    plhs[0] = mxCreateDoubleMatrix(1, m, mxREAL);
+    mxArray* obj = mxCreateDoubleMatrix(1, p.iters > 0 ? p.iters : 1, mxREAL);
+    mxArray* avg = mxCreateDoubleMatrix(1, p.iters > 0 ? p.iters : 1, mxREAL);
+    mxArray* am = mxCreateDoubleMatrix(1, mc, mxREAL);
+    mxArray* av = mxCreateDoubleMatrix(1, mc, mxREAL);
+    if (nrhs >= 5 && !mxIsEmpty(prhs[3]) && !mxIsEmpty(prhs[4])) {
+        if (mxGetNumberOfElements(prhs[3]) != mc || mxGetNumberOfElements(prhs[4]) != mc) {
+            desc_structure_free(st);
+            mexErrMsgIdAndTxt("desc_amd:adam", "HybridGradient state has a different length than this problem's cycle vector");
+        }
+        memcpy(mxGetPr(am), mxGetPr(prhs[3]), sizeof(double) * mc);
+        memcpy(mxGetPr(av), mxGetPr(prhs[4]), sizeof(double) * mc);
+    }
+    desc_result r;
+    memset(&r, 0, sizeof r);
+    r.s_vec = mxGetPr(plhs[0]);
+    r.obj_trace = mxGetPr(obj);
+    r.avg_change_trace = mxGetPr(avg);
+    if (p.step_kind == DESC_STEP_HYBRID && p.hybrid_strategy == 0) { r.adam_m = mxGetPr(am); r.adam_v = mxGetPr(av); }
+
+    desc_pgd* h = NULL;
+    int rc = desc_pgd_create(&prob, st, p.device, &h);
+    const double ms_structure = 0.0;
+    desc_structure_free(st);
+    if (rc == DESC_OK) rc = desc_pgd_run(h, &p, &r);
+    if (h) desc_pgd_destroy(h);
+    if (rc != DESC_OK) mexErrMsgIdAndTxt("desc_amd:run", "%s", desc_last_error());
+
+    if (nlhs > 1) {
+        const char* names[] = {"iters_run", "t_end", "obj_vals", "avg_change", "adam_m", "adam_v", "ms_structure", "ms_pgd", "ms_total"};
+        plhs[1] = mxCreateStructMatrix(1, 1, 9, names);
+        mxSetField(plhs[1], 0, "iters_run", mxCreateDoubleScalar(r.iters_run));
+        mxSetField(plhs[1], 0, "t_end", mxCreateDoubleScalar(r.t_end));
+        mxSetField(plhs[1], 0, "obj_vals", obj);
+        mxSetField(plhs[1], 0, "avg_change", avg);
+        mxSetField(plhs[1], 0, "adam_m", am);
+        mxSetField(plhs[1], 0, "adam_v", av);
+        mxSetField(plhs[1], 0, "ms_structure", mxCreateDoubleScalar(ms_structure));
+        mxSetField(plhs[1], 0, "ms_pgd", mxCreateDoubleScalar(r.ms_pgd));
+        mxSetField(plhs[1], 0, "ms_total", mxCreateDoubleScalar(r.ms_total));
+    }
+}
