@@ -104,8 +104,10 @@ def main():
     mo, nn, ii, jj, rij = generate(name)
     t_gen = time.perf_counter() - t0
     prob = _lib.ProblemArrays(nn, ii, jj, rij)
+    _lib.Structure.build(_lib.ProblemArrays(3, np.array([0, 0, 1], dtype=np.int32), np.array([1, 2, 2], dtype=np.int32)),
+                         30, 0, _lib.BUILD_DEVICE, 0).free()          # HIP context / code-object load, outside the timers
     t0 = time.perf_counter()
-    st = _lib.Structure.build(prob, 30, args.seed, _lib.BUILD_HOST, 0)
+    st = _lib.Structure.build(prob, 30, args.seed, _lib.BUILD_DEVICE, 0)
     t_struct = time.perf_counter() - t0
     arrays = st.arrays()
     t0 = time.perf_counter()
@@ -146,7 +148,8 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
                      "bytes_per_launch": bytes_per_launch, "kernel_ms": ms_kernel},
         "cycle_updates_per_s": m_cycle * K / dt,
-        "setup_ms": {"generate": t_gen * 1e3, "structure_host": t_struct * 1e3, "upload_and_cycle_d": t_create * 1e3},
+        "setup_ms": {"generate": t_gen * 1e3, "structure_device": t_struct * 1e3, "upload_layout_cycle_d": t_create * 1e3},
+        "end_to_end_100_iters_ms": (t_struct + t_create) * 1e3 + 100 * dt / K * 1e3,
         "mean_abs_err_vs_truth": float(np.mean(np.abs(out["S_vec"] - mo.ErrVec))),
     }
     if not args.no_cpu_baseline:

@@ -118,7 +118,7 @@ def make_c_params(params):
     p.seed = int(_get(params, "seed", 0))
     p.device = int(_get(params, "device", 0))
     p.verbose = 1 if _get(params, "verbose", True) else 0
-    p.build_where = int(_get(params, "build_where", _lib.BUILD_HOST))
+    p.build_where = int(_get(params, "build_where", _lib.BUILD_DEVICE))
     return p, G
 
 
@@ -139,7 +139,13 @@ def DESC_PGD(Ind, RijMat, params, return_info=False):
         raise ValueError("empty edge list")
     prob = _lib.ProblemArrays(n, ii, jj, rij)
     verbose = bool(p.verbose)
-    st = _lib.Structure.build(prob, p.n_sample_min, p.seed, p.build_where, p.device)
+    try:
+        st = _lib.Structure.build(prob, p.n_sample_min, p.seed, p.build_where, p.device)
+    except _lib.DescError as e:
+        # the device builder refuses graphs whose bitmaps / per-edge staging exceed its budget
+        if p.build_where != _lib.BUILD_DEVICE or "DESC_BUILD_HOST" not in str(e):
+            raise
+        st = _lib.Structure.build(prob, p.n_sample_min, p.seed, _lib.BUILD_HOST, p.device)
     try:
         solver = _lib.Solver(prob, st, p.device)
         sizes = st.sizes()

@@ -43,7 +43,7 @@ void desc_params_default(desc_params* p) {
     p->patience = 30;                    // DESC_PGD.m:180
     p->stop_tol = 1e-5;                  // DESC_PGD.m:243
     p->n_sample_min = 30;                // DESC_PGD.m:43
-    p->build_where = DESC_BUILD_HOST;
+    p->build_where = DESC_BUILD_DEVICE;
 }
 
 int desc_structure_build(const desc_problem* prob, int32_t n_sample_min, uint64_t seed,
@@ -121,6 +121,8 @@ int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* 
     auto t0 = std::chrono::steady_clock::now();
     desc_structure* s = nullptr;
     int rc = desc_structure_build(prob, p->n_sample_min > 0 ? p->n_sample_min : 30, p->seed, p->build_where, p->device, &s);
+    if (rc == DESC_ERR_TOO_LARGE && p->build_where == DESC_BUILD_DEVICE)      // device budget exceeded: host builder
+        rc = desc_structure_build(prob, p->n_sample_min > 0 ? p->n_sample_min : 30, p->seed, DESC_BUILD_HOST, p->device, &s);
     if (rc) return rc;
     double ms_structure = s->ms_build;
     desc_pgd* h = nullptr;

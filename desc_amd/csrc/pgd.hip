@@ -446,34 +446,38 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void k_sweep_node(NodeSweepArgs a
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int grp = lane >> 4, r16 = lane & 15;
+    // Chunks are dealt round-robin: at any moment the resident workgroups read one contiguous
+    // window of the streamed arrays (DRAM row-buffer locality; disjoint far-apart streams per
+    // workgroup measured ~half the bandwidth).  k-th chunk of this workgroup = lb + k*nb.
     const int nb = gridDim.x;
-    const int lb = xcd_logical_block(blockIdx.x, nb);
-    const int per_block = (a.nchunks + nb - 1) / nb;
-    const int ch_lo = lb * per_block;
-    const int ch_hi = min(a.nchunks, ch_lo + per_block);
+    const int lb = blockIdx.x;
+    const int nk = lb < a.nchunks ? (a.nchunks - lb + nb - 1) / nb : 0;
     double obj_acc = 0.0, chg_acc = 0.0;
-    if (ch_lo >= ch_hi) { block_partials(obj_acc, chg_acc, a.partials, lb); return; }
+    if (nk == 0) { block_partials(obj_acc, chg_acc, a.partials, lb); return; }
 
     if (tid <= 64) s_nv[tid] = tid <= a.max_cnt ? a.nv_tab[tid] : 0.0;
-    StreamRegs SA{}, SB{};                                   // chunks ch_lo+even -> SA, ch_lo+odd -> SB
-    double sjk[U], ski[U];
-    int r_base = 0; EdgeInfo r_ei{0, 0, 0, 0}; double r_T1 = 0.0, r_T2 = 0.0, r_So = 0.0;
+    StreamRegs SA{}, SB{};                                   // even chunks of this workgroup -> SA, odd ones -> SB
+    struct RecRegs { int base; EdgeInfo ei; };
+    struct GatherRegs { double sjk[U], ski[U], T1, T2, So; };
 #ifdef DESC_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = 0;
 #endif
 
-    auto load_records = [&](int ch) {            // cum / einfo of chunk ch -> registers (clamped, unconditional)
+    // (register sets are passed and returned BY VALUE and every pipelined load is
+    //  unconditional: a reference to a local struct would push it to scratch, and a value merged
+    //  at a control-flow join makes the compiler wait for the load right where it was issued)
+    auto load_records = [&](int ch) -> RecRegs {  // cum / einfo of chunk ch -> registers (clamped, unconditional)
         const int l0 = uniform_load(a.chunk_seg, ch), ns = uniform_load(a.chunk_seg, ch + 1) - l0;
-        r_base = a.cum[l0 + min(tid, ns)];
-        r_ei = a.einfo[l0 + min(tid, ns - 1)];
+        RecRegs rr;
+        rr.base = a.cum[l0 + min(tid, ns)];
+        rr.ei = a.einfo[l0 + min(tid, ns - 1)];
+        return rr;
     };
-    auto publish_records = [&](int ch, SegRec& rr) {
+    auto publish_records = [&](int ch, const RecRegs rg, SegRec& rr) {
         const int ns = uniform_load(a.chunk_seg, ch + 1) - uniform_load(a.chunk_seg, ch);
-        if (tid <= ns) rr.base[tid] = r_base;
-        if (tid < ns) { rr.rbi[tid] = r_ei.rb_i; rr.rbj[tid] = r_ei.rb_j; rr.sa[tid] = r_ei.slot_a; rr.sb[tid] = r_ei.slot_b; }
+        if (tid <= ns) rr.base[tid] = rg.base;
+        if (tid < ns) { rr.rbi[tid] = rg.ei.rb_i; rr.rbj[tid] = rg.ei.rb_j; rr.sa[tid] = rg.ei.slot_a; rr.sb[tid] = rg.ei.slot_b; }
     };
-    // (register sets are passed and returned BY VALUE: a reference to a local struct would
-    //  push it to scratch memory)
     auto load_stream = [&](int ch) -> StreamRegs {            // 16-byte loads; image entry 0 = cycle a0 = c0 & ~3
         const int c0 = uniform_load(a.chunk_c0, ch), c1 = uniform_load(a.chunk_c0, ch + 1);
         const int a0 = c0 & ~3, last = c1 - 1 - a0;          // last image entry that is needed
@@ -494,7 +498,8 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void k_sweep_node(NodeSweepArgs a
             for (int q = lane; q < cnt; q += 64) c_seg[b + q] = (uint8_t)t;
         }
     };
-    auto issue_gathers = [&](int ch, const SegRec& rr, const ChunkBuf& xb) {
+    auto issue_gathers = [&](int ch, const SegRec& rr, const ChunkBuf& xb) -> GatherRegs {
+        GatherRegs gr;
         const int c0 = uniform_load(a.chunk_c0, ch), c1 = uniform_load(a.chunk_c0, ch + 1);
         const int off = c0 & 3, hi = off + (c1 - c0) - 1, ns = uniform_load(a.chunk_seg, ch + 1) - uniform_load(a.chunk_seg, ch);
 #pragma unroll
@@ -504,45 +509,49 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void k_sweep_node(NodeSweepArgs a
             const uint32_t p = xb.pk[q];
             int si = rr.rbi[sg] + (int)(p & 0x7FFFu), sj = rr.rbj[sg] + (int)((p >> 16) & 0x7FFFu);
             if (a.ablate & 1) { si = lane; sj = lane; }     // diagnostics: gathers that always hit L1
-            sjk[u] = a.S_old[sj]; ski[u] = a.S_old[si];
+            gr.sjk[u] = a.S_old[sj]; gr.ski[u] = a.S_old[si];
         }
         const int tt = min(tid, ns - 1);
         const int sa = rr.sa[tt], sb = rr.sb[tt];
-        r_T1 = a.Tfull[sa];                     // column j of node i = sum(wijk(IKJ(mask)))  (:189)
-        r_T2 = a.Tfull[sb];                     // column i of node j = sum(wijk(JKI(mask)))  (:190)
-        r_So = a.S_old[sa];
+        gr.T1 = a.Tfull[sa];                    // column j of node i = sum(wijk(IKJ(mask)))  (:189)
+        gr.T2 = a.Tfull[sb];                    // column i of node j = sum(wijk(JKI(mask)))  (:190)
+        gr.So = a.S_old[sa];
+        return gr;
     };
-    auto park_gathers = [&](int ch, SegRec& rr, ChunkBuf& xb) {
+    auto park_gathers = [&](int ch, const GatherRegs gr, SegRec& rr, ChunkBuf& xb) {
         const int c0 = uniform_load(a.chunk_c0, ch), c1 = uniform_load(a.chunk_c0, ch + 1);
         const int off = c0 & 3, hi = off + (c1 - c0) - 1, ns = uniform_load(a.chunk_seg, ch + 1) - uniform_load(a.chunk_seg, ch);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int q = tid + NT * u;
-            if (q >= off && q <= hi) xb.ss[q] = sjk[u] + ski[u];                                     // S(jk)+S(ki)
+            if (q >= off && q <= hi) xb.ss[q] = gr.sjk[u] + gr.ski[u];                               // S(jk)+S(ki)
         }
-        if (tid < ns) { rr.T1[tid] = r_T1; rr.T2[tid] = r_T2; rr.So[tid] = r_So; }
+        if (tid < ns) { rr.T1[tid] = gr.T1; rr.T2[tid] = gr.T2; rr.So[tid] = gr.So; }
     };
 
     // one pipeline iteration; s1 = register set of chunk ch+1 (and, after parking, of chunk ch+3)
-    auto iterate = [&](int ch, StreamRegs s1) -> StreamRegs {
-        const bool has1 = ch + 1 < ch_hi, has2 = ch + 2 < ch_hi, has3 = ch + 3 < ch_hi;
-        SegRec& rc = R[ch & 1];
-        ChunkBuf& xc = X[ch & 1];
-        SegRec& rn = R[(ch + 1) & 1];
-        ChunkBuf& xn = X[(ch + 1) & 1];
+    auto iterate = [&](int k, StreamRegs s1) -> StreamRegs {
+        // past the end the loads are redirected to this workgroup's current chunk: harmless, and
+        // the pipeline stays free of branches
+        const int ch = lb + k * nb;
+        const int ch1 = k + 1 < nk ? ch + nb : ch, ch2 = k + 2 < nk ? ch + 2 * nb : ch, ch3 = k + 3 < nk ? ch + 3 * nb : ch;
+        SegRec& rc = R[k & 1];
+        ChunkBuf& xc = X[k & 1];
+        SegRec& rn = R[(k + 1) & 1];
+        ChunkBuf& xn = X[(k + 1) & 1];
         STAMP(7);
         __syncthreads();                                        // chunk ch staged, records of ch+1 visible
         STAMP(0);
         // ---- 1: chunk ch+1: park the streamed arrays, segment ids
-        if (has1) park_stream_and_fill(ch + 1, s1, rn, xn);
+        park_stream_and_fill(ch1, s1, rn, xn);
         __syncthreads();
         STAMP(1);
         // ---- 2: its gathers
-        if (has1) issue_gathers(ch + 1, rn, xn);
+        const GatherRegs gr = issue_gathers(ch1, rn, xn);
         STAMP(2);
         // ---- 3: records of chunk ch+2, stream of chunk ch+3
-        if (has2) load_records(ch + 2);
-        if (has3) s1 = load_stream(ch + 3);
+        const RecRegs rg = load_records(ch2);
+        s1 = load_stream(ch3);
         STAMP(3);
         // ---- 4: D(ch)
         const int c0 = uniform_load(a.chunk_c0, ch), c1 = uniform_load(a.chunk_c0, ch + 1), a0 = c0 & ~3;
@@ -625,27 +634,31 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void k_sweep_node(NodeSweepArgs a
         if (tid < nseg) { const double sv = rc.T1[tid]; a.S_new[rc.sa[tid]] = sv; a.S_new[rc.sb[tid]] = sv; }
         STAMP(6);
         // ---- 6: chunk ch+1 complete in LDS; records of chunk ch+2 published
-        if (has1) park_gathers(ch + 1, rn, xn);
-        if (has2) publish_records(ch + 2, rc);
+        park_gathers(ch1, gr, rn, xn);
+        publish_records(ch2, rg, rc);
         return s1;
     };
 
-    // ---- prologue: chunk ch_lo fully staged; ch_lo+1 and ch_lo+2 streaming
-    load_records(ch_lo);
-    SA = load_stream(ch_lo);
-    publish_records(ch_lo, R[ch_lo & 1]);
-    __syncthreads();
-    park_stream_and_fill(ch_lo, SA, R[ch_lo & 1], X[ch_lo & 1]);
-    __syncthreads();
-    issue_gathers(ch_lo, R[ch_lo & 1], X[ch_lo & 1]);
-    if (ch_lo + 1 < ch_hi) { load_records(ch_lo + 1); SB = load_stream(ch_lo + 1); }
-    if (ch_lo + 2 < ch_hi) SA = load_stream(ch_lo + 2);
-    park_gathers(ch_lo, R[ch_lo & 1], X[ch_lo & 1]);
-    if (ch_lo + 1 < ch_hi) publish_records(ch_lo + 1, R[(ch_lo + 1) & 1]);
+    // ---- prologue: chunk 0 of this workgroup fully staged; chunks 1 and 2 streaming
+    {
+        const RecRegs rg0 = load_records(lb);
+        SA = load_stream(lb);
+        publish_records(lb, rg0, R[0]);
+        __syncthreads();
+        park_stream_and_fill(lb, SA, R[0], X[0]);
+        __syncthreads();
+        const GatherRegs gr0 = issue_gathers(lb, R[0], X[0]);
+        const int c1 = nk > 1 ? lb + nb : lb, c2 = nk > 2 ? lb + 2 * nb : lb;
+        const RecRegs rg1 = load_records(c1);
+        SB = load_stream(c1);
+        SA = load_stream(c2);
+        park_gathers(lb, gr0, R[0], X[0]);
+        publish_records(c1, rg1, R[1]);
+    }
 
-    for (int ch = ch_lo; ch < ch_hi; ch += 2) {
-        SB = iterate(ch, SB);                                   // chunk ch+1 (odd offset) lives in SB
-        if (ch + 1 < ch_hi) SA = iterate(ch + 1, SA);
+    for (int k = 0; k < nk; k += 2) {
+        SB = iterate(k, SB);                                    // odd chunks live in SB, even ones in SA
+        if (k + 1 < nk) SA = iterate(k + 1, SA);
     }
 #ifdef DESC_STAMPS
     if (tid == 0 && a.stamps) for (int k = 0; k < 8; ++k) a.stamps[8 * lb + k] = stamp_acc[k];

@@ -203,3 +203,26 @@ def test_desc_pgd_wrapper_unsorted_input_and_plugin_state(lib, oracle):
     am = np.zeros(st["m_cycle"]); av = np.zeros(st["m_cycle"])
     r1 = oracle.pgd_run(st, S0, 5, step_kind=2, lr=0.002, beta1=0.9, beta2=0.999, decay_interval=10, adam_m=am, adam_v=av)
     assert np.abs(H.m_t - am).max() < 1e-9 and np.abs(H.v_t - av).max() < 1e-9
+
+
+@pytest.mark.parametrize("kind,n,p", [("uniform", 12, 0.6), ("uniform", 40, 0.5), ("uniform", 150, 0.55), ("uniform", 500, 0.1),
+                                      ("nonuniform", 120, 0.4), ("uniform", 300, 0.9)])
+def test_device_structure_build_bit_exact(lib, oracle, kind, n, p):
+    """a-1..a-3 on the device (DESC_BUILD_DEVICE) == host builder == oracle, bit for bit."""
+    mo, nn, ii, jj, rij = make_problem(kind, n=n, p=p, seed=13)
+    for seed in (0, 77):
+        dev = lib.Structure.build(lib.ProblemArrays(nn, ii, jj), 30, seed, lib.BUILD_DEVICE, 0).arrays()
+        ref = oracle.build_structure(nn, ii, jj, seed=seed)
+        assert_structure_equal(dev, ref)
+        assert np.array_equal(dev["codeg"], ref["codeg"]) and dev["max_cnt"] == int(np.diff(ref["cum_ind"]).max())
+
+
+def test_device_structure_edge_cases(lib):
+    a = lib.Structure.build(lib.ProblemArrays(5, np.array([0, 1, 2, 2], dtype=np.int32), np.array([1, 2, 3, 4], dtype=np.int32)),
+                            30, 0, lib.BUILD_DEVICE, 0).arrays()
+    assert a["m_pos"] == 0 and a["m_cycle"] == 0 and a["n_sample"] == 30
+    from desc_amd import ConstantStepSize, DESC_PGD
+    mo, nn, ii, jj, rij = make_problem("uniform", n=70, p=0.5, seed=14)
+    S_host = DESC_PGD(mo.Ind, mo.RijMat, dict(iters=20, Gradient=ConstantStepSize(0.01), seed=5, verbose=False))
+    S_dev = DESC_PGD(mo.Ind, mo.RijMat, dict(iters=20, Gradient=ConstantStepSize(0.01), seed=5, verbose=False, build_where=lib.BUILD_DEVICE))
+    assert np.array_equal(S_host, S_dev)

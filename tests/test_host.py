@@ -37,7 +37,7 @@ def test_struct_layouts_match_header(lib):
     assert C.sizeof(lib.Result) == 96
     assert C.sizeof(lib.StructureView) == 104
     p = lib.default_params()
-    assert (p.iters, p.step_kind, p.patience, p.n_sample_min) == (100, 0, 30, 30)
+    assert (p.iters, p.step_kind, p.patience, p.n_sample_min, p.build_where) == (100, 0, 30, 30, lib.BUILD_DEVICE)
     assert p.lr == 0.01 and p.stop_tol == 1e-5
 
 
