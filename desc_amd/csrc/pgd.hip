@@ -673,13 +673,13 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void k_sweep_node(NodeSweepArgs a
 // round-robin; third vertices inside a segment are distinct), copies are added in a
 // fixed order at the end -> bitwise reproducible.  Loads of COLSUM_U segments are in
 // flight per wave at once.
-constexpr int COLSUM_U = 16;
+constexpr int COLSUM_U = 8;
 __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, const int2* adj_seg, const uint32_t* pk, const double* w,
                                                      double* Tfull, int n, int stride_cols, const DevState* st) {
     if (st->stop) return;
     extern __shared__ double acc[];                   // [4][stride_cols] doubles, then 2 ints per incident edge
     int* seg_base = (int*)(acc + 4 * stride_cols);
-    int* seg_cf = seg_base + stride_cols;             // cnt | (v is the smaller endpoint) << 31
+    int* seg_cf = seg_base + stride_cols;             // n_both | n_i << 7 | n_jonly << 14 | (v is the smaller endpoint) << 31
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int v = blockIdx.x; v < n; v += gridDim.x) {
         const int r0 = rowptr[v], deg = rowptr[v + 1] - r0;
@@ -691,28 +691,48 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
         }
         __syncthreads();
         double* mine = acc + wv * stride_cols;
-        for (int t = wv; t < deg; t += 4 * COLSUM_U) {
-            uint32_t pv[COLSUM_U]; double wvv[COLSUM_U]; uint32_t sh[COLSUM_U];
-            // issue every load of the batch before touching any result (no use between loads:
-            // the compiler would otherwise wait for each one)
+        // Inside a segment the cycles are ordered [both mirrors | (ik;j) only | (jk;i) only |
+        // none], so an endpoint reads only the `nact` cycles that contribute to its columns
+        // (~n_sample/codeg of them).  A wave instruction serves 4 segments x 16 lanes; segments
+        // with more than 16 contributing cycles take further passes.  Every load of a batch is
+        // issued before any result is touched (a use between loads would make the compiler wait
+        // for each one).
+        const int sub = lane >> 4, l16 = lane & 15;
+        for (int g0 = wv; 4 * g0 < deg; g0 += 4 * COLSUM_U) {      // groups of 4 consecutive segments, dealt to waves round-robin
+            // pieces 0 and 1 (contributing cycles 0..31 of each segment) are loaded together;
+            // segments with more take further rounds
+            for (int round = 0; round < 2; ++round) {
+                uint32_t pv[2 * COLSUM_U]; double wvv[2 * COLSUM_U]; uint32_t sh[COLSUM_U];
+                bool more = false;
 #pragma unroll
-            for (int u = 0; u < COLSUM_U; ++u) {
-                const int tt = t + 4 * u;
-                pv[u] = 0; wvv[u] = 0.0; sh[u] = 16;
-                if (tt < deg) {
-                    const uint32_t cf = (uint32_t)seg_cf[tt];
-                    sh[u] = (cf & 0x80000000u) ? 0u : 16u;
-                    if (lane < (int)(cf & 0x7FFFFFFFu)) {
-                        const int64_t c = (int64_t)seg_base[tt] + lane;
-                        pv[u] = pk[c];
-                        wvv[u] = w[c];
+                for (int u = 0; u < COLSUM_U; ++u) {
+                    const int tt = 4 * (g0 + 4 * u) + sub;
+                    pv[2 * u] = 0; pv[2 * u + 1] = 0; wvv[2 * u] = 0.0; wvv[2 * u + 1] = 0.0; sh[u] = 16;
+                    if (tt < deg) {
+                        const uint32_t cf = (uint32_t)seg_cf[tt];
+                        const int n_both = cf & 0x7Fu, n_i = (cf >> 7) & 0x7Fu, n_jo = (cf >> 14) & 0x7Fu;
+                        const bool v_is_i = cf & 0x80000000u;
+                        sh[u] = v_is_i ? 0u : 16u;
+                        const int nact = v_is_i ? n_i : n_both + n_jo;
+                        more |= nact > 32 * (round + 1);
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const int q = l16 + 16 * (2 * round + h2);
+                            if (q < nact) {
+                                const int off = (v_is_i || q < n_both) ? q : n_i + (q - n_both);
+                                const int64_t c = (int64_t)seg_base[tt] + off;
+                                pv[2 * u + h2] = pk[c];
+                                wvv[2 * u + h2] = w[c];
+                            }
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < COLSUM_U; ++u) {
-                const uint32_t half = (pv[u] >> sh[u]) & 0xFFFFu;
-                if (half & 0x8000u) unsafeAtomicAdd(&mine[half & 0x7FFFu], wvv[u]);   // ds_add_f64; same-wave adds stay in program order
+                for (int u = 0; u < 2 * COLSUM_U; ++u) {
+                    const uint32_t half = (pv[u] >> sh[u >> 1]) & 0xFFFFu;
+                    if (half & 0x8000u) unsafeAtomicAdd(&mine[half & 0x7FFFu], wvv[u]);   // ds_add_f64
+                }
+                if (!__any(more)) break;
             }
         }
         __syncthreads();
@@ -797,16 +817,17 @@ __global__ void k_extract_S(const double* Sfull, const int32_t* eslot, double* S
         S_vec[e] = Sfull[eslot[e]];
 }
 // per-cycle vector between natural order and device order (dir 0: natural -> device, 1: device -> natural)
-__global__ __launch_bounds__(256) void k_reorder_cycles(const int32_t* cum, const int32_t* src_start, const double* in,
-                                                        double* out, int m_pos, int dir) {
+__global__ __launch_bounds__(256) void k_reorder_cycles(const int32_t* cum, const int32_t* src_start, const uint8_t* seg_perm,
+                                                        const double* in, double* out, int m_pos, int dir) {
     const int lane = threadIdx.x & 63;
     const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * 256) >> 6;
     for (int64_t l = wid; l < m_pos; l += nw) {
         const int base = cum[l], cnt = cum[l + 1] - base, src = src_start[l];
         for (int t = lane; t < cnt; t += 64) {
-            if (dir == 0) out[(int64_t)base + t] = in[(int64_t)src + t];
-            else out[(int64_t)src + t] = in[(int64_t)base + t];
+            const int o = seg_perm[(int64_t)base + t];          // natural offset of the cycle stored at device slot t
+            if (dir == 0) out[(int64_t)base + t] = in[(int64_t)src + o];
+            else out[(int64_t)src + o] = in[(int64_t)base + t];
         }
     }
 }
@@ -937,6 +958,7 @@ struct desc_pgd {
     int nchunks = 0;
     double *d_T = nullptr, *d_Svec = nullptr;
     unsigned long long* d_stamps = nullptr;
+    uint8_t* d_seg_perm = nullptr;     // natural in-segment offset of every device-order cycle
     // sharding (world == 1: the whole problem)
     int rank = 0, world = 1;
     int64_t seg_lo = 0, seg_hi = 0;     // device-order range of segments owned by this rank
@@ -1255,6 +1277,28 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
             einfo[q] = EdgeInfo{rowptr[i], rowptr[j], eslot[e], rowptr[j] + idx_in_row(j, i)};
         }
     });
+    // k with the two mirror-present bits of the owned cycles, device order.  Inside a segment
+    // the cycles are stored [both mirrors sampled | (ik;j) only | (jk;i) only | none] (ascending k
+    // within a class): the column-sum pass then reads only the cycles that contribute
+    // (a fraction ~n_sample/codeg of them), the per-segment arithmetic is order independent.
+    std::vector<uint32_t> kf((size_t)mcl);
+    std::vector<uint8_t> seg_perm((size_t)mcl);
+    std::vector<uint32_t> seg_counts((size_t)mp, 0);          // n_both | n_i << 7 | n_jonly << 14 (owned segments)
+    host_parallel(nsl, [&](int64_t a, int64_t b) {
+        for (int64_t q = h->seg_lo + a; q < h->seg_lo + b; ++q) {
+            const int64_t src = src_start[q], dst = cum_loc[q], cnt = cum2[q + 1] - cum2[q];
+            int n_cls[4] = {0, 0, 0, 0};                      // class 0 both, 1 i-only, 2 j-only, 3 none
+            auto cls = [&](int64_t t) { const bool fi = s->ikj[src + t] >= 0, fj = s->jki[src + t] >= 0; return fi ? (fj ? 0 : 1) : (fj ? 2 : 3); };
+            for (int64_t t = 0; t < cnt; ++t) n_cls[cls(t)]++;
+            int pos[4] = {0, n_cls[0], n_cls[0] + n_cls[1], n_cls[0] + n_cls[1] + n_cls[2]};
+            for (int64_t t = 0; t < cnt; ++t) {
+                const int o = pos[cls(t)]++;
+                kf[dst + o] = (uint32_t)s->k[src + t] | (s->ikj[src + t] >= 0 ? 1u << 30 : 0u) | (s->jki[src + t] >= 0 ? 1u << 31 : 0u);
+                seg_perm[dst + o] = (uint8_t)t;
+            }
+            seg_counts[q] = (uint32_t)n_cls[0] | (uint32_t)(n_cls[0] + n_cls[1]) << 7 | (uint32_t)n_cls[2] << 14;
+        }
+    });
     std::vector<int2> adj_seg((size_t)2 * m);
     host_parallel(n, [&](int64_t a, int64_t b) {
         for (int64_t v = a; v < b; ++v)
@@ -1263,19 +1307,10 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
                 int2 rec{0, 0};
                 if (q >= h->seg_lo && q < h->seg_hi) {       // only segments this rank owns
                     rec.x = cum_loc[q];
-                    rec.y = (int)((uint32_t)(cum2[q + 1] - cum2[q]) | (v < adj[t] ? 0x80000000u : 0u));
+                    rec.y = (int)(seg_counts[q] | (v < adj[t] ? 0x80000000u : 0u));
                 }
                 adj_seg[t] = rec;
             }
-    });
-    // k with the two mirror-present bits of the owned cycles, device order
-    std::vector<uint32_t> kf((size_t)mcl);
-    host_parallel(nsl, [&](int64_t a, int64_t b) {
-        for (int64_t q = h->seg_lo + a; q < h->seg_lo + b; ++q) {
-            const int64_t src = src_start[q], dst = cum_loc[q], cnt = cum2[q + 1] - cum2[q];
-            for (int64_t t = 0; t < cnt; ++t)
-                kf[dst + t] = (uint32_t)s->k[src + t] | (s->ikj[src + t] >= 0 ? 1u << 30 : 0u) | (s->jki[src + t] >= 0 ? 1u << 31 : 0u);
-        }
     });
     // chunk tables: all chunks, local cycle numbering
     std::vector<int32_t> chunk_seg(P.chunk_seg), chunk_c0((size_t)nch_all + 2);
@@ -1287,6 +1322,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     if ((rc = dalloc(h, &h->d_w[0], mcl + 8))) return rc;
     if ((rc = dalloc(h, &h->d_w[1], mcl + 8))) return rc;
     if ((rc = dalloc(h, &h->d_pk, mcl + 8))) return rc;
+    if ((rc = dalloc(h, &h->d_seg_perm, mcl))) return rc;
     if ((rc = dalloc(h, &h->d_einfo, mp))) return rc;
     if ((rc = dalloc(h, &h->d_rowptr, n + 1))) return rc;
     if ((rc = dalloc(h, &h->d_adj_seg, 2 * m))) return rc;
@@ -1325,6 +1361,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     if ((rc = upload(h, d_adj_eid, adj_eid.data(), (size_t)2 * m))) return rc;
     if ((rc = upload(h, d_pos_edge2, pos_edge2.data(), (size_t)mp))) return rc;
     if ((rc = upload(h, d_kf, kf.data(), (size_t)mcl))) return rc;
+    if ((rc = upload(h, h->d_seg_perm, seg_perm.data(), (size_t)mcl))) return rc;
     if ((rc = upload(h, d_rij, prob->rij, 9 * (size_t)m))) return rc;
     DESC_HIP(hipStreamSynchronize(h->stream));
     h->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1381,14 +1418,14 @@ int cycles_to_device(desc_pgd* h, const double* host, double* dev) {
     if (h->variant != VARIANT_NODE) { DESC_HIP(hipMemcpyAsync(dev, host, sizeof(double) * h->m_cycle, hipMemcpyHostToDevice, h->stream)); return DESC_OK; }
     DESC_HIP(hipMemcpyAsync(h->d_scratch, host, sizeof(double) * h->m_cycle, hipMemcpyHostToDevice, h->stream));
     int g = (int)std::min<int64_t>(4096, (h->m_pos + 3) / 4);
-    hipLaunchKernelGGL(k_reorder_cycles, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo, h->d_scratch, dev, (int)(h->seg_hi - h->seg_lo), 0);
+    hipLaunchKernelGGL(k_reorder_cycles, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo, h->d_seg_perm, h->d_scratch, dev, (int)(h->seg_hi - h->seg_lo), 0);
     return DESC_OK;
 }
 int cycles_to_host(desc_pgd* h, const double* dev, double* host) {
     if (h->m_cycle == 0) return DESC_OK;
     if (h->variant != VARIANT_NODE) { DESC_HIP(hipMemcpy(host, dev, sizeof(double) * h->m_cycle, hipMemcpyDeviceToHost)); return DESC_OK; }
     int g = (int)std::min<int64_t>(4096, (h->m_pos + 3) / 4);
-    hipLaunchKernelGGL(k_reorder_cycles, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo, dev, h->d_scratch, (int)(h->seg_hi - h->seg_lo), 1);
+    hipLaunchKernelGGL(k_reorder_cycles, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo, h->d_seg_perm, dev, h->d_scratch, (int)(h->seg_hi - h->seg_lo), 1);
     DESC_HIP(hipMemcpyAsync(host, h->d_scratch, sizeof(double) * h->m_cycle, hipMemcpyDeviceToHost, h->stream));
     DESC_HIP(hipStreamSynchronize(h->stream));
     return DESC_OK;
