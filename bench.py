@@ -138,6 +138,14 @@ def main():
 
     bytes_per_launch = 72.0 * m_cycle + 12.0 * m_pos
     achieved = bytes_per_launch / (ms_kernel * 1e-3) / 1e9 if ms_kernel else 0.0
+    # HBM traffic per iteration from the PMC passes committed under profiles/ (rocprofv3 cannot
+    # be run from inside the bench); null for workloads that have not been profiled
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            traffic = json.load(f).get(name, {}).get("per_iteration_bytes")
+    except OSError:
+        pass
     line = {
         "metric": "DESC_PGD iters/sec", "value": K / dt, "unit": "iters/s", "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -145,7 +153,8 @@ def main():
         "config": {"workload": describe(name), "n": nn, "m": m, "m_pos": m_pos, "m_cycle": m_cycle,
                    "n_sample": int(arrays["n_sample"]), "sampling_seed": args.seed, "parallelism": "1 GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "k_colsum_node + " + kname + "0> (one iteration = both launches)" if "node" in kname else kname,
                      "bytes_per_launch": bytes_per_launch, "kernel_ms": ms_kernel},
         "cycle_updates_per_s": m_cycle * K / dt,
         "setup_ms": {"generate": t_gen * 1e3, "structure_device": t_struct * 1e3, "upload_layout_cycle_d": t_create * 1e3},
