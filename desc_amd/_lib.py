@@ -26,7 +26,7 @@ EXPORTS = [
     "desc_pgd_iterate_timed", "desc_pgd_sync", "desc_pgd_download", "desc_pgd_get_s0",
     "desc_pgd_sizes", "desc_pgd_kernel_name", "desc_pgd_solve", "desc_selftest_group_sum",
     "desc_pgd_create_shard", "desc_pgd_shard_info", "desc_pgd_shard_bind", "desc_pgd_shard_colsum", "desc_pgd_shard_sweep",
-    "desc_pgd_shard_finish", "desc_pgd_shard_objective", "desc_pgd_stopped",
+    "desc_pgd_shard_finish", "desc_pgd_shard_objective", "desc_pgd_stopped", "desc_spectral_run",
 ]
 
 I32P = C.POINTER(C.c_int32)
@@ -65,6 +65,11 @@ class ShardInfo(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("t_len", C.c_int64), ("slice_len", C.c_int64),
                 ("seg_lo", C.c_int64), ("seg_hi", C.c_int64), ("cyc_lo", C.c_int64), ("cyc_hi", C.c_int64),
                 ("m_pos", C.c_int64), ("m_cycle", C.c_int64)]
+
+
+class SpectralInfo(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("products", C.c_int32), ("converged", C.c_int32), ("reserved", C.c_int32), ("residual", C.c_double),
+                ("eigenvalues", C.c_double * 3), ("ms_total", C.c_double)]
 
 
 class DescError(RuntimeError):
@@ -124,6 +129,8 @@ def load():
     L.desc_pgd_shard_finish.argtypes = [C.c_void_p, C.c_int32]
     L.desc_pgd_shard_objective.argtypes = [C.c_void_p, C.c_int32]
     L.desc_pgd_stopped.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    L.desc_spectral_run.argtypes = [C.POINTER(Problem), F64P, C.c_int32, C.c_double, C.c_int32, C.c_int32, F64P,
+                                    C.POINTER(SpectralInfo)]
     _lib = L
     return L
 
@@ -319,6 +326,18 @@ class Solver:
             self.destroy()
         except Exception:
             pass
+
+
+def spectral_run(prob: ProblemArrays, weights=None, normalize_rows=False, tol=1e-13, max_iters=500, device=0):
+    """desc_spectral_run -> (R (3,3,n) Fortran-ordered, info dict)."""
+    n = prob.c.n
+    R = np.zeros(9 * max(n, 1))
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+    info = SpectralInfo()
+    check(load().desc_spectral_run(C.byref(prob.c), ptr(w, F64P), 1 if normalize_rows else 0, tol, max_iters, device,
+                                   ptr(R, F64P), C.byref(info)))
+    return R[:9 * n].reshape((3, 3, n), order="F"), dict(iters=info.iters, products=info.products, converged=bool(info.converged), residual=info.residual,
+                                                        eigenvalues=list(info.eigenvalues), ms_total=info.ms_total)
 
 
 def device_count():

@@ -185,3 +185,43 @@ def DESC_PGD(Ind, RijMat, params, return_info=False):
         info["ms_structure"] = ms_structure
         return S_vec, info
     return S_vec
+
+
+def Spectral(Ind, RijMat, device=0, return_info=False):
+    """R_est = Spectral(Ind, RijMat) -- Algorithms/Spectral.m:15.  3 x 3 x n rotations, defined
+    up to one global right rotation (use Rotation_Alignment to compare)."""
+    n, ii, jj, rij, perm = marshal_edges(Ind, RijMat)
+    prob = _lib.ProblemArrays(n, ii, jj, rij)
+    R, info = _lib.spectral_run(prob, None, False, device=device)
+    return (R, info) if return_info else R
+
+
+def GCW(Ind, AdjMat, RijMat, S_vec, device=0, return_info=False):
+    """R_est = GCW(Ind, AdjMat, RijMat, S_vec) -- Utils/GCW.m:1.  ``AdjMat`` is accepted for
+    signature compatibility and not used (it is implied by ``Ind``)."""
+    n, ii, jj, rij, perm = marshal_edges(Ind, RijMat)
+    S = np.asarray(S_vec, dtype=np.float64).reshape(-1)
+    if S.shape[0] != ii.shape[0]:
+        raise ValueError("S_vec must have one entry per edge")
+    if perm is not None:
+        S = S[perm]
+    w = 1.0 / (S ** 1.5 + 1e-8)                               # GCW.m:20
+    prob = _lib.ProblemArrays(n, ii, jj, rij)
+    R, info = _lib.spectral_run(prob, w, True, device=device)
+    return (R, info) if return_info else R
+
+
+def Rotation_Alignment(R_est, R_gt):
+    """[R_out, R_align, mean_error, median_error] = Rotation_Alignment(R_est, R_gt)
+    -- Utils/Rotation_Alignment.m:13-38 (evaluation helper: host NumPy, O(n))."""
+    R_est = np.asarray(R_est, dtype=np.float64); R_gt = np.asarray(R_gt, dtype=np.float64)
+    d, n = R_gt.shape[0], R_gt.shape[2]
+    A = np.einsum("abk,ack->bc", R_est, R_gt)                 # sum_k R_est_k' R_gt_k
+    U1, _, V1t = np.linalg.svd(A)
+    D = np.eye(d); D[-1, -1] = np.linalg.det(U1 @ V1t)
+    R_align = U1 @ D @ V1t
+    R_out = np.einsum("abk,bc->ack", R_est, R_align)
+    tr = np.einsum("abk,abk->k", R_gt, R_out)
+    x = (tr - 1.0) / 2.0
+    err = np.where(np.abs(x) <= 1, np.arccos(np.clip(x, -1, 1)), np.abs(np.arccos(x.astype(complex)))) / np.pi * 180
+    return R_out, R_align, float(np.mean(err)), float(np.median(err))

@@ -1,0 +1,422 @@
+// Spectral / GCW synchronisation: top-3 eigenvectors of the 3n x 3n block
+// connection matrix by block subspace iteration on the device, then per-node projection
+// onto SO(3).
+//
+// Reference text reproduced:
+//   Algorithms/Spectral.m:18-46   Rij_blk (blocks R_ij / R_ij'), eigs(.,3,'la'), sign fix, SVD projection
+//   Utils/GCW.m:9-36              the same with weights 1/(s^1.5+1e-8), row-normalised (:20-21)
+// The reference builds a dense 3n x 3n matrix (1.8 GB at n = 5000) and calls eigs (Krylov-
+// Schur).  Here the matrix is block-CSR with 2m blocks of 72 B (each edge in both endpoint
+// rows, transposed in the larger endpoint's row); GCW's row-normalised D^-1 A is iterated in
+// its symmetric similar form D^-1/2 A D^-1/2 (eigenvectors mapped back by D^-1/2 and
+// re-normalised to unit 2-norm, as eigs returns them).  Block size 6 (3 wanted + 3 guard
+// vectors), Chebyshev-filtered subspace iteration (the filter damps [-sigma, smallest Ritz value]),
+// Rayleigh-Ritz in every outer step (b x b work on the host), explicit-residual stop.
+// HBM-bound: 144 B and 54*b/3 flops per block and step; MFMA is not used (3x3 blocks, f64).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "device_utils.h"
+
+namespace desc {
+namespace {
+
+constexpr int BW = 6;    // block width of the subspace iteration
+
+// y[v] = alpha * sum_t blocks[t] * x[adj[t]] + s1 * x[v] + s2 * z[v];  x, y, z: (3n x BW) row-major
+// (z may alias y: every element is read before it is written by the same lane); 16 lanes per node row
+__global__ __launch_bounds__(256) void k_bsr_spmm(const int32_t* rowptr, const int32_t* adj, const double* blocks, const double* x,
+                                                  const double* z, double* y, int n, double alpha, double s1, double s2) {
+    const int lane = threadIdx.x & 63, l16 = lane & 15;
+    const int row0 = (blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int nrows = (gridDim.x * 256) >> 4;
+    for (int vb = row0 - (row0 % 4); vb < n; vb += nrows) {      // the 4 rows of a wave advance together (DPP needs full waves)
+        const int v = vb + (row0 % 4);
+        double acc[3][BW];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < BW; ++c) acc[r][c] = 0.0;
+        if (v < n) {
+            for (int t = rowptr[v] + l16; t < rowptr[v + 1]; t += 16) {
+                const double* B = blocks + 9 * (int64_t)t;          // column-major 3x3: B(r,k) = B[r + 3k]
+                const double* xj = x + (int64_t)3 * BW * adj[t];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int c = 0; c < BW; ++c) {
+                        const double xv = xj[k * BW + c];
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) acc[r][c] += B[r + 3 * k] * xv;
+                    }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < BW; ++c) acc[r][c] = group16_sum(acc[r][c]);
+        if (v < n && l16 == 0) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < BW; ++c) {
+                    const int64_t o = ((int64_t)3 * v + r) * BW + c;
+                    y[o] = alpha * acc[r][c] + s1 * x[o] + (s2 != 0.0 ? s2 * z[o] : 0.0);
+                }
+        }
+    }
+}
+
+// partial Gram matrices per workgroup: G1 = X'Y, G2 = Y'Y  (rows = 3n)
+__global__ __launch_bounds__(256) void k_gram(const double* X, const double* Y, int64_t rows, double* partials) {
+    double g1[BW][BW], g2[BW][BW];
+#pragma unroll
+    for (int a = 0; a < BW; ++a)
+#pragma unroll
+        for (int b = 0; b < BW; ++b) { g1[a][b] = 0.0; g2[a][b] = 0.0; }
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+        double xr[BW], yr[BW];
+#pragma unroll
+        for (int c = 0; c < BW; ++c) { xr[c] = X[r * BW + c]; yr[c] = Y[r * BW + c]; }
+#pragma unroll
+        for (int a = 0; a < BW; ++a)
+#pragma unroll
+            for (int b = 0; b < BW; ++b) { g1[a][b] += xr[a] * yr[b]; g2[a][b] += yr[a] * yr[b]; }
+    }
+    __shared__ double sh[4][2 * BW * BW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < BW; ++a)
+#pragma unroll
+        for (int b = 0; b < BW; ++b) {
+            const double s1 = group_sum<64>(g1[a][b]), s2 = group_sum<64>(g2[a][b]);
+            if (lane == 0) { sh[wv][a * BW + b] = s1; sh[wv][BW * BW + a * BW + b] = s2; }
+        }
+    __syncthreads();
+    if (threadIdx.x < 2 * BW * BW)
+        partials[(int64_t)blockIdx.x * 2 * BW * BW + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+// Xnew = Y * C  (C: BW x BW row-major, passed by value)
+struct SmallMat { double c[BW * BW]; };
+struct ResArgs { double z[BW * 3]; double theta[3]; };
+// explicit residuals of the three wanted Ritz pairs: partial sums of |Y z_c - theta_c X z_c|^2
+// (the Gram-matrix form z'G2z - theta^2 cancels catastrophically below ~1e-8 relative)
+__global__ __launch_bounds__(256) void k_residual(const double* X, const double* Y, int64_t rows, ResArgs a, double* partials) {
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double yz = 0.0, xz = 0.0;
+#pragma unroll
+            for (int k = 0; k < BW; ++k) { yz += Y[r * BW + k] * a.z[k * 3 + c]; xz += X[r * BW + k] * a.z[k * 3 + c]; }
+            const double d = yz - a.theta[c] * xz;
+            acc[c] += d * d;
+        }
+    }
+    __shared__ double sh[4][3];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const double s = group_sum<64>(acc[c]); if (lane == 0) sh[wv][c] = s; }
+    __syncthreads();
+    if (threadIdx.x < 3) partials[(int64_t)blockIdx.x * 3 + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+__global__ void k_combine(const double* Y, double* Xn, int64_t rows, SmallMat C) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        double yr[BW];
+#pragma unroll
+        for (int c = 0; c < BW; ++c) yr[c] = Y[r * BW + c];
+#pragma unroll
+        for (int b = 0; b < BW; ++b) {
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a < BW; ++a) s += yr[a] * C.c[a * BW + b];
+            Xn[r * BW + b] = s;
+        }
+    }
+}
+
+// ---- small dense helpers (host) ---------------------------------------------------------
+// cyclic Jacobi eigen-decomposition of a symmetric N x N matrix (row-major); eigenvalues
+// descending in w, eigenvectors in the columns of V
+template <int N>
+void jacobi_eig(const double* Ain, double* w, double* V) {
+    double A[N][N];
+    for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) { A[i][j] = 0.5 * (Ain[i * N + j] + Ain[j * N + i]); V[i * N + j] = i == j; }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < N; ++p) for (int q = p + 1; q < N; ++q) off += A[p][q] * A[p][q];
+        if (off < 1e-300) break;
+        for (int p = 0; p < N; ++p)
+            for (int q = p + 1; q < N; ++q) {
+                if (std::fabs(A[p][q]) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < N; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq; }
+                for (int k = 0; k < N; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk; }
+                for (int k = 0; k < N; ++k) { const double vkp = V[k * N + p], vkq = V[k * N + q]; V[k * N + p] = c * vkp - s * vkq; V[k * N + q] = s * vkp + c * vkq; }
+            }
+    }
+    int idx[N];
+    for (int i = 0; i < N; ++i) idx[i] = i;
+    std::sort(idx, idx + N, [&](int a, int b) { return A[a][a] > A[b][b]; });
+    double Vs[N * N];
+    for (int c = 0; c < N; ++c) { w[c] = A[idx[c]][idx[c]]; for (int k = 0; k < N; ++k) Vs[k * N + c] = V[k * N + idx[c]]; }
+    std::memcpy(V, Vs, sizeof Vs);
+}
+
+// R = U*diag(1,1,det(U*V'))*V' for the 3x3 block M (row-major)  (Spectral.m:43-45)
+void project_so3(const double* M, double* R) {
+    // eigen-decomposition of M'M gives V and the singular values; U = M V / sigma
+    double MtM[9], w[3], V[9];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { double s = 0; for (int k = 0; k < 3; ++k) s += M[k * 3 + a] * M[k * 3 + b]; MtM[a * 3 + b] = s; }
+    jacobi_eig<3>(MtM, w, V);
+    double U[9];
+    const double s0 = std::sqrt(std::max(w[0], 0.0));
+    int good = 0;
+    for (int c = 0; c < 3; ++c) {
+        const double sc = std::sqrt(std::max(w[c], 0.0));
+        if (sc > 1e-12 * std::max(s0, 1e-300) && sc > 1e-300) {
+            for (int r = 0; r < 3; ++r) { double s = 0; for (int k = 0; k < 3; ++k) s += M[r * 3 + k] * V[k * 3 + c]; U[r * 3 + c] = s / sc; }
+            good = c + 1;
+        } else break;
+    }
+    if (good == 0) { for (int i = 0; i < 9; ++i) { U[i] = (i % 4 == 0); V[i] = (i % 4 == 0); } good = 3; }   // svd(0): U = V = I
+    if (good == 1) {      // complete an orthonormal basis
+        double a[3] = {U[0], U[3], U[6]}; int k = std::fabs(a[0]) < std::fabs(a[1]) ? (std::fabs(a[0]) < std::fabs(a[2]) ? 0 : 2) : (std::fabs(a[1]) < std::fabs(a[2]) ? 1 : 2);
+        double e[3] = {0, 0, 0}; e[k] = 1;
+        double b[3] = {a[1] * e[2] - a[2] * e[1], a[2] * e[0] - a[0] * e[2], a[0] * e[1] - a[1] * e[0]};
+        const double nb = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+        for (int r = 0; r < 3; ++r) U[r * 3 + 1] = b[r] / nb;
+        good = 2;
+    }
+    if (good == 2) {
+        const double a[3] = {U[0], U[3], U[6]}, b[3] = {U[1], U[4], U[7]};
+        U[2] = a[1] * b[2] - a[2] * b[1]; U[5] = a[2] * b[0] - a[0] * b[2]; U[8] = a[0] * b[1] - a[1] * b[0];
+    }
+    auto det3 = [](const double* A) { return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]); };
+    double UVt[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += U[r * 3 + k] * V[c * 3 + k]; UVt[r * 3 + c] = s; }
+    const double d = det3(UVt) < 0 ? -1.0 : 1.0;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[r * 3 + c] = U[r * 3 + 0] * V[c * 3 + 0] + U[r * 3 + 1] * V[c * 3 + 1] + d * U[r * 3 + 2] * V[c * 3 + 2];
+}
+
+struct Dev {
+    std::vector<void*> p;
+    ~Dev() { for (void* q : p) if (q) (void)hipFree(q); }
+    template <class T> int alloc(T** out, size_t count) {
+        void* q = nullptr;
+        DESC_HIP(hipMalloc(&q, sizeof(T) * (count ? count : 1)));
+        p.push_back(q); *out = (T*)q;
+        return DESC_OK;
+    }
+};
+
+}  // namespace
+}  // namespace desc
+
+using namespace desc;
+
+extern "C" int desc_spectral_run(const desc_problem* prob, const double* weights, int32_t normalize_rows, double tol,
+                                 int32_t max_iters, int32_t device, double* R_out, desc_spectral_info* info) {
+    if (!prob || !R_out) return fail(DESC_ERR_INVALID, "NULL argument");
+    int rc = validate_problem(prob, true);
+    if (rc) return rc;
+    const int64_t n = prob->n, m = prob->m;
+    if (n == 0) return DESC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DESC_ERR_HIP, "no HIP device visible: the eigen-solve has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(DESC_ERR_INVALID, "device %d out of range", device);
+    DESC_HIP(hipSetDevice(device));
+    auto t0 = std::chrono::steady_clock::now();
+    if (tol <= 0) tol = 1e-13;
+    if (max_iters <= 0) max_iters = 500;
+
+    // block CSR: every edge in both endpoint rows
+    std::vector<int32_t> rowptr((size_t)n + 1, 0), adj((size_t)2 * m);
+    std::vector<double> blocks((size_t)18 * m), deg((size_t)n, 0.0);
+    for (int64_t e = 0; e < m; ++e) { rowptr[prob->ind_i[e] + 1]++; rowptr[prob->ind_j[e] + 1]++; }
+    for (int64_t v = 0; v < n; ++v) rowptr[v + 1] += rowptr[v];
+    for (int64_t e = 0; e < m; ++e) {
+        const double w = weights ? weights[e] : 1.0;
+        if (!(w >= 0) || !std::isfinite(w)) return fail(DESC_ERR_INVALID, "weight %lld is not a finite non-negative number", (long long)e);
+        deg[prob->ind_i[e]] += w; deg[prob->ind_j[e]] += w;
+    }
+    double sigma = 0.0;
+    std::vector<double> dinv((size_t)n, 1.0);               // D^-1/2
+    if (normalize_rows) {
+        for (int64_t v = 0; v < n; ++v) dinv[v] = deg[v] > 0 ? 1.0 / std::sqrt(deg[v]) : 0.0;
+        sigma = 1.0;                                        // spectrum of D^-1/2 A D^-1/2 lies in [-1,1]
+    } else {
+        for (int64_t v = 0; v < n; ++v) sigma = std::max(sigma, deg[v]);   // ||A||_2 <= max weighted degree (orthogonal blocks)
+    }
+    {
+        std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
+        for (int64_t e = 0; e < m; ++e) {
+            const int32_t i = prob->ind_i[e], j = prob->ind_j[e];
+            const double w = (weights ? weights[e] : 1.0) * dinv[i] * dinv[j];
+            const double* R = prob->rij + 9 * e;             // column-major R_ij
+            double* bi = &blocks[9 * (size_t)fill[i]]; adj[fill[i]++] = j;
+            double* bj = &blocks[9 * (size_t)fill[j]]; adj[fill[j]++] = i;
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { bi[r + 3 * c] = w * R[r + 3 * c]; bj[r + 3 * c] = w * R[c + 3 * r]; }   // (i,j) = R, (j,i) = R'
+        }
+    }
+    const int64_t rows = 3 * n;
+    // deterministic start: hashed pseudo-random entries in [-1,1)
+    std::vector<double> X0((size_t)rows * BW);
+    for (size_t t = 0; t < X0.size(); ++t) X0[t] = (double)(int64_t)(mix64(0xC0FFEEull + t) >> 11) / 4503599627370496.0 - 1.0;
+
+    Dev D;
+    int32_t *d_rowptr, *d_adj; double *d_blocks, *d_X, *d_Y, *d_part;
+    const int ggrid = 256;
+    if ((rc = D.alloc(&d_rowptr, n + 1)) || (rc = D.alloc(&d_adj, 2 * m)) || (rc = D.alloc(&d_blocks, 18 * m)) ||
+        (rc = D.alloc(&d_X, rows * BW)) || (rc = D.alloc(&d_Y, rows * BW)) || (rc = D.alloc(&d_part, (size_t)ggrid * 2 * BW * BW))) return rc;
+    DESC_HIP(hipMemcpy(d_rowptr, rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
+    if (m) {
+        DESC_HIP(hipMemcpy(d_adj, adj.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
+        DESC_HIP(hipMemcpy(d_blocks, blocks.data(), sizeof(double) * 18 * m, hipMemcpyHostToDevice));
+    }
+    DESC_HIP(hipMemcpy(d_Y, X0.data(), sizeof(double) * rows * BW, hipMemcpyHostToDevice));
+
+    std::vector<double> part((size_t)ggrid * 2 * BW * BW);
+    double G1[BW * BW], G2[BW * BW];
+    auto grams = [&](const double* A, const double* B) -> int {
+        hipLaunchKernelGGL(k_gram, dim3(ggrid), dim3(256), 0, 0, A, B, rows, d_part);
+        DESC_HIP(hipMemcpy(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost));
+        for (int t = 0; t < BW * BW; ++t) { double s1 = 0, s2 = 0; for (int b = 0; b < ggrid; ++b) { s1 += part[(size_t)b * 2 * BW * BW + t]; s2 += part[(size_t)b * 2 * BW * BW + BW * BW + t]; } G1[t] = s1; G2[t] = s2; }
+        return DESC_OK;
+    };
+    // C = Z * L^-T where K = Z' G Z = L L'  (columns of Y*C are orthonormal)
+    auto ortho_coeffs = [&](const double* G, const double* Z, SmallMat& C) -> bool {
+        double K[BW][BW], L[BW][BW] = {};
+        for (int a = 0; a < BW; ++a) for (int b = 0; b < BW; ++b) { double s = 0; for (int p = 0; p < BW; ++p) for (int q = 0; q < BW; ++q) s += Z[p * BW + a] * G[p * BW + q] * Z[q * BW + b]; K[a][b] = s; }
+        for (int a = 0; a < BW; ++a) {
+            for (int b = 0; b <= a; ++b) {
+                double s = 0.5 * (K[a][b] + K[b][a]);
+                for (int k = 0; k < b; ++k) s -= L[a][k] * L[b][k];
+                if (a == b) { if (!(s > 0)) return false; L[a][a] = std::sqrt(s); } else L[a][b] = s / L[b][b];
+            }
+        }
+        // Linv' : solve L' X = I  -> X = L^-T ; then C = Z X
+        double Li[BW][BW] = {};
+        for (int c = 0; c < BW; ++c)
+            for (int r = BW - 1; r >= 0; --r) { double s = (r == c); for (int k = r + 1; k < BW; ++k) s -= L[k][r] * Li[k][c]; Li[r][c] = s / L[r][r]; }
+        for (int a = 0; a < BW; ++a) for (int b = 0; b < BW; ++b) { double s = 0; for (int k = 0; k < BW; ++k) s += Z[a * BW + k] * Li[k][b]; C.c[a * BW + b] = s; }
+        return true;
+    };
+    double Ident[BW * BW];
+    for (int t = 0; t < BW * BW; ++t) Ident[t] = (t % (BW + 1) == 0);
+    // X = orth(X0)
+    SmallMat C;
+    if ((rc = grams(d_Y, d_Y))) return rc;
+    if (!ortho_coeffs(G2, Ident, C)) return fail(DESC_ERR_INVALID, "degenerate start basis");
+    hipLaunchKernelGGL(k_combine, dim3(512), dim3(256), 0, 0, d_Y, d_X, rows, C);
+
+    // Chebyshev-filtered subspace iteration (Zhou & Saad): each outer step damps the unwanted
+    // part of the spectrum [lo, cut] with a degree-CHEB_DEG Chebyshev polynomial of A, then
+    // Rayleigh-Ritz.  lo = -sigma is a lower bound of the spectrum; cut = smallest Ritz value of
+    // the block (the largest unwanted eigenvalue's estimate).  A plain power step (degree 1)
+    // needs ~1/gap products when the top of the spectrum is clustered (GCW weights span many
+    // orders of magnitude); the filter needs ~1/sqrt(gap).
+    constexpr int CHEB_DEG = 16;
+    double *d_P, *d_Q;
+    if ((rc = D.alloc(&d_P, rows * BW)) || (rc = D.alloc(&d_Q, rows * BW))) return rc;
+    double theta[BW] = {}, Z[BW * BW], res = 1e300;
+    int it = 0, products = 0;
+    bool converged = false;
+    const int sgrid = (int)std::min<int64_t>(4096, (n * 16 + 255) / 256);
+    auto spmm = [&](const double* x, const double* z, double* y, double alpha, double s1, double s2) {
+        hipLaunchKernelGGL(k_bsr_spmm, dim3(sgrid), dim3(256), 0, 0, d_rowptr, d_adj, d_blocks, x, z, y, (int)n, alpha, s1, s2);
+        ++products;
+    };
+    const double lo = -sigma;
+    double cut = 0.0;                                         // set after the first Rayleigh-Ritz
+    for (it = 1; it <= max_iters; ++it) {
+        // ---- Rayleigh-Ritz on the current orthonormal basis X
+        spmm(d_X, d_X, d_Y, 1.0, 0.0, 0.0);                  // Y = A X
+        if ((rc = grams(d_X, d_Y))) return rc;               // G1 = X'AX, G2 = Y'Y
+        jacobi_eig<BW>(G1, theta, Z);
+        {
+            ResArgs ra;
+            for (int k = 0; k < BW; ++k) for (int c = 0; c < 3; ++c) ra.z[k * 3 + c] = Z[k * BW + c];
+            for (int c = 0; c < 3; ++c) ra.theta[c] = theta[c];
+            hipLaunchKernelGGL(k_residual, dim3(ggrid), dim3(256), 0, 0, d_X, d_Y, rows, ra, d_part);
+            DESC_HIP(hipMemcpy(part.data(), d_part, sizeof(double) * 3 * ggrid, hipMemcpyDeviceToHost));
+            res = 0.0;
+            const double scale = std::max(std::fabs(theta[0]), sigma);
+            for (int c = 0; c < 3; ++c) { double r2 = 0; for (int bb = 0; bb < ggrid; ++bb) r2 += part[(size_t)3 * bb + c]; res = std::max(res, std::sqrt(r2) / std::max(scale, 1e-300)); }
+        }
+        if (res <= tol) { converged = true; break; }
+        // ---- filter: P <- p(A) X with p small on [lo, cut], large above
+        cut = theta[BW - 1];
+        const double top = theta[0];
+        if (!(cut > lo) || !(top > cut)) cut = lo + 0.5 * (top - lo);   // degenerate block: fall back to a mild filter
+        const double e = 0.5 * (cut - lo), c = 0.5 * (cut + lo);
+        double s_prev = e / (top - c);
+        const double s1c = s_prev;
+        // P = (A X - c X) * s_prev / e
+        spmm(d_X, d_X, d_P, s_prev / e, -c * s_prev / e, 0.0);
+        double* Xp = d_X; double* Pp = d_P; double* Qp = d_Q;  // X_{k-1}, X_k, scratch
+        for (int k = 2; k <= CHEB_DEG; ++k) {
+            const double s_new = 1.0 / (2.0 / s1c - s_prev);
+            // Q = (2 s_new / e) (A P - c P) - (s_prev s_new) X_{k-1}
+            spmm(Pp, Xp, Qp, 2.0 * s_new / e, -2.0 * s_new * c / e, -s_prev * s_new);
+            double* t3 = Xp; Xp = Pp; Pp = Qp; Qp = t3;
+            s_prev = s_new;
+        }
+        // ---- X <- orth(filtered block)
+        if ((rc = grams(Pp, Pp))) return rc;
+        SmallMat Co;
+        if (!ortho_coeffs(G2, Ident, Co)) return fail(DESC_ERR_INVALID, "subspace iteration broke down (rank-deficient block)");
+        double* Xn = (Pp == d_X) ? (Xp == d_P ? d_Q : d_P) : d_X;       // a buffer that is not Pp
+        hipLaunchKernelGGL(k_combine, dim3(512), dim3(256), 0, 0, Pp, Xn, rows, Co);
+        if (Xn != d_X) DESC_HIP(hipMemcpyAsync(d_X, Xn, sizeof(double) * rows * BW, hipMemcpyDeviceToDevice, 0));
+    }
+    // Ritz vectors of the converged subspace: V = X Z (X still holds the basis G1 was formed with)
+    // Z belongs to the basis in d_X in both exits (the loop leaves right after a Rayleigh-Ritz,
+    // or after max_iters with the last Ritz rotation still unapplied)
+    if (!converged && it > max_iters) {                       // last pass replaced X after its RR: redo RR once
+        spmm(d_X, d_X, d_Y, 1.0, 0.0, 0.0);
+        if ((rc = grams(d_X, d_Y))) return rc;
+        jacobi_eig<BW>(G1, theta, Z);
+    }
+    SmallMat CZ; std::memcpy(CZ.c, Z, sizeof Z);
+    hipLaunchKernelGGL(k_combine, dim3(512), dim3(256), 0, 0, d_X, d_Y, rows, CZ);
+    DESC_HIP(hipGetLastError());
+    std::vector<double> Vh((size_t)rows * BW);
+    DESC_HIP(hipMemcpy(Vh.data(), d_Y, sizeof(double) * rows * BW, hipMemcpyDeviceToHost));
+
+    // back to the eigenvectors of D^-1 A, unit 2-norm columns (what eigs returns)   (GCW.m:21,27)
+    std::vector<double> V((size_t)rows * 3);
+    double nrm[3] = {0, 0, 0};
+    for (int64_t v = 0; v < n; ++v) for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+        const double x = Vh[((size_t)3 * v + r) * BW + c] * (normalize_rows ? dinv[v] : 1.0);
+        V[((size_t)3 * v + r) * 3 + c] = x; nrm[c] += x * x;
+    }
+    for (size_t t = 0; t < V.size(); ++t) V[t] /= std::sqrt(nrm[t % 3]);
+    // V(:,1) = V(:,1)*sign(det(V(1:3,:)))   (Spectral.m:39 / GCW.m:28)
+    {
+        const double* A = V.data();
+        const double det = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+        const double sg = det > 0 ? 1.0 : (det < 0 ? -1.0 : 0.0);
+        for (int64_t r = 0; r < rows; ++r) V[(size_t)r * 3] *= sg;
+    }
+    for (int64_t v = 0; v < n; ++v) {
+        double R[9];
+        project_so3(&V[(size_t)9 * v], R);                   // rows 3v..3v+2 of V = the node's 3x3 block, row-major
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R_out[9 * v + r + 3 * c] = R[r * 3 + c];   // MATLAB column-major 3x3xn
+    }
+    if (info) {
+        info->iters = std::min(it, max_iters);
+        info->converged = converged ? 1 : 0;
+        info->residual = res;
+        for (int c = 0; c < 3; ++c) info->eigenvalues[c] = theta[c];
+        info->products = products;
+        info->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return DESC_OK;
+}

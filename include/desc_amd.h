@@ -189,6 +189,25 @@ int desc_pgd_shard_objective(desc_pgd* h, int32_t phase);
  * the handle's stream. */
 int desc_pgd_stopped(desc_pgd* h, int32_t* stopped);
 
+/* ------------------------------------------------- Spectral / GCW (next row f-1) -- */
+/* Top-3 eigenvectors ('la') of the 3n x 3n block connection matrix + per-node projection onto
+ * SO(3).  weights == NULL, normalize_rows == 0: Algorithms/Spectral.m:18-46.
+ * weights[l] = 1/(S_vec[l]^1.5 + 1e-8), normalize_rows == 1: Utils/GCW.m:9-36 (the matrix
+ * D^-1*W .* Rij_blk; iterated in its symmetric similar form, eigenvectors mapped back and
+ * re-normalised).  R_out: n*9 doubles, 3x3xn in MATLAB column-major order.  Rotations are
+ * defined up to one global right rotation (compare after Utils/Rotation_Alignment.m). */
+typedef struct desc_spectral_info {
+    int32_t iters;            /* outer (filter + Rayleigh-Ritz) steps              */
+    int32_t products;         /* block matrix products (3n x 6 each)               */
+    int32_t converged;        /* residual <= tol reached                           */
+    int32_t reserved;
+    double  residual;         /* max relative residual of the three Ritz pairs     */
+    double  eigenvalues[3];   /* the three largest eigenvalues                     */
+    double  ms_total;
+} desc_spectral_info;
+int desc_spectral_run(const desc_problem* prob, const double* weights, int32_t normalize_rows, double tol,
+                      int32_t max_iters, int32_t device, double* R_out, desc_spectral_info* info);
+
 /* One-shot: what the MEX shim calls.  Builds the structure (p->build_where),
  * uploads, runs, downloads, frees. */
 int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* r);
