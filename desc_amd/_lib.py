@@ -26,7 +26,7 @@ EXPORTS = [
     "desc_pgd_iterate_timed", "desc_pgd_sync", "desc_pgd_download", "desc_pgd_get_s0",
     "desc_pgd_sizes", "desc_pgd_kernel_name", "desc_pgd_solve", "desc_selftest_group_sum",
     "desc_pgd_create_shard", "desc_pgd_shard_info", "desc_pgd_shard_bind", "desc_pgd_shard_colsum", "desc_pgd_shard_sweep",
-    "desc_pgd_shard_finish", "desc_pgd_shard_objective", "desc_pgd_stopped", "desc_spectral_run",
+    "desc_pgd_shard_finish", "desc_pgd_shard_objective", "desc_pgd_stopped", "desc_spectral_run", "desc_cemp_run",
 ]
 
 I32P = C.POINTER(C.c_int32)
@@ -338,6 +338,18 @@ def spectral_run(prob: ProblemArrays, weights=None, normalize_rows=False, tol=1e
                                    ptr(R, F64P), C.byref(info)))
     return R[:9 * n].reshape((3, 3, n), order="F"), dict(iters=info.iters, products=info.products, converged=bool(info.converged), residual=info.residual,
                                                         eigenvalues=list(info.eigenvalues), ms_total=info.ms_total)
+
+
+def cemp_run(prob: ProblemArrays, beta, max_iter, nsample, seed=0, device=0):
+    b = np.ascontiguousarray(beta, dtype=np.float64).reshape(-1)
+    S = np.zeros(max(prob.c.m, 1))
+    ms = C.c_double()
+    L = load()
+    L.desc_cemp_run.argtypes = [C.POINTER(Problem), F64P, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, F64P,
+                                C.POINTER(C.c_double)]
+    check(L.desc_cemp_run(C.byref(prob.c), ptr(b, F64P), b.shape[0], int(max_iter), int(nsample), int(seed), device, ptr(S, F64P),
+                          C.byref(ms)))
+    return S[:prob.c.m], ms.value
 
 
 def device_count():

@@ -211,6 +211,24 @@ def GCW(Ind, AdjMat, RijMat, S_vec, device=0, return_info=False):
     return (R, info) if return_info else R
 
 
+def CEMP(Ind, RijMat, CEMP_parameters, return_info=False):
+    """SVec = CEMP(Ind, RijMat, CEMP_parameters) -- Algorithms/CEMP.m:24.  Fields read:
+    ``max_iter``, ``reweighting``, ``nsample`` (``gcw_beta`` is ignored, as in the reference);
+    optional ``seed`` / ``device`` (not in the reference)."""
+    n, ii, jj, rij, perm = marshal_edges(Ind, RijMat)
+    prob = _lib.ProblemArrays(n, ii, jj, rij)
+    beta = np.atleast_1d(np.asarray(_get(CEMP_parameters, "reweighting"), dtype=np.float64))
+    if _get(CEMP_parameters, "verbose", False):
+        for line in ("sampling 3-cycles", "Sampling Finished!", "Initializing", "Initialization completed!",
+                     "Reweighting Procedure Started ..."):           # CEMP.m:45,67,68,104,105
+            print(line)
+    S, ms = _lib.cemp_run(prob, beta, int(_get(CEMP_parameters, "max_iter")), int(_get(CEMP_parameters, "nsample")),
+                          int(_get(CEMP_parameters, "seed", 0)), int(_get(CEMP_parameters, "device", 0)))
+    if perm is not None:
+        out = np.empty_like(S); out[perm] = S; S = out
+    return (S, dict(ms_total=ms)) if return_info else S
+
+
 def Rotation_Alignment(R_est, R_gt):
     """[R_out, R_align, mean_error, median_error] = Rotation_Alignment(R_est, R_gt)
     -- Utils/Rotation_Alignment.m:13-38 (evaluation helper: host NumPy, O(n))."""

@@ -46,4 +46,6 @@ int build_structure_host(const desc_problem* prob, int32_t n_sample_min, uint64_
 int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint64_t seed,
                            int32_t device, desc_structure* out);
 int validate_problem(const desc_problem* prob, bool need_rij);
+int build_cemp_samples_host(const desc_problem* prob, int32_t nsample, uint64_t seed, std::vector<int32_t>& pos_edge,
+                            std::vector<int32_t>& kk, std::vector<int32_t>& e_jk, std::vector<int32_t>& e_ki);
 }  // namespace desc

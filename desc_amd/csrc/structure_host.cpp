@@ -131,6 +131,32 @@ inline void common_of(const Graph& g, int32_t i, int32_t j, std::vector<Tri>& ou
 
 }  // namespace
 
+// CEMP's cycle sample (Algorithms/CEMP.m:44-65): nsample third vertices per edge-with-cycles,
+// drawn WITH replacement; datasample's RNG is replaced by  CoInd[sample_key(seed, edge, t) mod codeg].
+int build_cemp_samples_host(const desc_problem* prob, int32_t nsample, uint64_t seed, std::vector<int32_t>& pos_edge,
+                            std::vector<int32_t>& kk, std::vector<int32_t>& e_jk, std::vector<int32_t>& e_ki) {
+    Graph g; g.n = prob->n; g.m = prob->m; g.ii = prob->ind_i; g.jj = prob->ind_j;
+    build_graph(g);
+    std::vector<int32_t> cd((size_t)g.m);
+    parallel_for(g.m, [&](int64_t a, int64_t b, int) { for (int64_t e = a; e < b; ++e) cd[e] = codeg_of(g, g.ii[e], g.jj[e]); });
+    pos_edge.clear();
+    for (int64_t e = 0; e < g.m; ++e) if (cd[e] > 0) pos_edge.push_back((int32_t)e);
+    const int64_t mp = (int64_t)pos_edge.size();
+    kk.assign((size_t)mp * nsample, 0); e_jk.assign((size_t)mp * nsample, 0); e_ki.assign((size_t)mp * nsample, 0);
+    parallel_for(mp, [&](int64_t a, int64_t b, int) {
+        std::vector<Tri> tri;
+        for (int64_t l = a; l < b; ++l) {
+            const int32_t e = pos_edge[l];
+            common_of(g, g.ii[e], g.jj[e], tri);
+            for (int32_t t = 0; t < nsample; ++t) {
+                const Tri& q = tri[sample_key(seed, (uint64_t)e, (uint64_t)t) % tri.size()];
+                kk[(size_t)l * nsample + t] = q.k; e_jk[(size_t)l * nsample + t] = q.ejk; e_ki[(size_t)l * nsample + t] = q.eki;
+            }
+        }
+    });
+    return DESC_OK;
+}
+
 int validate_problem(const desc_problem* prob, bool need_rij) {
     if (!prob) return fail(DESC_ERR_INVALID, "problem is NULL");
     if (prob->n < 0 || prob->m < 0) return fail(DESC_ERR_INVALID, "negative n or m");

@@ -208,6 +208,14 @@ typedef struct desc_spectral_info {
 int desc_spectral_run(const desc_problem* prob, const double* weights, int32_t normalize_rows, double tol,
                       int32_t max_iters, int32_t device, double* R_out, desc_spectral_info* info);
 
+/* ------------------------------------------------------------ CEMP (next row f-2) -- */
+/* SVec = CEMP(Ind, RijMat, CEMP_parameters) -- Algorithms/CEMP.m:24-132.  beta[0..n_beta-1] =
+ * CEMP_parameters.reweighting (missing entries repeat the last one, CEMP.m:30-34), max_iter =
+ * .max_iter, nsample = .nsample (cycles per edge, sampled with replacement, CEMP.m:64; MATLAB's
+ * RNG is replaced by CoInd[desc_sample_key(seed, edge, t) mod codeg]).  s_vec: m doubles out. */
+int desc_cemp_run(const desc_problem* prob, const double* beta, int32_t n_beta, int32_t max_iter, int32_t nsample,
+                  uint64_t seed, int32_t device, double* s_vec, double* ms_total);
+
 /* One-shot: what the MEX shim calls.  Builds the structure (p->build_where),
  * uploads, runs, downloads, frees. */
 int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* r);
