@@ -6,8 +6,8 @@ include/desc_amd.h).  Importing the package does not need a GPU; creating a solv
 does, and there is no CPU fallback.
 """
 from .stepsize import ConstantStepSize, HybridGradient, PiecewiseStepSize  # noqa: F401
-from .algorithms import CEMP, DESC_PGD, GCW, Rotation_Alignment, Spectral  # noqa: F401
+from .algorithms import CEMP, DESC, DESC_PGD, GCW, Rotation_Alignment, Spectral  # noqa: F401
 from .models import Nonuniform_Topology, Uniform_Topology  # noqa: F401
 
-__all__ = ["DESC_PGD", "CEMP", "Spectral", "GCW", "Rotation_Alignment", "ConstantStepSize", "PiecewiseStepSize", "HybridGradient",
+__all__ = ["DESC", "DESC_PGD", "CEMP", "Spectral", "GCW", "Rotation_Alignment", "ConstantStepSize", "PiecewiseStepSize", "HybridGradient",
            "Uniform_Topology", "Nonuniform_Topology"]

@@ -26,7 +26,7 @@ EXPORTS = [
     "desc_pgd_iterate_timed", "desc_pgd_sync", "desc_pgd_download", "desc_pgd_get_s0",
     "desc_pgd_sizes", "desc_pgd_kernel_name", "desc_pgd_solve", "desc_selftest_group_sum",
     "desc_pgd_create_shard", "desc_pgd_shard_info", "desc_pgd_shard_bind", "desc_pgd_shard_colsum", "desc_pgd_shard_sweep",
-    "desc_pgd_shard_finish", "desc_pgd_shard_objective", "desc_pgd_stopped", "desc_spectral_run", "desc_cemp_run",
+    "desc_pgd_shard_finish", "desc_pgd_shard_objective", "desc_pgd_stopped", "desc_spectral_run", "desc_cemp_run", "desc_refine_run",
 ]
 
 I32P = C.POINTER(C.c_int32)
@@ -70,6 +70,11 @@ class ShardInfo(C.Structure):
 class SpectralInfo(C.Structure):
     _fields_ = [("iters", C.c_int32), ("products", C.c_int32), ("converged", C.c_int32), ("reserved", C.c_int32), ("residual", C.c_double),
                 ("eigenvalues", C.c_double * 3), ("ms_total", C.c_double)]
+
+
+class RefineInfo(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("cg_iters", C.c_int32), ("verbose", C.c_int32), ("reserved", C.c_int32),
+                ("score", C.c_double), ("ms_total", C.c_double)]
 
 
 class DescError(RuntimeError):
@@ -350,6 +355,19 @@ def cemp_run(prob: ProblemArrays, beta, max_iter, nsample, seed=0, device=0):
     check(L.desc_cemp_run(C.byref(prob.c), ptr(b, F64P), b.shape[0], int(max_iter), int(nsample), int(seed), device, ptr(S, F64P),
                           C.byref(ms)))
     return S[:prob.c.m], ms.value
+
+
+def refine_run(prob: ProblemArrays, s_vec, R_init, stop_threshold=1e-3, max_iters=100, device=0, verbose=False):
+    """desc_refine_run -> (R (3,3,n), info)."""
+    n = prob.c.n
+    S = np.ascontiguousarray(s_vec, dtype=np.float64)
+    Ri = np.ascontiguousarray(np.asarray(R_init, dtype=np.float64).reshape(-1, order="F"))
+    Ro = np.zeros(9 * max(n, 1))
+    info = RefineInfo(); info.verbose = 1 if verbose else 0
+    L = load()
+    L.desc_refine_run.argtypes = [C.POINTER(Problem), F64P, F64P, C.c_double, C.c_int32, C.c_int32, F64P, C.POINTER(RefineInfo)]
+    check(L.desc_refine_run(C.byref(prob.c), ptr(S, F64P), ptr(Ri, F64P), stop_threshold, max_iters, device, ptr(Ro, F64P), C.byref(info)))
+    return Ro[:9 * n].reshape((3, 3, n), order="F"), dict(iters=info.iters, cg_iters=info.cg_iters, score=info.score, ms_total=info.ms_total)
 
 
 def device_count():

@@ -229,6 +229,27 @@ def CEMP(Ind, RijMat, CEMP_parameters, return_info=False):
     return (S, dict(ms_total=ms)) if return_info else S
 
 
+def DESC(Ind, RijMat, params, return_info=False):
+    """[R_est, R_init, S_vec] = DESC(Ind, RijMat, params) -- Algorithms/DESC.m:14 (the call of
+    Demo/compare_algorithms.m:72): DESC_PGD (:16-261) -> GCW initialisation (:263) -> reweighted
+    Lie-algebraic refinement (:265-313).  All three stages run on the GPU."""
+    S_vec, info = DESC_PGD(Ind, RijMat, params, return_info=True)
+    n, ii, jj, rij, perm = marshal_edges(Ind, RijMat)
+    S_sorted = S_vec if perm is None else S_vec[perm]
+    prob = _lib.ProblemArrays(n, ii, jj, rij)
+    device = int(_get(params, "device", 0))
+    R_init, ginfo = _lib.spectral_run(prob, 1.0 / (S_sorted ** 1.5 + 1e-8), True, device=device)     # GCW.m:20
+    verbose = bool(_get(params, "verbose", True))
+    if verbose:
+        print("Rotation Initialized!"); print("Start DESC refinement ...")                    # DESC.m:283-284
+    R_est, rinfo = _lib.refine_run(prob, S_sorted, R_init, device=device, verbose=verbose)
+    if verbose:
+        print("DONE!")                                                                        # DESC.m:313
+    if return_info:
+        return R_est, R_init, S_vec, dict(pgd=info, gcw=ginfo, refine=rinfo)
+    return R_est, R_init, S_vec
+
+
 def Rotation_Alignment(R_est, R_gt):
     """[R_out, R_align, mean_error, median_error] = Rotation_Alignment(R_est, R_gt)
     -- Utils/Rotation_Alignment.m:13-38 (evaluation helper: host NumPy, O(n))."""

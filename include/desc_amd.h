@@ -216,6 +216,22 @@ int desc_spectral_run(const desc_problem* prob, const double* weights, int32_t n
 int desc_cemp_run(const desc_problem* prob, const double* beta, int32_t n_beta, int32_t max_iter, int32_t nsample,
                   uint64_t seed, int32_t device, double* s_vec, double* ms_total);
 
+/* ----------------------------------------- DESC refinement tail (next row f-3) -- */
+/* Reweighted Lie-algebraic averaging, Algorithms/DESC.m:265-313 with Utils/Weighted_LAA.m,
+ * Build_Amatrix.m, R2Q.m, q2R.m.  s_vec: m (the PGD output), R_init: n*9 (3x3xn column-major, the
+ * GCW output, DESC.m:263), R_out: n*9.  stop_threshold <= 0 -> 1e-3, max_iters <= 0 -> 100
+ * (DESC.m:272).  MATLAB's sparse-QR least squares is replaced by f64 PCG on the normal equations. */
+typedef struct desc_refine_info {
+    int32_t iters;            /* refinement steps executed                                     */
+    int32_t cg_iters;         /* conjugate-gradient steps in total                             */
+    int32_t verbose;          /* in: print the reference's "Iter %d: ||dR||= %f" lines          */
+    int32_t reserved;
+    double  score;            /* last mean rotation update (Weighted_LAA.m:40)                 */
+    double  ms_total;
+} desc_refine_info;
+int desc_refine_run(const desc_problem* prob, const double* s_vec, const double* R_init, double stop_threshold,
+                    int32_t max_iters, int32_t device, double* R_out, desc_refine_info* info);
+
 /* One-shot: what the MEX shim calls.  Builds the structure (p->build_where),
  * uploads, runs, downloads, frees. */
 int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* r);
