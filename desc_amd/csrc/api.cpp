@@ -61,7 +61,7 @@ int desc_structure_build(const desc_problem* prob, int32_t n_sample_min, uint64_
     } catch (const std::bad_alloc&) {
         rc = fail(DESC_ERR_INVALID, "out of host memory while building the structure");
     }
-    if (rc) { delete s; return rc; }
+    if (rc) { structure_free_device(s); delete s; return rc; }
     *out = s;
     return DESC_OK;
 }
@@ -104,8 +104,11 @@ int desc_structure_import(int64_t n, int64_t m, int64_t m_pos, int32_t n_sample,
     return DESC_OK;
 }
 
-int desc_structure_get(const desc_structure* s, desc_structure_view* v) {
-    if (!s || !v) return fail(DESC_ERR_INVALID, "NULL argument");
+int desc_structure_get(const desc_structure* cs, desc_structure_view* v) {
+    if (!cs || !v) return fail(DESC_ERR_INVALID, "NULL argument");
+    desc_structure* s = const_cast<desc_structure*>(cs);      // lazily materialises the host copy of a device-built structure
+    int rc = structure_ensure_host(s);
+    if (rc) return rc;
     v->n = s->n; v->m = s->m; v->m_pos = s->m_pos; v->m_cycle = s->m_cycle;
     v->n_sample = s->n_sample; v->max_cnt = s->max_cnt;
     v->codeg = s->codeg.data(); v->pos_edge = s->pos_edge.data(); v->cum_ind = s->cum_ind.data();
@@ -114,7 +117,7 @@ int desc_structure_get(const desc_structure* s, desc_structure_view* v) {
     return DESC_OK;
 }
 
-void desc_structure_free(desc_structure* s) { delete s; }
+void desc_structure_free(desc_structure* s) { if (s) { structure_free_device(s); delete s; } }
 
 int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* r) {
     if (!p || !r) return fail(DESC_ERR_INVALID, "NULL argument");

@@ -34,8 +34,13 @@ struct desc_structure {
     int32_t n_sample = 0, max_cnt = 0;
     std::vector<int32_t> codeg, pos_edge;
     std::vector<int64_t> cum_ind;
-    std::vector<int32_t> k, e_jk, e_ki, ikj, jki;
+    std::vector<int32_t> k, e_jk, e_ki, ikj, jki;   // per-cycle arrays on the host (valid iff host_cycles)
     double ms_build = 0.0;
+    // A structure built on the device keeps its per-cycle arrays in HBM (natural order) and copies
+    // them to the host only when somebody asks (desc_structure_get, the gather layout).
+    bool host_cycles = true;
+    int dev = -1;
+    int32_t *d_k = nullptr, *d_ejk = nullptr, *d_eki = nullptr, *d_ikj = nullptr, *d_jki = nullptr;
 };
 
 namespace desc {
@@ -46,6 +51,9 @@ int build_structure_host(const desc_problem* prob, int32_t n_sample_min, uint64_
 int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint64_t seed,
                            int32_t device, desc_structure* out);
 int validate_problem(const desc_problem* prob, bool need_rij);
+// device-resident structures (structure_device.hip)
+int structure_ensure_host(desc_structure* s);      // copy the per-cycle arrays to the host if they live on the device
+void structure_free_device(desc_structure* s);
 int build_cemp_samples_host(const desc_problem* prob, int32_t nsample, uint64_t seed, std::vector<int32_t>& pos_edge,
                             std::vector<int32_t>& kk, std::vector<int32_t>& e_jk, std::vector<int32_t>& e_ki);
 }  // namespace desc

@@ -370,7 +370,13 @@ struct EdgeInfo {
 #define STAMP(slot) do {} while (0)
 #endif
 
-constexpr int CHUNK_LDS = 960;    // entries of the LDS image of a chunk
+#ifndef DESC_CHUNK_LDS
+#define DESC_CHUNK_LDS 960
+#endif
+#ifndef DESC_SWEEP_THREADS
+#define DESC_SWEEP_THREADS 512
+#endif
+constexpr int CHUNK_LDS = DESC_CHUNK_LDS;    // entries of the LDS image of a chunk
 constexpr int CHUNK_CAP = CHUNK_LDS - 4;   // cycles per chunk: the image starts up to 3 entries before the chunk (16-byte alignment)
 constexpr int CHUNK_SEG = 64;     // segments per chunk
 
@@ -410,7 +416,7 @@ struct alignas(16) ChunkBuf {
     double w[CHUNK_LDS], d[CHUNK_LDS], ss[CHUNK_LDS];
     uint32_t pk[CHUNK_LDS];
 };
-constexpr int SWEEP_THREADS = 512;
+constexpr int SWEEP_THREADS = DESC_SWEEP_THREADS;
 
 struct StreamRegs { uint4 pk; double2 w, d; };   // one 16-byte vector of each streamed array
 
@@ -434,7 +440,7 @@ struct StreamRegs { uint4 pk; double2 w, d; };   // one 16-byte vector of each s
 //     6  [gathers landed] S(jk)+S(ki) and T1/T2/S_old of chunk i+1 -> LDS; publish the
 //        segment records of chunk i+2
 template <int E, int STEP>
-__global__ __launch_bounds__(SWEEP_THREADS, 4) void k_sweep_node(NodeSweepArgs a) {
+__global__ __launch_bounds__(SWEEP_THREADS, 4) void k_sweep_node(NodeSweepArgs a) {   // 4 waves per SIMD: <= 128 VGPRs
     __shared__ ChunkBuf X[2];
     __shared__ SegRec R[2];
     __shared__ uint8_t c_seg[CHUNK_LDS];
@@ -539,6 +545,10 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void k_sweep_node(NodeSweepArgs a
         ChunkBuf& xc = X[k & 1];
         SegRec& rn = R[(k + 1) & 1];
         ChunkBuf& xn = X[(k + 1) & 1];
+        if (a.ablate & 256) {          // diagnostics: pure streaming ceiling of this launch geometry
+            obj_acc += s1.w.x + s1.d.y + (double)s1.pk.x;
+            return load_stream(ch3);
+        }
         STAMP(7);
         __syncthreads();                                        // chunk ch staged, records of ch+1 visible
         STAMP(0);
@@ -772,6 +782,64 @@ __global__ __launch_bounds__(256) void k_layout_node(const int32_t* cum, const i
             S0[(int64_t)base + q] = abs_acos_ext((tr - 1.0) / 2.0) / M_PI;
         }
     }
+}
+
+// The same, reading a device-built structure in place (natural order: k, ikj, jki) and doing the
+// within-segment re-ordering [both mirrors | (ik;j) only | (jk;i) only | none] in the wave
+// (stable: ascending k inside a class, exactly like the host path).  Segments have <= 64 cycles.
+__global__ __launch_bounds__(256) void k_layout_node_dev(const int32_t* cum, const int32_t* src_start, const int32_t* pos_edge,
+                                                         const int32_t* ind_i, const int32_t* ind_j, const int32_t* nat_k,
+                                                         const int32_t* nat_ikj, const int32_t* nat_jki, const int32_t* rowptr,
+                                                         const int32_t* adj, const int32_t* adj_eid, const double* rij, uint32_t* pk,
+                                                         double* S0, uint8_t* seg_perm, uint32_t* seg_counts, int m_pos) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t l = wid; l < m_pos; l += nw) {
+        const int base = cum[l], cnt = cum[l + 1] - base, src = src_start[l];
+        const int e = pos_edge[l], i = ind_i[e], j = ind_j[e];
+        const int ri = rowptr[i], di = rowptr[i + 1] - ri, rj = rowptr[j], dj = rowptr[j + 1] - rj;
+        double A[9];
+        for (int t = 0; t < 9; ++t) A[t] = rij[9 * (int64_t)e + t];
+        const bool on = lane < cnt;
+        int k = 0; bool fi = false, fj = false;
+        if (on) { k = nat_k[(int64_t)src + lane]; fi = nat_ikj[(int64_t)src + lane] >= 0; fj = nat_jki[(int64_t)src + lane] >= 0; }
+        const int cls = !on ? 4 : fi ? (fj ? 0 : 1) : (fj ? 2 : 3);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
+        const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2);
+        int o = 0;
+        if (cls == 0) o = __popcll(m0 & lt);
+        else if (cls == 1) o = n0 + __popcll(m1 & lt);
+        else if (cls == 2) o = n0 + n1 + __popcll(m2 & lt);
+        else if (cls == 3) o = n0 + n1 + n2 + __popcll(m3 & lt);
+        if (lane == 0) seg_counts[l] = (uint32_t)n0 | (uint32_t)(n0 + n1) << 7 | (uint32_t)n2 << 14;
+        if (on) {
+            int lo = 0, hi = di;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (adj[ri + mid] < k) lo = mid + 1; else hi = mid; }
+            const int xi = min(lo, max(di - 1, 0));
+            lo = 0; hi = dj;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (adj[rj + mid] < k) lo = mid + 1; else hi = mid; }
+            const int xj = min(lo, max(dj - 1, 0));
+            pk[(int64_t)base + o] = (uint32_t)xi | (fi ? 1u : 0u) << 15 | (uint32_t)xj << 16 | (fj ? 1u : 0u) << 31;
+            seg_perm[(int64_t)base + o] = (uint8_t)lane;
+            const double tr = cycle_trace(A, rij + 9 * (int64_t)adj_eid[rj + xj], !(j < k), rij + 9 * (int64_t)adj_eid[ri + xi], !(k < i));
+            S0[(int64_t)base + o] = abs_acos_ext((tr - 1.0) / 2.0) / M_PI;
+        }
+    }
+}
+// CSR-aligned segment records for the column-sum pass: 16 lanes per node row
+__global__ __launch_bounds__(256) void k_adj_seg(const int32_t* rowptr, const int32_t* adj, const int32_t* adj_eid, const int32_t* devpos,
+                                                 const int32_t* cum, const uint32_t* seg_counts, int seg_lo, int seg_hi, int2* adj_seg, int n) {
+    const int l16 = threadIdx.x & 15;
+    const int row0 = (blockIdx.x * 256 + threadIdx.x) >> 4, nrows = (gridDim.x * 256) >> 4;
+    for (int v = row0; v < n; v += nrows)
+        for (int t = rowptr[v] + l16; t < rowptr[v + 1]; t += 16) {
+            const int q = devpos[adj_eid[t]];
+            int2 rec{0, 0};
+            if (q >= seg_lo && q < seg_hi) { rec.x = cum[q]; rec.y = (int)(seg_counts[q] | (v < adj[t] ? 0x80000000u : 0u)); }
+            adj_seg[t] = rec;
+        }
 }
 
 __global__ __launch_bounds__(256) void k_init_node(const int32_t* cum, const EdgeInfo* einfo, const double* S0,
@@ -1118,6 +1186,7 @@ int choose_grid(desc_pgd* h) {
 int setup_gather(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     const int64_t m = h->m, mp = h->m_pos, mc = h->m_cycle;
     int rc;
+    if ((rc = structure_ensure_host(const_cast<desc_structure*>(s)))) return rc;
     if ((rc = dalloc(h, &h->d_pos_edge, mp))) return rc;
     if ((rc = dalloc(h, &h->d_ejk, mc))) return rc;
     if ((rc = dalloc(h, &h->d_eki, mc))) return rc;
@@ -1277,13 +1346,15 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
             einfo[q] = EdgeInfo{rowptr[i], rowptr[j], eslot[e], rowptr[j] + idx_in_row(j, i)};
         }
     });
+    const bool dev_cycles = !s->host_cycles && s->dev == h->device && s->d_k != nullptr;   // structure built on this device
+    std::vector<uint32_t> kf; std::vector<uint8_t> seg_perm; std::vector<uint32_t> seg_counts; std::vector<int2> adj_seg;
+    if (!dev_cycles) {
+        if ((rc = structure_ensure_host(const_cast<desc_structure*>(s)))) return rc;
     // k with the two mirror-present bits of the owned cycles, device order.  Inside a segment
     // the cycles are stored [both mirrors sampled | (ik;j) only | (jk;i) only | none] (ascending k
     // within a class): the column-sum pass then reads only the cycles that contribute
     // (a fraction ~n_sample/codeg of them), the per-segment arithmetic is order independent.
-    std::vector<uint32_t> kf((size_t)mcl);
-    std::vector<uint8_t> seg_perm((size_t)mcl);
-    std::vector<uint32_t> seg_counts((size_t)mp, 0);          // n_both | n_i << 7 | n_jonly << 14 (owned segments)
+    kf.assign((size_t)mcl, 0u); seg_perm.assign((size_t)mcl, 0); seg_counts.assign((size_t)mp, 0u);   // counts: n_both | n_i << 7 | n_jonly << 14
     host_parallel(nsl, [&](int64_t a, int64_t b) {
         for (int64_t q = h->seg_lo + a; q < h->seg_lo + b; ++q) {
             const int64_t src = src_start[q], dst = cum_loc[q], cnt = cum2[q + 1] - cum2[q];
@@ -1299,7 +1370,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
             seg_counts[q] = (uint32_t)n_cls[0] | (uint32_t)(n_cls[0] + n_cls[1]) << 7 | (uint32_t)n_cls[2] << 14;
         }
     });
-    std::vector<int2> adj_seg((size_t)2 * m);
+    adj_seg.resize((size_t)2 * m);
     host_parallel(n, [&](int64_t a, int64_t b) {
         for (int64_t v = a; v < b; ++v)
             for (int32_t t = rowptr[v]; t < rowptr[v + 1]; ++t) {
@@ -1312,6 +1383,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
                 adj_seg[t] = rec;
             }
     });
+    }
     // chunk tables: all chunks, local cycle numbering
     std::vector<int32_t> chunk_seg(P.chunk_seg), chunk_c0((size_t)nch_all + 2);
     for (int64_t t = 0; t <= nch_all; ++t) chunk_c0[t] = cum_loc[chunk_seg[t]];
@@ -1343,13 +1415,13 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     if ((rc = dalloc(h, &d_adj, 2 * m))) return rc;
     if ((rc = dalloc(h, &d_adj_eid, 2 * m))) return rc;
     if ((rc = dalloc(h, &d_pos_edge2, mp))) return rc;
-    if ((rc = dalloc(h, &d_kf, mcl))) return rc;
+    if (!dev_cycles && (rc = dalloc(h, &d_kf, mcl))) return rc;
     if ((rc = dalloc(h, &d_rij, 9 * (size_t)m))) return rc;
     std::vector<int32_t> rank_seg32(h->rank_seg.begin(), h->rank_seg.end());
     if ((rc = upload(h, h->d_cum, cum_loc.data(), (size_t)mp + 1))) return rc;
     if ((rc = upload(h, h->d_einfo, einfo.data(), (size_t)mp))) return rc;
     if ((rc = upload(h, h->d_rowptr, rowptr.data(), (size_t)n + 1))) return rc;
-    if ((rc = upload(h, h->d_adj_seg, adj_seg.data(), (size_t)2 * m))) return rc;
+    if (!dev_cycles && (rc = upload(h, h->d_adj_seg, adj_seg.data(), (size_t)2 * m))) return rc;
     if ((rc = upload(h, h->d_src_start, src_start.data(), (size_t)mp))) return rc;
     if ((rc = upload(h, h->d_eslot, eslot.data(), (size_t)m))) return rc;
     if ((rc = upload(h, h->d_chunk_seg, chunk_seg.data(), chunk_seg.size()))) return rc;
@@ -1360,8 +1432,8 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     if ((rc = upload(h, d_adj, adj.data(), (size_t)2 * m))) return rc;
     if ((rc = upload(h, d_adj_eid, adj_eid.data(), (size_t)2 * m))) return rc;
     if ((rc = upload(h, d_pos_edge2, pos_edge2.data(), (size_t)mp))) return rc;
-    if ((rc = upload(h, d_kf, kf.data(), (size_t)mcl))) return rc;
-    if ((rc = upload(h, h->d_seg_perm, seg_perm.data(), (size_t)mcl))) return rc;
+    if (!dev_cycles && (rc = upload(h, d_kf, kf.data(), (size_t)mcl))) return rc;
+    if (!dev_cycles && (rc = upload(h, h->d_seg_perm, seg_perm.data(), (size_t)mcl))) return rc;
     if ((rc = upload(h, d_rij, prob->rij, 9 * (size_t)m))) return rc;
     DESC_HIP(hipStreamSynchronize(h->stream));
     h->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1396,10 +1468,27 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     hipEvent_t e0, e1;
     DESC_HIP(hipEventCreate(&e0)); DESC_HIP(hipEventCreate(&e1));
     (void)hipEventRecord(e0, h->stream);
-    if (nsl > 0) {
+    if (nsl > 0 && !dev_cycles) {
         int g = (int)std::min<int64_t>(4096, (nsl + 3) / 4);
         hipLaunchKernelGGL(k_layout_node, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, d_pos_edge2 + h->seg_lo, d_ii, d_jj,
                            d_kf, h->d_rowptr, d_adj, d_adj_eid, d_rij, h->d_pk, h->d_S0, (int)nsl);
+    } else if (dev_cycles) {
+        // the structure's per-cycle arrays never left the device: lay them out in place
+        int32_t* d_devpos = nullptr; uint32_t* d_counts = nullptr;
+        if ((rc = dalloc(h, &d_devpos, m))) return rc;
+        if ((rc = dalloc(h, &d_counts, mp))) return rc;
+        if ((rc = upload(h, d_devpos, devpos.data(), (size_t)m))) return rc;
+        DESC_HIP(hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * std::max<int64_t>(1, mp), h->stream));
+        if (nsl > 0) {
+            int g = (int)std::min<int64_t>(4096, (nsl + 3) / 4);
+            hipLaunchKernelGGL(k_layout_node_dev, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo,
+                               d_pos_edge2 + h->seg_lo, d_ii, d_jj, s->d_k, s->d_ikj, s->d_jki, h->d_rowptr, d_adj, d_adj_eid, d_rij,
+                               h->d_pk, h->d_S0, h->d_seg_perm, d_counts + h->seg_lo, (int)nsl);
+        }
+        hipLaunchKernelGGL(k_adj_seg, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256))), dim3(256), 0, h->stream,
+                           h->d_rowptr, d_adj, d_adj_eid, d_devpos, h->d_cum, d_counts, (int)h->seg_lo, (int)h->seg_hi, h->d_adj_seg, (int)n);
+        DESC_HIP(hipStreamSynchronize(h->stream));
+        dfree(h, d_devpos); dfree(h, d_counts);
     }
     (void)hipEventRecord(e1, h->stream);
     hipError_t e = hipStreamSynchronize(h->stream);

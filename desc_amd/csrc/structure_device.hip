@@ -257,15 +257,22 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
     if (max_codeg > MAX_CODEG_LDS)
         return fail(DESC_ERR_TOO_LARGE, "an edge has %d common neighbours (> %d): use DESC_BUILD_HOST", max_codeg, MAX_CODEG_LDS);
     const int64_t mp = s->m_pos, mc = s->m_cycle;
-    s->k.assign((size_t)mc, 0); s->e_jk.assign((size_t)mc, 0); s->e_ki.assign((size_t)mc, 0);
-    s->ikj.assign((size_t)mc, -1); s->jki.assign((size_t)mc, -1);
+    s->k.clear(); s->e_jk.clear(); s->e_ki.clear(); s->ikj.clear(); s->jki.clear();
+    s->host_cycles = (mp == 0);                       // per-cycle arrays stay in HBM until somebody asks for them
     if (mp > 0) {
         std::vector<int32_t> cum32((size_t)mp + 1), pos_of_edge((size_t)m, -1);
         for (int64_t l = 0; l <= mp; ++l) cum32[l] = (int32_t)s->cum_ind[l];
         for (int64_t l = 0; l < mp; ++l) pos_of_edge[s->pos_edge[l]] = (int32_t)l;
         int32_t *d_pos, *d_cum, *d_poe, *d_k, *d_ejk, *d_eki, *d_ikj, *d_jki;
-        if ((rc = D.alloc(&d_pos, mp)) || (rc = D.alloc(&d_cum, mp + 1)) || (rc = D.alloc(&d_poe, m)) || (rc = D.alloc(&d_k, mc)) ||
-            (rc = D.alloc(&d_ejk, mc)) || (rc = D.alloc(&d_eki, mc)) || (rc = D.alloc(&d_ikj, mc)) || (rc = D.alloc(&d_jki, mc))) return rc;
+        if ((rc = D.alloc(&d_pos, mp)) || (rc = D.alloc(&d_cum, mp + 1)) || (rc = D.alloc(&d_poe, m))) return rc;
+        // the five per-cycle arrays outlive this call: owned by the structure object
+        s->dev = device;
+        DESC_HIP(hipMalloc((void**)&s->d_k, sizeof(int32_t) * mc));
+        DESC_HIP(hipMalloc((void**)&s->d_ejk, sizeof(int32_t) * mc));
+        DESC_HIP(hipMalloc((void**)&s->d_eki, sizeof(int32_t) * mc));
+        DESC_HIP(hipMalloc((void**)&s->d_ikj, sizeof(int32_t) * mc));
+        DESC_HIP(hipMalloc((void**)&s->d_jki, sizeof(int32_t) * mc));
+        d_k = s->d_k; d_ejk = s->d_ejk; d_eki = s->d_eki; d_ikj = s->d_ikj; d_jki = s->d_jki;
         DESC_HIP(hipMemcpy(d_pos, s->pos_edge.data(), sizeof(int32_t) * mp, hipMemcpyHostToDevice));
         DESC_HIP(hipMemcpy(d_cum, cum32.data(), sizeof(int32_t) * (mp + 1), hipMemcpyHostToDevice));
         DESC_HIP(hipMemcpy(d_poe, pos_of_edge.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
@@ -281,14 +288,31 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
         hipLaunchKernelGGL(k_mirror, dim3(g), dim3(256), 0, 0, d_pos, d_cum, d_poe, d_ii, d_jj, d_k, d_ejk, d_eki, d_ikj, d_jki, mp);
         DESC_HIP(hipGetLastError());
         DESC_HIP(hipDeviceSynchronize());
-        DESC_HIP(hipMemcpy(s->k.data(), d_k, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
-        DESC_HIP(hipMemcpy(s->e_jk.data(), d_ejk, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
-        DESC_HIP(hipMemcpy(s->e_ki.data(), d_eki, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
-        DESC_HIP(hipMemcpy(s->ikj.data(), d_ikj, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
-        DESC_HIP(hipMemcpy(s->jki.data(), d_jki, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
     }
     s->ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return DESC_OK;
+}
+
+int structure_ensure_host(desc_structure* s) {
+    if (!s || s->host_cycles) return DESC_OK;
+    const int64_t mc = s->m_cycle;
+    DESC_HIP(hipSetDevice(s->dev));
+    s->k.resize((size_t)mc); s->e_jk.resize((size_t)mc); s->e_ki.resize((size_t)mc); s->ikj.resize((size_t)mc); s->jki.resize((size_t)mc);
+    DESC_HIP(hipMemcpy(s->k.data(), s->d_k, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
+    DESC_HIP(hipMemcpy(s->e_jk.data(), s->d_ejk, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
+    DESC_HIP(hipMemcpy(s->e_ki.data(), s->d_eki, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
+    DESC_HIP(hipMemcpy(s->ikj.data(), s->d_ikj, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
+    DESC_HIP(hipMemcpy(s->jki.data(), s->d_jki, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
+    s->host_cycles = true;
+    return DESC_OK;
+}
+
+void structure_free_device(desc_structure* s) {
+    if (!s || s->dev < 0) return;
+    (void)hipSetDevice(s->dev);
+    for (int32_t* q : {s->d_k, s->d_ejk, s->d_eki, s->d_ikj, s->d_jki}) if (q) (void)hipFree(q);
+    s->d_k = s->d_ejk = s->d_eki = s->d_ikj = s->d_jki = nullptr;
+    s->dev = -1;
 }
 
 }  // namespace desc
