@@ -109,10 +109,10 @@ def main():
     t0 = time.perf_counter()
     st = _lib.Structure.build(prob, 30, args.seed, _lib.BUILD_DEVICE, 0)
     t_struct = time.perf_counter() - t0
-    arrays = st.arrays()
     t0 = time.perf_counter()
     solver = _lib.Solver(prob, st, 0)
     t_create = time.perf_counter() - t0
+    arrays = st.arrays()                 # host copy for the CPU baseline (not needed by the GPU path; untimed)
     st.free()
 
     p = _lib.default_params()

@@ -163,6 +163,7 @@ class ProblemArrays:
         self.ind_j = np.ascontiguousarray(ind_j, dtype=np.int32)
         self.rij = None if rij is None else np.ascontiguousarray(rij, dtype=np.float64).reshape(-1)
         m = self.ind_i.shape[0]
+        self.n, self.m = int(n), int(m)
         if self.rij is not None and self.rij.shape[0] != 9 * m:
             raise ValueError("rij must hold m*9 doubles")
         self.c = Problem(int(n), m, ptr(self.ind_i, I32P), ptr(self.ind_j, I32P), ptr(self.rij, F64P))
@@ -331,6 +332,19 @@ class Solver:
             self.destroy()
         except Exception:
             pass
+
+
+def solve(prob: ProblemArrays, params: Params, want_w=False):
+    """One-shot desc_pgd_solve: structure build + layout + run + download in one C call."""
+    r = Result()
+    bufs = dict(s_vec=np.zeros(max(prob.m, 1)), obj=np.zeros(max(params.iters, 1)), avg=np.zeros(max(params.iters, 1)))
+    r.s_vec = ptr(bufs["s_vec"], F64P)
+    r.obj_trace = ptr(bufs["obj"], F64P)
+    r.avg_change_trace = ptr(bufs["avg"], F64P)
+    check(load().desc_pgd_solve(C.byref(prob.c), C.byref(params), C.byref(r)))
+    it = r.iters_run
+    return dict(S_vec=bufs["s_vec"][:prob.m], obj=bufs["obj"][:it], avg=bufs["avg"][:it], iters_run=it, t_end=r.t_end,
+                ms_upload=r.ms_upload, ms_cycle_d=r.ms_cycle_d, ms_pgd=r.ms_pgd, ms_total=r.ms_total, ms_structure=r.ms_structure)
 
 
 def spectral_run(prob: ProblemArrays, weights=None, normalize_rows=False, tol=1e-13, max_iters=500, device=0):

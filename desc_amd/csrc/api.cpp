@@ -123,14 +123,15 @@ int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* 
     if (!p || !r) return fail(DESC_ERR_INVALID, "NULL argument");
     auto t0 = std::chrono::steady_clock::now();
     desc_structure* s = nullptr;
-    int rc = desc_structure_build(prob, p->n_sample_min > 0 ? p->n_sample_min : 30, p->seed, p->build_where, p->device, &s);
+    int rc = validate_problem(prob, true);
+    if (rc) return rc;
+    rc = desc_structure_build(prob, p->n_sample_min > 0 ? p->n_sample_min : 30, p->seed, p->build_where, p->device, &s);
     if (rc == DESC_ERR_TOO_LARGE && p->build_where == DESC_BUILD_DEVICE)      // device budget exceeded: host builder
         rc = desc_structure_build(prob, p->n_sample_min > 0 ? p->n_sample_min : 30, p->seed, DESC_BUILD_HOST, p->device, &s);
     if (rc) return rc;
     double ms_structure = s->ms_build;
     desc_pgd* h = nullptr;
-    rc = validate_problem(prob, true);
-    if (!rc) rc = desc_pgd_create(prob, s, p->device, &h);
+    rc = desc_pgd_create(prob, s, p->device, &h);
     desc_structure_free(s);
     if (rc) return rc;
     rc = desc_pgd_run(h, p, r);

@@ -1258,17 +1258,20 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
     if (band <= 0)   // rows of one band should stay in an XCD's 4 MiB L2 next to the streamed arrays: ~1 MiB
         band = (int)std::max<int64_t>(8, std::min<int64_t>(512, (1 << 20) / (8 * (int64_t)std::max(1, max_deg))));
     P.band = band;
+    // order by (band(i), j, i): Ind is sorted by (i, j), so two stable counting sorts (by j, then
+    // by band) give it in O(m_pos + n)
     P.order.resize((size_t)mp);
-    for (int64_t l = 0; l < mp; ++l) P.order[l] = (int32_t)l;
     {
         const int32_t* ii = prob->ind_i; const int32_t* jj = prob->ind_j; const int32_t* pe = s->pos_edge.data();
-        std::sort(P.order.begin(), P.order.end(), [=](int32_t x, int32_t y) {      // (band(i), j, i)
-            const int32_t ex = pe[x], ey = pe[y];
-            const int32_t bx = ii[ex] / band, by = ii[ey] / band;
-            if (bx != by) return bx < by;
-            if (jj[ex] != jj[ey]) return jj[ex] < jj[ey];
-            return ii[ex] < ii[ey];
-        });
+        const int64_t n = prob->n, nb = n / band + 1;
+        std::vector<int32_t> tmp((size_t)mp), cnt((size_t)std::max(n, nb) + 1, 0);
+        for (int64_t l = 0; l < mp; ++l) cnt[jj[pe[l]] + 1]++;
+        for (int64_t v = 0; v < n; ++v) cnt[v + 1] += cnt[v];
+        for (int64_t l = 0; l < mp; ++l) tmp[cnt[jj[pe[l]]]++] = (int32_t)l;
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (int64_t l = 0; l < mp; ++l) cnt[ii[pe[l]] / band + 1]++;
+        for (int64_t b = 0; b < nb; ++b) cnt[b + 1] += cnt[b];
+        for (int64_t t = 0; t < mp; ++t) { const int32_t l = tmp[t]; P.order[cnt[ii[pe[l]] / band]++] = l; }
     }
     P.cum2.assign((size_t)mp + 1, 0);
     for (int64_t q = 0; q < mp; ++q) {
@@ -1292,10 +1295,19 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
 int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     const int64_t n = h->n, m = h->m, mp = h->m_pos;
     auto t0 = std::chrono::steady_clock::now();
+    auto t_lap = t0;
+    const bool timing = env_int("DESC_DEBUG_TIMING", 0) != 0;
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[desc_amd] setup_node %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_lap).count());
+        t_lap = now;
+    };
     int rc;
     NodePlan P;
     if ((rc = make_node_plan(prob, s, h->max_deg, h->world, P))) return rc;
     h->band = P.band;
+    lap("plan");
     const std::vector<int32_t>& cum2 = P.cum2;
     const int64_t nch_all = (int64_t)P.chunk_seg.size() - 1;
     const int64_t ch_a = P.rank_chunk[h->rank], ch_b = P.rank_chunk[h->rank + 1];
@@ -1314,24 +1326,18 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     std::vector<int32_t> rowptr((size_t)n + 1, 0), adj((size_t)2 * m), adj_eid((size_t)2 * m);
     for (int64_t e = 0; e < m; ++e) { rowptr[prob->ind_i[e] + 1]++; rowptr[prob->ind_j[e] + 1]++; }
     for (int64_t v = 0; v < n; ++v) rowptr[v + 1] += rowptr[v];
+    // slot of every edge in its two endpoint rows (eslot: smaller endpoint, for S_vec extraction)
+    std::vector<int32_t> eslot((size_t)m), eslot_b((size_t)m);
     {
         std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
         for (int64_t e = 0; e < m; ++e) {
             const int32_t i = prob->ind_i[e], j = prob->ind_j[e];
+            eslot[e] = fill[i]; eslot_b[e] = fill[j];
             adj[fill[i]] = j; adj_eid[fill[i]++] = (int32_t)e;
             adj[fill[j]] = i; adj_eid[fill[j]++] = (int32_t)e;
         }
     }
-    auto idx_in_row = [&](int32_t v, int32_t u) {
-        const int32_t* b = adj.data() + rowptr[v];
-        const int32_t* e = adj.data() + rowptr[v + 1];
-        return (int32_t)(std::lower_bound(b, e, u) - b);
-    };
-    // slot of every edge in its smaller endpoint's row (for S_vec extraction)
-    std::vector<int32_t> eslot((size_t)m);
-    host_parallel(m, [&](int64_t a, int64_t b) {
-        for (int64_t e = a; e < b; ++e) eslot[e] = rowptr[prob->ind_i[e]] + idx_in_row(prob->ind_i[e], prob->ind_j[e]);
-    });
+    lap("csr+eslot");
     std::vector<int32_t> cum_loc((size_t)mp + 1), src_start((size_t)mp), pos_edge2((size_t)mp), devpos((size_t)m, -1);
     std::vector<EdgeInfo> einfo((size_t)mp);
     for (int64_t q = 0; q <= mp; ++q) cum_loc[q] = cum2[q] - (int32_t)h->cyc_lo;   // local cycle numbering (meaningful for owned segments)
@@ -1343,10 +1349,11 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     host_parallel(mp, [&](int64_t a, int64_t b) {
         for (int64_t q = a; q < b; ++q) {
             const int32_t e = pos_edge2[q], i = prob->ind_i[e], j = prob->ind_j[e];
-            einfo[q] = EdgeInfo{rowptr[i], rowptr[j], eslot[e], rowptr[j] + idx_in_row(j, i)};
+            einfo[q] = EdgeInfo{rowptr[i], rowptr[j], eslot[e], eslot_b[e]};
         }
     });
-    const bool dev_cycles = !s->host_cycles && s->dev == h->device && s->d_k != nullptr;   // structure built on this device
+    lap("einfo");
+    const bool dev_cycles = s->dev == h->device && s->d_k != nullptr;   // structure built on this device
     std::vector<uint32_t> kf; std::vector<uint8_t> seg_perm; std::vector<uint32_t> seg_counts; std::vector<int2> adj_seg;
     if (!dev_cycles) {
         if ((rc = structure_ensure_host(const_cast<desc_structure*>(s)))) return rc;
@@ -1384,6 +1391,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
             }
     });
     }
+    lap("host pack");
     // chunk tables: all chunks, local cycle numbering
     std::vector<int32_t> chunk_seg(P.chunk_seg), chunk_c0((size_t)nch_all + 2);
     for (int64_t t = 0; t <= nch_all; ++t) chunk_c0[t] = cum_loc[chunk_seg[t]];
@@ -1408,6 +1416,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     if ((rc = dalloc(h, &h->d_chunk_c0, chunk_c0.size()))) return rc;
     if ((rc = dalloc(h, &h->d_pairs, 2 * (size_t)h->world))) return rc;
     if ((rc = dalloc(h, &h->d_rank_seg, (size_t)h->world + 1))) return rc;
+    lap("alloc");
     int32_t *d_ii = nullptr, *d_jj = nullptr, *d_adj = nullptr, *d_adj_eid = nullptr, *d_pos_edge2 = nullptr;
     uint32_t* d_kf = nullptr; double* d_rij = nullptr;
     if ((rc = dalloc(h, &d_ii, m))) return rc;
@@ -1437,6 +1446,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     if ((rc = upload(h, d_rij, prob->rij, 9 * (size_t)m))) return rc;
     DESC_HIP(hipStreamSynchronize(h->stream));
     h->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    lap("upload");
 
     h->G = h->max_cnt <= 16 ? 1 : h->max_cnt <= 32 ? 2 : 4;   // cycles per lane, 16 lanes per segment
     {   // persistent grid: exactly the workgroups that are co-resident (registers / LDS decide)
@@ -1465,6 +1475,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     snprintf(nm, sizeof nm, "k_sweep_node<%d,", h->G);
     h->kname = nm;
 
+    lap("occupancy/attrs");
     hipEvent_t e0, e1;
     DESC_HIP(hipEventCreate(&e0)); DESC_HIP(hipEventCreate(&e1));
     (void)hipEventRecord(e0, h->stream);
@@ -1495,6 +1506,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     if (e == hipSuccess) e = hipGetLastError();
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     h->ms_cycle_d = ms;
+    lap("layout kernels");
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     dfree(h, d_ii); dfree(h, d_jj); dfree(h, d_adj); dfree(h, d_adj_eid); dfree(h, d_pos_edge2); dfree(h, d_kf); dfree(h, d_rij);
     if (e != hipSuccess) return fail(DESC_ERR_HIP, "k_layout_node: %s", hipGetErrorString(e));

@@ -226,3 +226,40 @@ def test_device_structure_edge_cases(lib):
     S_host = DESC_PGD(mo.Ind, mo.RijMat, dict(iters=20, Gradient=ConstantStepSize(0.01), seed=5, verbose=False))
     S_dev = DESC_PGD(mo.Ind, mo.RijMat, dict(iters=20, Gradient=ConstantStepSize(0.01), seed=5, verbose=False, build_where=lib.BUILD_DEVICE))
     assert np.array_equal(S_host, S_dev)
+
+
+@pytest.mark.parametrize("n,p,seed,kind", [(30, 0.5, 1, 0), (120, 0.6, 3, 1), (260, 0.5, 5, 2), (200, 0.5, 4, 0)])
+def test_device_resident_structure_layout(lib, oracle, n, p, seed, kind):
+    """Structure built on the device and laid out in place (k_layout_node_dev / k_adj_seg; no host copy
+    of the per-cycle arrays) against the oracle: S0, w, S_vec, traces."""
+    mo, nn, ii, jj, rij = make_problem("uniform", n=n, p=p, q=0.2, sigma=0.1, seed=seed)
+    step = dict(step_kind=kind, lr=0.01)
+    st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=21, iters=60, **step)
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    dev_st = lib.Structure.build(prob, 30, 21, lib.BUILD_DEVICE, 0)
+    solver = lib.Solver(prob, dev_st, 0)          # before any .arrays(): the host copy does not exist yet
+    try:
+        assert "node" in solver.kernel_name()
+        s0 = solver.s0()
+        out = solver.run(c_params(60, seed=21, **step), want_w=True)
+    finally:
+        solver.destroy()
+    assert_structure_equal(dev_st.arrays(), st)   # lazy download still works afterwards
+    dev_st.free()
+    check(out, ref, s0, S0)
+
+
+def test_one_shot_solve(lib, oracle):
+    """desc_pgd_solve (build + layout + run in one C call) == oracle; also with the host builder."""
+    mo, nn, ii, jj, rij = make_problem("uniform", n=150, p=0.5, q=0.3, sigma=0.1, seed=8)
+    st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=4, iters=100, lr=0.01)
+    for where in (lib.BUILD_DEVICE, lib.BUILD_HOST):
+        p = c_params(100, lr=0.01, seed=4)
+        p.build_where = where
+        out = lib.solve(lib.ProblemArrays(nn, ii, jj, rij), p)
+        assert out["iters_run"] == ref["iters_run"]
+        assert np.abs(out["S_vec"] - ref["S_vec"]).max() <= TOL
+        assert np.allclose(out["obj"], ref["obj"], rtol=1e-12, atol=1e-9)
+        assert out["ms_total"] >= out["ms_pgd"] > 0
+    with pytest.raises(lib.DescError):
+        lib.solve(lib.ProblemArrays(nn, ii, jj), c_params(10))       # no rotations: must refuse, not crash
