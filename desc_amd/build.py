@@ -30,22 +30,6 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_variant(tag, defines):
-    """Tuning builds with other compile-time geometry (tools/ only)."""
-    out = os.path.join(HERE, f"libdesc_amd_{tag}.so")
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    subprocess.check_call([hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", out] + sources())
-    return out
-
-
-def build_stamps():
-    """Diagnostic library with in-kernel s_memtime stamps (tools/ only, never loaded by the package)."""
-    out = os.path.join(HERE, "libdesc_amd_stamps.so")
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    subprocess.check_call([hipcc] + FLAGS + ["-DDESC_STAMPS", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", out] + sources())
-    return out
-
-
 def build(force=False, verbose=False):
     """Compile every HIP/C++ source of the package into desc_amd/libdesc_amd.so."""
     if not force and not needs_build():

@@ -354,31 +354,20 @@ struct EdgeInfo {
 // packed per-cycle word: bits 0-14 idx_i(k), bit 15 cycle (ik;j) sampled (IKJ_appears, :113),
 //                        bits 16-30 idx_j(k), bit 31 cycle (jk;i) sampled (JKI_appears, :124)
 
-// Diagnostic build only (-DDESC_STAMPS, tools/): per-phase s_memtime shares of the sweep,
-// written to a buffer of their own; no stamp executes in the production library.
-#ifdef DESC_STAMPS
-#define STAMP(slot)                                                                      \
-    do {                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                               \
-        unsigned long long _t;                                                           \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");       \
-        __builtin_amdgcn_sched_barrier(0);                                               \
-        if (tid == 0) stamp_acc[slot] += _t - stamp_last;                                \
-        stamp_last = _t;                                                                 \
-    } while (0)
-#else
-#define STAMP(slot) do {} while (0)
-#endif
 
-#ifndef DESC_CHUNK_LDS
-#define DESC_CHUNK_LDS 960
-#endif
-#ifndef DESC_SWEEP_THREADS
-#define DESC_SWEEP_THREADS 512
-#endif
-constexpr int CHUNK_LDS = DESC_CHUNK_LDS;    // entries of the LDS image of a chunk
+constexpr int SWEEP_THREADS = 512;
+constexpr int CHUNK_LDS = 960;             // entries of the LDS image of a chunk: one 16-byte vector of w per thread
 constexpr int CHUNK_CAP = CHUNK_LDS - 4;   // cycles per chunk: the image starts up to 3 entries before the chunk (16-byte alignment)
-constexpr int CHUNK_SEG = 64;     // segments per chunk
+constexpr int CHUNK_SEG = 32;              // segments per chunk: one pass of the 8 waves x 4 groups of 16 lanes
+
+// first / end cycle and first / end segment of a chunk, one 16-byte scalar load
+struct alignas(16) ChunkDesc { int32_t c0, c1, l0, l1; };
+__device__ __forceinline__ ChunkDesc uniform_load_desc(const ChunkDesc* p, int i) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef const v4i __attribute__((address_space(4)))* cptr_t;
+    const v4i v = ((cptr_t)(unsigned long long)p)[i];
+    return ChunkDesc{v.x, v.y, v.z, v.w};
+}
 
 struct NodeSweepArgs {
     const int32_t* cum;        // m_pos+1, device order
@@ -393,100 +382,87 @@ struct NodeSweepArgs {
     const double* nv_tab;
     double* partials;
     const DevState* state;
-    const int32_t* chunk_seg;  // nchunks+1: first segment of every chunk
-    const int32_t* chunk_c0;   // nchunks+1: first cycle of every chunk
+    const ChunkDesc* chunk_desc;   // nchunks: {c0, c1, l0, l1}
     StepArgs st;
     int32_t nchunks;
     int32_t max_cnt;
     int32_t ablate;
-    unsigned long long* stamps;   // diagnostic build only: [grid][8] cycle sums per phase
 };
-
-// Per-chunk segment records in LDS
-struct SegRec {
-    int base[CHUNK_SEG + 1];                 // first cycle of each segment (+ end)
-    int rbi[CHUNK_SEG], rbj[CHUNK_SEG];      // rowptr[i], rowptr[j]
-    int sa[CHUNK_SEG], sb[CHUNK_SEG];        // slots of the edge in rows i and j
-    double T1[CHUNK_SEG], T2[CHUNK_SEG], So[CHUNK_SEG];
-};
-// LDS image of one chunk.  Entry q' = (cycle - a0) where a0 = c0 & ~3 is the chunk's first
-// cycle rounded down to a 16-byte boundary of the packed-word array, so that every
-// streaming load / store is a 16-byte access.
-struct alignas(16) ChunkBuf {
-    double w[CHUNK_LDS], d[CHUNK_LDS], ss[CHUNK_LDS];
-    uint32_t pk[CHUNK_LDS];
-};
-constexpr int SWEEP_THREADS = DESC_SWEEP_THREADS;
 
 struct StreamRegs { uint4 pk; double2 w, d; };   // one 16-byte vector of each streamed array
 
-// Sweep over chunks of consecutive segments (<= CHUNK_CAP cycles, <= CHUNK_SEG segments
-// per workgroup pass), software-pipelined with double-buffered LDS.  While chunk i is
-// computed out of LDS, the row gathers S(jk), S(ki) of chunk i+1 and the 16-byte streaming
-// loads of chunks i+2 and i+3 are in flight (two register sets, loop unrolled by two).
-// gfx950 retires loads AND stores through one in-order counter (vmcnt), so (1) loads are
-// issued in the order in which they are consumed, (2) every pipelined load is
-// unconditional (clamped index instead of a branch) so the compiler can count them and
-// emit exact vmcnt(N) waits, (3) the chunk's stores are the youngest memory operations of
-// an iteration.
-//   iteration i:
-//     1  [streaming registers of chunk i+1 landed] park pk, w, d in LDS buffer (i+1)&1;
-//        segment id of every cycle of chunk i+1
-//     2  issue its row gathers (2 per cycle) and its per-edge T1/T2/S_old loads
-//     3  issue segment-record loads of chunk i+2 and streaming loads of chunk i+3
-//     4  D(i): per-segment arithmetic out of LDS buffer i&1 -- 16 lanes per segment,
-//        E cycles per lane, 4 segments per wave pass; results stay in LDS
-//     5  16-byte stores of w_new, S_new of chunk i
-//     6  [gathers landed] S(jk)+S(ki) and T1/T2/S_old of chunk i+1 -> LDS; publish the
-//        segment records of chunk i+2
+// LDS image of one chunk.  Entry q' = (cycle - a0) where a0 = c0 & ~3 is the chunk's first
+// cycle rounded down to a 16-byte boundary of the packed-word array, so that every
+// streaming load is a 16-byte access.
+struct alignas(16) ChunkBuf {
+    double w[CHUNK_LDS], d[CHUNK_LDS];
+    uint32_t pk[CHUNK_LDS];
+};
+
+// The sweep (dominant kernel).  512-thread persistent workgroups take chunks of consecutive
+// segments (<= CHUNK_CAP cycles, <= CHUNK_SEG segments) round-robin: at any moment the
+// resident workgroups read one contiguous window of the streamed arrays (DRAM row-buffer
+// locality; disjoint far-apart streams per workgroup measured ~half the bandwidth).
+// pk, w and S0 of a chunk arrive with 16-byte loads, two chunks ahead, and are parked in a
+// triple-buffered LDS image.  Everything per segment lives in the registers of the 16 lanes
+// that own the segment (a chunk = one pass of the 8 waves x 4 lane groups): the lane group
+// that will compute segment t of chunk c+1 loads its records, issues its row gathers
+// (addresses from the packed words already parked in LDS) and keeps their sums until the
+// arithmetic of chunk c+1; E cycles per lane, reductions = E in-lane adds + 4 DPP steps
+// shared by the 4 segments of a wave; simplex threshold by Michelot's fixed point with a
+// division-free comparison (same active set as the reference's sort-and-scan, :215-223);
+// weights and S leave with 8-byte stores straight from registers (16 lanes x 8 B = 128
+// contiguous bytes).  One workgroup barrier per chunk.
+//   iteration c:  park stream(c+1) -> LDS[(c+1)%3] | barrier | gathers(c+1) | records(c+2),
+//                 stream(c+3) | arithmetic(c) out of LDS[c%3] + registers | land gathers and
+//                 records | stores(c)
+// gfx950 retires loads AND stores through one in-order counter (vmcnt): every pipelined
+// load is unconditional (clamped index instead of a branch) so the compiler can count
+// them, and a load that is waited for after a store point would make the wave wait for the
+// stores too, so gathers and records are consumed (landed) after the arithmetic but before
+// the stores of the iteration that issued them.  Chunk descriptors are prefetched four
+// chunks ahead with one scalar 16-byte load (constant cache: off vmcnt).
 template <int E, int STEP>
-__global__ __launch_bounds__(SWEEP_THREADS, 4) void k_sweep_node(NodeSweepArgs a) {   // 4 waves per SIMD: <= 128 VGPRs
-    __shared__ ChunkBuf X[2];
-    __shared__ SegRec R[2];
-    __shared__ uint8_t c_seg[CHUNK_LDS];
+__global__ __launch_bounds__(SWEEP_THREADS, 4) void k_sweep_node(NodeSweepArgs a) {
+    __shared__ ChunkBuf X[3];
     __shared__ double s_nv[65];
     if (a.state->stop) return;
-    constexpr int NT = SWEEP_THREADS, NW = NT / 64;
-    constexpr int U = (CHUNK_LDS + NT - 1) / NT;          // cycles per thread in the gather step
+    constexpr int NT = SWEEP_THREADS;
+    static_assert(NT == 512 && CHUNK_SEG == 32, "8 waves x 4 lane groups = CHUNK_SEG");
     static_assert(CHUNK_LDS / 2 <= NT, "one 16-byte vector of w per thread");
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int grp = lane >> 4, r16 = lane & 15;
-    // Chunks are dealt round-robin: at any moment the resident workgroups read one contiguous
-    // window of the streamed arrays (DRAM row-buffer locality; disjoint far-apart streams per
-    // workgroup measured ~half the bandwidth).  k-th chunk of this workgroup = lb + k*nb.
-    const int nb = gridDim.x;
-    const int lb = blockIdx.x;
+    const int ts = wv * 4 + grp;                       // segment slot of this lane group
+    const int nb = gridDim.x, lb = blockIdx.x;         // chunks dealt round-robin (see k_sweep_node)
     const int nk = lb < a.nchunks ? (a.nchunks - lb + nb - 1) / nb : 0;
     double obj_acc = 0.0, chg_acc = 0.0;
     if (nk == 0) { block_partials(obj_acc, chg_acc, a.partials, lb); return; }
-
     if (tid <= 64) s_nv[tid] = tid <= a.max_cnt ? a.nv_tab[tid] : 0.0;
-    StreamRegs SA{}, SB{};                                   // even chunks of this workgroup -> SA, odd ones -> SB
-    struct RecRegs { int base; EdgeInfo ei; };
-    struct GatherRegs { double sjk[U], ski[U], T1, T2, So; };
-#ifdef DESC_STAMPS
-    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = 0;
-#endif
 
-    // (register sets are passed and returned BY VALUE and every pipelined load is
-    //  unconditional: a reference to a local struct would push it to scratch, and a value merged
-    //  at a control-flow join makes the compiler wait for the load right where it was issued)
-    auto load_records = [&](int ch) -> RecRegs {  // cum / einfo of chunk ch -> registers (clamped, unconditional)
-        const int l0 = uniform_load(a.chunk_seg, ch), ns = uniform_load(a.chunk_seg, ch + 1) - l0;
-        RecRegs rr;
-        rr.base = a.cum[l0 + min(tid, ns)];
-        rr.ei = a.einfo[l0 + min(tid, ns - 1)];
-        return rr;
+    struct RecRaw { int b0, b1; EdgeInfo ei; };
+    struct Rec { int qb, cnt, rbi, rbj, sa, sb; };     // qb: image entry of the segment's first cycle
+    struct Gat { double sjk[E], ski[E], T1, T2, So; };
+    struct Landed { double ss[E], T1, T2, So; };       // S(jk)+S(ki) per cycle, mirror sums, old S of the segment
+    struct Carry { StreamRegs s; Landed g; Rec r; };
+
+    // past the end every load is redirected to this workgroup's last chunk: harmless and branch-free
+    auto desc_of = [&](int k) -> ChunkDesc { return uniform_load_desc(a.chunk_desc, lb + min(k, nk - 1) * nb); };
+    auto load_rec = [&](const ChunkDesc d) -> RecRaw {
+        const int t = d.l0 + min(ts, d.l1 - d.l0 - 1);
+        RecRaw r;
+        r.b0 = a.cum[t]; r.b1 = a.cum[t + 1]; r.ei = a.einfo[t];
+        return r;
     };
-    auto publish_records = [&](int ch, const RecRegs rg, SegRec& rr) {
-        const int ns = uniform_load(a.chunk_seg, ch + 1) - uniform_load(a.chunk_seg, ch);
-        if (tid <= ns) rr.base[tid] = rg.base;
-        if (tid < ns) { rr.rbi[tid] = rg.ei.rb_i; rr.rbj[tid] = rg.ei.rb_j; rr.sa[tid] = rg.ei.slot_a; rr.sb[tid] = rg.ei.slot_b; }
+    auto land_rec = [&](const ChunkDesc d, const RecRaw q) -> Rec {
+        Rec r;
+        r.qb = q.b0 - (d.c0 & ~3);
+        r.cnt = ts < d.l1 - d.l0 ? q.b1 - q.b0 : 0;
+        r.rbi = q.ei.rb_i; r.rbj = q.ei.rb_j; r.sa = q.ei.slot_a; r.sb = q.ei.slot_b;
+        return r;
     };
-    auto load_stream = [&](int ch) -> StreamRegs {            // 16-byte loads; image entry 0 = cycle a0 = c0 & ~3
-        const int c0 = uniform_load(a.chunk_c0, ch), c1 = uniform_load(a.chunk_c0, ch + 1);
-        const int a0 = c0 & ~3, last = c1 - 1 - a0;          // last image entry that is needed
+    auto load_stream = [&](const ChunkDesc d) -> StreamRegs {   // 16-byte loads; image entry 0 = cycle a0 = c0 & ~3
+        const int a0 = d.c0 & ~3, last = d.c1 - 1 - a0;
         const int v2 = min(tid, last >> 1), v4 = min(tid, last >> 2);
         StreamRegs sr;
         sr.w = *reinterpret_cast<const double2*>(a.w_old + a0 + 2 * (int64_t)v2);
@@ -494,94 +470,58 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void k_sweep_node(NodeSweepArgs a
         sr.pk = *reinterpret_cast<const uint4*>(a.pk + a0 + 4 * (int64_t)v4);
         return sr;
     };
-    auto park_stream_and_fill = [&](int ch, const StreamRegs sr, const SegRec& rr, ChunkBuf& xb) {
-        const int c0 = uniform_load(a.chunk_c0, ch), c1 = uniform_load(a.chunk_c0, ch + 1);
-        const int a0 = c0 & ~3, last = c1 - 1 - a0, ns = uniform_load(a.chunk_seg, ch + 1) - uniform_load(a.chunk_seg, ch);
+    auto park = [&](const ChunkDesc d, const StreamRegs sr, ChunkBuf& xb) {
+        const int last = d.c1 - 1 - (d.c0 & ~3);
         if (tid <= (last >> 1)) { *reinterpret_cast<double2*>(&xb.w[2 * tid]) = sr.w; *reinterpret_cast<double2*>(&xb.d[2 * tid]) = sr.d; }
         if (tid <= (last >> 2)) *reinterpret_cast<uint4*>(&xb.pk[4 * tid]) = sr.pk;
-        for (int t = wv; t < ns; t += NW) {
-            const int b = rr.base[t] - a0, cnt = rr.base[t + 1] - rr.base[t];
-            for (int q = lane; q < cnt; q += 64) c_seg[b + q] = (uint8_t)t;
-        }
     };
-    auto issue_gathers = [&](int ch, const SegRec& rr, const ChunkBuf& xb) -> GatherRegs {
-        GatherRegs gr;
-        const int c0 = uniform_load(a.chunk_c0, ch), c1 = uniform_load(a.chunk_c0, ch + 1);
-        const int off = c0 & 3, hi = off + (c1 - c0) - 1, ns = uniform_load(a.chunk_seg, ch + 1) - uniform_load(a.chunk_seg, ch);
+    auto issue_gathers = [&](const Rec r, const ChunkBuf& xb) -> Gat {
+        Gat g;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {          // all 2U gathers go out before any is consumed
-            const int q = min(max(tid + NT * u, off), hi);
-            const int sg = c_seg[q];
-            const uint32_t p = xb.pk[q];
-            int si = rr.rbi[sg] + (int)(p & 0x7FFFu), sj = rr.rbj[sg] + (int)((p >> 16) & 0x7FFFu);
+        for (int e = 0; e < E; ++e) {                // unconditional: idle lanes repeat the segment's first cycle
+            const int idx = r16 + 16 * e;
+            const uint32_t p = xb.pk[r.qb + (idx < r.cnt ? idx : 0)];
+            int si = r.rbi + (int)(p & 0x7FFFu), sj = r.rbj + (int)((p >> 16) & 0x7FFFu);
             if (a.ablate & 1) { si = lane; sj = lane; }     // diagnostics: gathers that always hit L1
-            gr.sjk[u] = a.S_old[sj]; gr.ski[u] = a.S_old[si];
+            if (a.ablate & 2) { si = (int)(p & 511u); sj = (int)((p >> 16) & 511u); }   // divergent, but inside one 4 KiB window
+            g.sjk[e] = a.S_old[sj]; g.ski[e] = a.S_old[si];
         }
-        const int tt = min(tid, ns - 1);
-        const int sa = rr.sa[tt], sb = rr.sb[tt];
-        gr.T1 = a.Tfull[sa];                    // column j of node i = sum(wijk(IKJ(mask)))  (:189)
-        gr.T2 = a.Tfull[sb];                    // column i of node j = sum(wijk(JKI(mask)))  (:190)
-        gr.So = a.S_old[sa];
-        return gr;
-    };
-    auto park_gathers = [&](int ch, const GatherRegs gr, SegRec& rr, ChunkBuf& xb) {
-        const int c0 = uniform_load(a.chunk_c0, ch), c1 = uniform_load(a.chunk_c0, ch + 1);
-        const int off = c0 & 3, hi = off + (c1 - c0) - 1, ns = uniform_load(a.chunk_seg, ch + 1) - uniform_load(a.chunk_seg, ch);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int q = tid + NT * u;
-            if (q >= off && q <= hi) xb.ss[q] = gr.sjk[u] + gr.ski[u];                               // S(jk)+S(ki)
-        }
-        if (tid < ns) { rr.T1[tid] = gr.T1; rr.T2[tid] = gr.T2; rr.So[tid] = gr.So; }
+        g.T1 = a.Tfull[r.sa];                    // column j of node i = sum(wijk(IKJ(mask)))  (:189)
+        g.T2 = a.Tfull[r.sb];                    // column i of node j = sum(wijk(JKI(mask)))  (:190)
+        g.So = a.S_old[r.sa];
+        return g;
     };
 
-    // one pipeline iteration; s1 = register set of chunk ch+1 (and, after parking, of chunk ch+3)
-    auto iterate = [&](int k, StreamRegs s1) -> StreamRegs {
-        // past the end the loads are redirected to this workgroup's current chunk: harmless, and
-        // the pipeline stays free of branches
-        const int ch = lb + k * nb;
-        const int ch1 = k + 1 < nk ? ch + nb : ch, ch2 = k + 2 < nk ? ch + 2 * nb : ch, ch3 = k + 3 < nk ? ch + 3 * nb : ch;
-        SegRec& rc = R[k & 1];
-        ChunkBuf& xc = X[k & 1];
-        SegRec& rn = R[(k + 1) & 1];
-        ChunkBuf& xn = X[(k + 1) & 1];
-        if (a.ablate & 256) {          // diagnostics: pure streaming ceiling of this launch geometry
-            obj_acc += s1.w.x + s1.d.y + (double)s1.pk.x;
-            return load_stream(ch3);
-        }
-        STAMP(7);
-        __syncthreads();                                        // chunk ch staged, records of ch+1 visible
-        STAMP(0);
-        // ---- 1: chunk ch+1: park the streamed arrays, segment ids
-        park_stream_and_fill(ch1, s1, rn, xn);
+    // one pipeline iteration: chunk k of this workgroup is computed; c.s = stream registers of
+    // chunk k+1, c.g = gathers of chunk k, c.r = records of chunk k+1; r0 = records of chunk k
+    auto iterate = [&](int k, const Carry c, const Rec r0, const ChunkDesc d0, const ChunkDesc d1, const ChunkDesc d2,
+                       const ChunkDesc d3) -> Carry {
+        Carry o;
+        Gat gn;
+        ChunkBuf& xc = X[k % 3];
+        ChunkBuf& xn = X[(k + 1) % 3];
+        park(d1, c.s, xn);
         __syncthreads();
-        STAMP(1);
-        // ---- 2: its gathers
-        const GatherRegs gr = issue_gathers(ch1, rn, xn);
-        STAMP(2);
-        // ---- 3: records of chunk ch+2, stream of chunk ch+3
-        const RecRegs rg = load_records(ch2);
-        s1 = load_stream(ch3);
-        STAMP(3);
-        // ---- 4: D(ch)
-        const int c0 = uniform_load(a.chunk_c0, ch), c1 = uniform_load(a.chunk_c0, ch + 1), a0 = c0 & ~3;
-        const int nseg = uniform_load(a.chunk_seg, ch + 1) - uniform_load(a.chunk_seg, ch);
-        for (int t0 = wv * 4; t0 < ((a.ablate & 64) ? 0 : nseg); t0 += 4 * NW) {
-            const int t = t0 + grp;
-            const bool edge_ok = t < nseg;
-            int base = 0, cnt = 0;
-            double T1 = 0.0, T2 = 0.0, nv = 0.0;
-            if (edge_ok) { base = rc.base[t] - a0; cnt = rc.base[t + 1] - rc.base[t]; T1 = rc.T1[t]; T2 = rc.T2[t]; nv = s_nv[cnt]; }
-            double ws[E];                      // gradient, then stepped weight, of this lane's E cycles
-            uint32_t okm = 0;
-            double part = 0.0;
+        gn = issue_gathers(c.r, xn);
+        const RecRaw q2 = load_rec(d2);
+        o.s = load_stream(d3);
+        // ---- arithmetic of chunk k
+        const int a0 = d0.c0 & ~3;
+        const int cnt = r0.cnt;
+        const double T1 = c.g.T1, T2 = c.g.T2, nv = cnt > 0 ? s_nv[cnt] : 0.0;
+        double ws[E];
+        uint32_t okm = 0;
+        double part = 0.0;
+        // waves whose four lane groups own no segment of this chunk skip the arithmetic (wave-uniform)
+        if (__ballot(cnt > 0) != 0ull && !(a.ablate & 64)) {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int idx = r16 + 16 * e;
                 const bool ok = idx < cnt;
-                const int q = base + idx;
-                uint32_t p = 0; double w = 0.0, d = 0.0, ss = 0.0;
-                if (ok) { p = xc.pk[q]; w = xc.w[q]; d = xc.d[q]; ss = xc.ss[q]; okm |= 1u << e; }
+                const int q = r0.qb + idx;
+                uint32_t p = 0; double w = 0.0, d = 0.0;
+                if (ok) { p = xc.pk[q]; w = xc.w[q]; d = xc.d[q]; okm |= 1u << e; }
+                const double ss = c.g.ss[e];                                                         // S(jk)+S(ki)
                 obj_acc += w * ss;                                                                   // :233, one sweep late
                 const double g = ss + (((p & 0x8000u) ? T1 : 0.0) + ((p & 0x80000000u) ? T2 : 0.0)) * d;   // :193
                 ws[e] = g;
@@ -590,7 +530,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void k_sweep_node(NodeSweepArgs a
             const double dot = group16_sum(part);                                                    // :199-201
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const int q = base + r16 + 16 * e;
+                const int q = r0.qb + r16 + 16 * e;
                 const double g = ws[e] - dot * nv;
                 ws[e] = ((okm >> e) & 1u) ? apply_step<STEP>(a.st, xc.w[q], g, (int64_t)a0 + q) : 0.0;   // :207
             }
@@ -616,63 +556,73 @@ __global__ __launch_bounds__(SWEEP_THREADS, 4) void k_sweep_node(NodeSweepArgs a
             double sn = 0.0;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                if ((okm >> e) & 1u) {
-                    const int q = base + r16 + 16 * e;
-                    const double wn = fmax(ws[e] - T, 0.0);                                          // :224
-                    xc.w[q] = wn;
-                    sn += wn * xc.d[q];
-                }
+                const double wn = fmax(ws[e] - T, 0.0);                                              // :224
+                ws[e] = wn;
+                if ((okm >> e) & 1u) sn += wn * xc.d[r0.qb + r16 + 16 * e];
             }
-            const double snew = group16_sum(sn);                                                     // :229
-            if (edge_ok && r16 == 0) {
-                chg_acc += fabs(snew - rc.So[t]);                                                    // :232
-                rc.T1[t] = snew;
+            part = group16_sum(sn);                                                                  // :229
+        }
+        // gathers of chunk k+1 and records of chunk k+2 are consumed before this iteration's stores
+        // (see the header); the gathers shrink to their sums
+#pragma unroll
+        for (int e = 0; e < E; ++e) o.g.ss[e] = gn.sjk[e] + gn.ski[e];
+        o.g.T1 = gn.T1; o.g.T2 = gn.T2; o.g.So = gn.So;
+        o.r = land_rec(d2, q2);
+        // pin the landing here: without it the scheduler sinks these adds below the stores
+#pragma unroll
+        for (int e = 0; e < E; ++e) asm volatile("" : "+v"(o.g.ss[e]));
+        asm volatile("" : "+v"(o.g.T1), "+v"(o.g.T2), "+v"(o.g.So));
+        asm volatile("" : "+v"(o.r.qb), "+v"(o.r.cnt), "+v"(o.r.rbi), "+v"(o.r.rbj), "+v"(o.r.sa), "+v"(o.r.sb));
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(a.ablate & 128)) {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if ((okm >> e) & 1u) a.w_new[(int64_t)a0 + r0.qb + r16 + 16 * e] = ws[e];
+            if (cnt > 0 && r16 == 0) {
+                chg_acc += fabs(part - c.g.So);                                                      // :232
+                a.S_new[r0.sa] = part; a.S_new[r0.sb] = part;
             }
         }
-        STAMP(4);
-        __syncthreads();                                        // results of chunk ch complete in LDS
-        STAMP(5);
-        // ---- 5: stores of chunk ch: 16 bytes per lane, 8 at the two ragged ends
-        {
-            const int off = c0 - a0, hi = off + (c1 - c0) - 1;  // valid image entries [off, hi]
-            const int e0 = 2 * tid, e1 = 2 * tid + 1;
-            if (a.ablate & 128) {}
-            else if (e0 >= off && e1 <= hi) *reinterpret_cast<double2*>(a.w_new + a0 + e0) = *reinterpret_cast<const double2*>(&xc.w[e0]);
-            else if (e0 >= off && e0 <= hi) a.w_new[(int64_t)a0 + e0] = xc.w[e0];
-            else if (e1 >= off && e1 <= hi) a.w_new[(int64_t)a0 + e1] = xc.w[e1];
-        }
-        if (tid < nseg) { const double sv = rc.T1[tid]; a.S_new[rc.sa[tid]] = sv; a.S_new[rc.sb[tid]] = sv; }
-        STAMP(6);
-        // ---- 6: chunk ch+1 complete in LDS; records of chunk ch+2 published
-        park_gathers(ch1, gr, rn, xn);
-        publish_records(ch2, rg, rc);
-        return s1;
+        return o;
     };
 
-    // ---- prologue: chunk 0 of this workgroup fully staged; chunks 1 and 2 streaming
+    // ---- prologue: chunk 0 parked and its gathers in flight, streams of chunks 1 and 2 in flight
+    ChunkDesc D0 = desc_of(0), D1 = desc_of(1), D2 = desc_of(2), D3 = desc_of(3);
+    Rec R0;
+    Carry CA, CB;
     {
-        const RecRegs rg0 = load_records(lb);
-        SA = load_stream(lb);
-        publish_records(lb, rg0, R[0]);
+        const RecRaw q0 = load_rec(D0);
+        const StreamRegs s0 = load_stream(D0);
+        const RecRaw q1 = load_rec(D1);
+        CA.s = load_stream(D1);                  // CA: consumed by even iterations
+        CB.s = load_stream(D2);
+        R0 = land_rec(D0, q0);
+        park(D0, s0, X[0]);
         __syncthreads();
-        park_stream_and_fill(lb, SA, R[0], X[0]);
-        __syncthreads();
-        const GatherRegs gr0 = issue_gathers(lb, R[0], X[0]);
-        const int c1 = nk > 1 ? lb + nb : lb, c2 = nk > 2 ? lb + 2 * nb : lb;
-        const RecRegs rg1 = load_records(c1);
-        SB = load_stream(c1);
-        SA = load_stream(c2);
-        park_gathers(lb, gr0, R[0], X[0]);
-        publish_records(c1, rg1, R[1]);
+        const Gat g0 = issue_gathers(R0, X[0]);
+#pragma unroll
+        for (int e = 0; e < E; ++e) CA.g.ss[e] = g0.sjk[e] + g0.ski[e];
+        CA.g.T1 = g0.T1; CA.g.T2 = g0.T2; CA.g.So = g0.So;
+        CA.r = land_rec(D1, q1);
     }
-
+    // Two iterations per trip (the register sets alternate).  The second one always runs -- with
+    // an odd number of chunks it computes nothing (cnt = 0) -- so that the compiler sees one
+    // straight-line loop body and can count the loads in flight across the back edge.
     for (int k = 0; k < nk; k += 2) {
-        SB = iterate(k, SB);                                    // odd chunks live in SB, even ones in SA
-        if (k + 1 < nk) SA = iterate(k + 1, SA);
+        {
+            const ChunkDesc Dn = desc_of(k + 4);
+            const Carry o = iterate(k, CA, R0, D0, D1, D2, D3);       // parks CA.s (chunk k+1), consumes CA.g (chunk k)
+            R0 = CA.r; CB.g = o.g; CB.r = o.r; CA.s = o.s;            // CA.s now streams chunk k+3
+            D0 = D1; D1 = D2; D2 = D3; D3 = Dn;
+        }
+        {
+            if (k + 1 >= nk) R0.cnt = 0;
+            const ChunkDesc Dn = desc_of(k + 5);
+            const Carry o = iterate(k + 1, Carry{CB.s, CB.g, CB.r}, R0, D0, D1, D2, D3);
+            R0 = CB.r; CA.g = o.g; CA.r = o.r; CB.s = o.s;
+            D0 = D1; D1 = D2; D2 = D3; D3 = Dn;
+        }
     }
-#ifdef DESC_STAMPS
-    if (tid == 0 && a.stamps) for (int k = 0; k < 8; ++k) a.stamps[8 * lb + k] = stamp_acc[k];
-#endif
     block_partials(obj_acc, chg_acc, a.partials, lb);
 }
 
@@ -1022,10 +972,10 @@ struct desc_pgd {
     EdgeInfo* d_einfo = nullptr;
     uint32_t* d_pk = nullptr;
     int2* d_adj_seg = nullptr;   // per CSR slot: {first cycle of the incident edge's segment, cnt | (row node is the smaller endpoint) << 31}
-    int32_t *d_rowptr = nullptr, *d_src_start = nullptr, *d_eslot = nullptr, *d_chunk_seg = nullptr, *d_chunk_c0 = nullptr;
+    int32_t *d_rowptr = nullptr, *d_src_start = nullptr, *d_eslot = nullptr;
+    ChunkDesc* d_chunk_desc = nullptr;
     int nchunks = 0;
     double *d_T = nullptr, *d_Svec = nullptr;
-    unsigned long long* d_stamps = nullptr;
     uint8_t* d_seg_perm = nullptr;     // natural in-segment offset of every device-order cycle
     // sharding (world == 1: the whole problem)
     int rank = 0, world = 1;
@@ -1156,7 +1106,7 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
         NodeSweepArgs a{};
         a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
         a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_T ? h->x_T : h->d_T; a.nv_tab = h->d_nv; a.partials = h->d_partials;
-        a.state = h->d_state; a.st = st; a.chunk_seg = h->d_chunk_seg + h->ch_lo; a.chunk_c0 = h->d_chunk_c0 + h->ch_lo; a.nchunks = h->nchunks; a.max_cnt = h->max_cnt; a.ablate = h->ablate; a.stamps = h->d_stamps;
+        a.state = h->d_state; a.st = st; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks; a.max_cnt = h->max_cnt; a.ablate = h->ablate;
         if (adam) launch_node<DESC_STEP_HYBRID>(h, a); else launch_node<DESC_STEP_CONSTANT>(h, a);
     } else {
         SweepArgs a{};
@@ -1252,7 +1202,7 @@ struct NodePlan {
     std::vector<int64_t> rank_chunk;  // world+1
 };
 
-int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_deg, int world, NodePlan& P) {
+int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_deg, int world, int max_seg, NodePlan& P) {
     const int64_t mp = s->m_pos;
     int band = env_int("DESC_DEBUG_BAND", 0);
     if (band <= 0)   // rows of one band should stay in an XCD's 4 MiB L2 next to the streamed arrays: ~1 MiB
@@ -1282,7 +1232,7 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
     P.chunk_seg.push_back(0);
     for (int64_t q = 0; q < mp;) {     // chunks: <= CHUNK_CAP cycles and <= CHUNK_SEG segments
         int64_t e = q;
-        while (e < mp && e - q < CHUNK_SEG && P.cum2[e + 1] - P.cum2[q] <= CHUNK_CAP) ++e;
+        while (e < mp && e - q < max_seg && P.cum2[e + 1] - P.cum2[q] <= CHUNK_CAP) ++e;
         q = e;                          // max_cnt <= 64 <= CHUNK_CAP: always advances
         P.chunk_seg.push_back((int32_t)q);
     }
@@ -1305,7 +1255,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     };
     int rc;
     NodePlan P;
-    if ((rc = make_node_plan(prob, s, h->max_deg, h->world, P))) return rc;
+    if ((rc = make_node_plan(prob, s, h->max_deg, h->world, CHUNK_SEG, P))) return rc;
     h->band = P.band;
     lap("plan");
     const std::vector<int32_t>& cum2 = P.cum2;
@@ -1393,10 +1343,9 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     }
     lap("host pack");
     // chunk tables: all chunks, local cycle numbering
-    std::vector<int32_t> chunk_seg(P.chunk_seg), chunk_c0((size_t)nch_all + 2);
-    for (int64_t t = 0; t <= nch_all; ++t) chunk_c0[t] = cum_loc[chunk_seg[t]];
-    chunk_c0[nch_all + 1] = cum_loc[mp];                 // pad: the kernel reads [ch+2] only when ch+1 exists
-    chunk_seg.push_back((int32_t)mp);
+    std::vector<ChunkDesc> chunk_desc((size_t)std::max<int64_t>(nch_all, 1));
+    for (int64_t t = 0; t < nch_all; ++t)
+        chunk_desc[t] = ChunkDesc{cum_loc[P.chunk_seg[t]], cum_loc[P.chunk_seg[t + 1]], P.chunk_seg[t], P.chunk_seg[t + 1]};
 
     if ((rc = dalloc(h, &h->d_S0, mcl + 8))) return rc;   // +8: 16-byte tail reads
     if ((rc = dalloc(h, &h->d_w[0], mcl + 8))) return rc;
@@ -1412,8 +1361,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     if ((rc = dalloc(h, &h->d_S[1], 2 * m))) return rc;
     if ((rc = dalloc(h, &h->d_T, 2 * m))) return rc;
     if ((rc = dalloc(h, &h->d_Svec, m))) return rc;
-    if ((rc = dalloc(h, &h->d_chunk_seg, chunk_seg.size()))) return rc;
-    if ((rc = dalloc(h, &h->d_chunk_c0, chunk_c0.size()))) return rc;
+    if ((rc = dalloc(h, &h->d_chunk_desc, chunk_desc.size()))) return rc;
     if ((rc = dalloc(h, &h->d_pairs, 2 * (size_t)h->world))) return rc;
     if ((rc = dalloc(h, &h->d_rank_seg, (size_t)h->world + 1))) return rc;
     lap("alloc");
@@ -1433,8 +1381,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     if (!dev_cycles && (rc = upload(h, h->d_adj_seg, adj_seg.data(), (size_t)2 * m))) return rc;
     if ((rc = upload(h, h->d_src_start, src_start.data(), (size_t)mp))) return rc;
     if ((rc = upload(h, h->d_eslot, eslot.data(), (size_t)m))) return rc;
-    if ((rc = upload(h, h->d_chunk_seg, chunk_seg.data(), chunk_seg.size()))) return rc;
-    if ((rc = upload(h, h->d_chunk_c0, chunk_c0.data(), chunk_c0.size()))) return rc;
+    if ((rc = upload(h, h->d_chunk_desc, chunk_desc.data(), chunk_desc.size()))) return rc;
     if ((rc = upload(h, h->d_rank_seg, rank_seg32.data(), rank_seg32.size()))) return rc;
     if ((rc = upload(h, d_ii, prob->ind_i, (size_t)m))) return rc;
     if ((rc = upload(h, d_jj, prob->ind_j, (size_t)m))) return rc;
@@ -1459,10 +1406,6 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
         int64_t want = std::min<int64_t>(std::max(h->nchunks, 1), (int64_t)ncu * per_cu);
         h->grid = (int)(std::max<int64_t>(want, 8) + 7) / 8 * 8;
     }
-#ifdef DESC_STAMPS
-    if ((rc = dalloc(h, &h->d_stamps, 8 * (size_t)h->grid))) return rc;
-    DESC_HIP(hipMemset(h->d_stamps, 0, sizeof(unsigned long long) * 8 * (size_t)h->grid));
-#endif
     h->obj_grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (nsl + 3) / 4));
     h->colsum_stride = (h->max_deg + 1) | 1;                 // odd stride: the 4 copies start on different banks
     h->colsum_grid = (int)std::max<int64_t>(1, n);            // one node per workgroup: the dispatcher balances
@@ -1875,8 +1818,8 @@ int desc_pgd_shard_sweep(desc_pgd* h) {
     NodeSweepArgs a{};
     a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
     a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_T; a.nv_tab = h->d_nv; a.partials = h->d_partials;
-    a.state = h->d_state; a.st = st; a.chunk_seg = h->d_chunk_seg + h->ch_lo; a.chunk_c0 = h->d_chunk_c0 + h->ch_lo; a.nchunks = h->nchunks;
-    a.max_cnt = h->max_cnt; a.ablate = 0; a.stamps = nullptr;
+    a.state = h->d_state; a.st = st; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks;
+    a.max_cnt = h->max_cnt; a.ablate = 0;
     if (adam) launch_node<DESC_STEP_HYBRID>(h, a); else launch_node<DESC_STEP_CONSTANT>(h, a);
     const int nloc = (int)(h->seg_hi - h->seg_lo);
     hipLaunchKernelGGL(k_pack_S, dim3(std::max(1, std::min(1024, (nloc + 255) / 256))), dim3(256), 0, h->stream, h->d_einfo, h->d_S[wr],
@@ -1942,16 +1885,6 @@ int desc_pgd_stopped(desc_pgd* h, int32_t* stopped) {
     return DESC_OK;
 }
 
-#ifdef DESC_STAMPS
-// diagnostic build: phase cycle sums of the last sweep, averaged over workgroups
-int desc_debug_stamps(desc_pgd* h, double* out8) {
-    if (!h || !out8 || !h->d_stamps) return fail(DESC_ERR_INVALID, "no stamps");
-    std::vector<unsigned long long> v(8 * (size_t)h->grid);
-    DESC_HIP(hipMemcpy(v.data(), h->d_stamps, sizeof(unsigned long long) * v.size(), hipMemcpyDeviceToHost));
-    for (int k = 0; k < 8; ++k) { double a = 0; for (int b = 0; b < h->grid; ++b) a += (double)v[8 * b + k]; out8[k] = a / h->grid; }
-    return DESC_OK;
-}
-#endif
 
 // test hook: group_sum over a buffer of 64*k doubles
 int desc_selftest_group_sum(const double* in, double* out, int32_t count, int32_t G, int32_t device) {

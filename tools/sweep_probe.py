@@ -14,6 +14,7 @@ ap.add_argument("--ablate", default="0,1,2,4,8,16,3,15,31")
 ap.add_argument("--grids", default="")
 ap.add_argument("--variant", default="0")
 ap.add_argument("--band", default="0")
+ap.add_argument("--warm", type=int, default=40)
 args = ap.parse_args()
 os.environ["DESC_DEBUG_VARIANT"] = args.variant
 os.environ["DESC_DEBUG_BAND"] = args.band
@@ -24,17 +25,9 @@ solver = _lib.Solver(prob, st, 0)
 st.free()
 B = 72.0 * solver.m_cycle + 12.0 * solver.m_pos
 def run(tag):
-    p = _lib.default_params(); p.iters = 2 * args.steps + 10; p.patience = (1 << 31) - 1
-    solver.reset(p); solver.iterate(3); solver.sync()
+    p = _lib.default_params(); p.iters = 2 * args.steps + args.warm + 10; p.patience = (1 << 31) - 1
+    solver.reset(p); solver.iterate(args.warm); solver.sync()
     ms, mk = solver.iterate_timed(args.steps, per_kernel=True)
-    if "stamps" in _lib.LIB_PATH:
-        import ctypes as C, numpy as np
-        out = np.zeros(8)
-        L = _lib.load(); L.desc_debug_stamps.argtypes = [C.c_void_p, _lib.F64P]
-        _lib.check(L.desc_debug_stamps(solver.handle, _lib.ptr(out, _lib.F64P)))
-        names = ["top_sync", "fill+sync", "gathers_issue+park", "issue_next", "D", "sync_afterD", "stores", "park_gathers+publish"]
-        tot = out.sum()
-        print("stamps (cycles per workgroup per sweep, share):", {n: (int(v), round(v / tot, 3)) for n, v in zip(names, out)}, flush=True)
     print(json.dumps(dict(variant=args.variant, band=args.band, kernel=solver.kernel_name(), tag=tag, kernel_ms=mk, step_ms=ms / args.steps, GBs=B / mk / 1e6, frac=B / mk / 1e6 / 8000)), flush=True)
 for ab in args.ablate.split(","):
     os.environ["DESC_DEBUG_ABLATE"] = ab
