@@ -19,12 +19,13 @@
 //  gather inside one contiguous row.  Per cycle one packed word holds idx_i(k), idx_j(k)
 //  and the two mirror-present bits (DESC_PGD.m:113,124).  The mirror sums are column
 //  sums of per-node weight matrices: T1(i,j) = sum_k w(ik;j) = column j of node i,
-//  T2(i,j) = column i of node j.  k_colsum_node streams every segment once per endpoint
-//  and accumulates the columns in LDS (per-wave private copies, fixed order ->
-//  bitwise reproducible); k_sweep_node then needs no gather of w at all.
+//  T2(i,j) = column i of node j.  k_colsum_node streams, per endpoint, the cycles of every
+//  incident segment whose mirror was sampled and accumulates the columns in LDS (per-wave
+//  private copies, fixed order -> bitwise reproducible); k_sweep_node then needs no gather
+//  of w at all.
 //    HBM traffic per cycle and iteration: sweep 28 B (w r/w 16, S0 8, packed word 4)
-//    + column sums 24 B (w 8 + packed word 4, per endpoint) = 52 B streamed, plus the
-//    row gathers of S served by L1/L2.
+//    + column sums (w 8 + packed word 4 for the mirrored cycles only), plus the row
+//    gathers of S served by L1/L2.
 //
 //  GATHER (fallback: max degree >= 32768, more LDS than a workgroup may hold, or
 //  segments longer than 64 cycles).  Natural edge order; per cycle e_jk, e_ki, ikj, jki
