@@ -8,7 +8,11 @@ inconsistencies are already resident in HBM when the timed region starts.
 
     python bench.py --gpus N --steps K --warmup W [--workload C1..C5]
 
-N = 1 runs BASELINE.json configs[1] (Uniform n=1000 p=0.5 q=0.3, sigma=0.1).
+Every N runs BASELINE.json configs[1] (C2: Uniform n=1000 p=0.5 q=0.3, sigma=0.1) -- strong
+scaling: the total work is fixed, at N > 1 the edges-with-cycles are sharded over the ranks with
+an all-reduce and an all-gather per iteration (desc_amd/sharded.py).  C2 is small enough that a
+single GPU is about as fast as any sharding, so the N > 1 line additionally carries
+`north_star_config`: the same measurement on C4 (configs[3], n=5000 p=0.2).
 Prints ONE JSON line (rank 0) with the contract's fields plus `roofline` (dominant
 kernel: the sweep, HBM-bound, algorithmic bytes 72*m_cycle + 12*m_pos per launch,
 SURVEY.md 8d) and `cpu_baseline` (the oracle's OpenMP C restatement timed on this
@@ -148,7 +152,7 @@ def main():
         pass
     line = {
         "metric": "DESC_PGD iters/sec", "value": K / dt, "unit": "iters/s", "n_gpus": 1, "steps": K, "warmup": W,
-        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": describe(name), "n": nn, "m": m, "m_pos": m_pos, "m_cycle": m_cycle,
                    "n_sample": int(arrays["n_sample"]), "sampling_seed": args.seed, "parallelism": "1 GPU"},

@@ -192,26 +192,28 @@ def init_distributed():
     return rank, world, device
 
 
-def bench_sharded(args, WORKLOADS, describe, generate, cpu_baseline):
-    """bench.py body for --gpus N > 1 (launched by torch.distributed.run, one rank per GPU)."""
-    import torch                                         # before libdesc_amd.so: see _lib.load()
-    rank, world, device = init_distributed()
-    name = args.workload or "C4"
+def _bench_one(name, args, rank, world, device, comm, describe, generate):
+    """K timed sharded iterations of one workload; returns the measurements (identical on every rank)."""
+    import torch
     K, W = args.steps, args.warmup
     mo, nn, ii, jj, rij = generate(name)                 # identical on every rank (fixed seeds)
     prob = _lib.ProblemArrays(nn, ii, jj, rij)
     t0 = time.perf_counter()
-    st = _lib.Structure.build(prob, 30, args.seed, _lib.BUILD_HOST, device)
+    try:
+        st = _lib.Structure.build(prob, 30, args.seed, _lib.BUILD_DEVICE, device)
+    except _lib.DescError:
+        st = _lib.Structure.build(prob, 30, args.seed, _lib.BUILD_HOST, device)
     t_struct = time.perf_counter() - t0
-    arrays_n_sample = st.sizes()["n_sample"]
+    n_sample = st.sizes()["n_sample"]
+    t0 = time.perf_counter()
     shard = HipShard(prob, st, device, rank, world)
+    t_create = time.perf_counter() - t0
     st.free()
-    comm = TorchComm()
     drv = ShardedDriver(shard, comm)
     p = _lib.default_params()
     p.iters = W + K + 4
     p.lr = 0.01
-    p.patience = (1 << 31) - 1
+    p.patience = (1 << 31) - 1          # the bench times exactly K sweeps: never stop early
     p.seed = args.seed
     drv.start(p)
     drv.iterate(W)
@@ -224,26 +226,54 @@ def bench_sharded(args, WORKLOADS, describe, generate, cpu_baseline):
     dt = comm.max_float(time.perf_counter() - t0)
     out = drv.finish()
     info = shard.info
-    m_cycle, m_pos, m = info.m_cycle, info.m_pos, shard.solver.m
-    bytes_iter = 72.0 * m_cycle + 12.0 * m_pos
+    res = dict(name=name, nn=nn, m=shard.solver.m, m_pos=info.m_pos, m_cycle=info.m_cycle, n_sample=int(n_sample), dt=dt,
+               t_struct=t_struct, t_create=t_create, err=float(np.mean(np.abs(out["S_vec"] - mo.ErrVec))),
+               workload=describe(name))
+    shard.destroy()
+    return res
+
+
+def bench_sharded(args, WORKLOADS, describe, generate, cpu_baseline):
+    """bench.py body for --gpus N > 1 (launched by torch.distributed.run, one rank per GPU).
+
+    The bench line is the same workload as at N = 1 (C2, strong scaling: total work fixed, edges
+    sharded over the ranks, all-reduce + all-gather per iteration).  C2 is small enough that one
+    GPU is about as fast as any sharding; the line therefore also carries
+    `north_star_config`: the same measurement on C4 (BASELINE.json configs[3], n = 5000)."""
+    import torch                                         # before libdesc_amd.so: see _lib.load()
+    rank, world, device = init_distributed()
+    comm = TorchComm()
+    K, W = args.steps, args.warmup
+    name = args.workload or "C2"
+    r = _bench_one(name, args, rank, world, device, comm, describe, generate)
+    extra = None
+    if args.workload is None:
+        x = _bench_one("C4", args, rank, world, device, comm, describe, generate)
+        xb = 72.0 * x["m_cycle"] + 12.0 * x["m_pos"]
+        extra = {"workload": x["workload"], "value": K / x["dt"], "unit": "iters/s", "ms_per_step": x["dt"] / K * 1e3,
+                 "m_cycle": x["m_cycle"], "roofline_frac_of_aggregate_hbm": xb / (x["dt"] / K) / 1e9 / (8000.0 * world),
+                 "setup_ms": {"structure": x["t_struct"] * 1e3, "create_shard": x["t_create"] * 1e3},
+                 "mean_abs_err_vs_truth": x["err"]}
+    dt = r["dt"]
+    bytes_iter = 72.0 * r["m_cycle"] + 12.0 * r["m_pos"]
     line = {
         "metric": "DESC_PGD iters/sec", "value": K / dt, "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": describe(name), "n": nn, "m": m, "m_pos": m_pos, "m_cycle": m_cycle,
-                   "n_sample": int(arrays_n_sample), "sampling_seed": args.seed,
+        "config": {"workload": r["workload"], "n": r["nn"], "m": r["m"], "m_pos": r["m_pos"], "m_cycle": r["m_cycle"],
+                   "n_sample": r["n_sample"], "sampling_seed": args.seed,
                    "parallelism": f"edges sharded over {world} GPUs; all-reduce T (2m f64) + all-gather S per iteration"},
         "roofline": {"bound": "hbm", "achieved": bytes_iter / (dt / K) / 1e9, "peak": 8000.0 * world, "unit": "GB/s",
                      "frac": bytes_iter / (dt / K) / 1e9 / (8000.0 * world), "traffic": None,
                      "kernel": "whole iteration incl. collectives (aggregate over ranks)", "bytes_per_launch": bytes_iter},
-        "cycle_updates_per_s": m_cycle * K / dt,
+        "cycle_updates_per_s": r["m_cycle"] * K / dt,
         "cpu_baseline": None,
-        "setup_ms": {"structure_host": t_struct * 1e3},
-        "mean_abs_err_vs_truth": float(np.mean(np.abs(out["S_vec"] - mo.ErrVec))),
+        "setup_ms": {"structure": r["t_struct"] * 1e3, "create_shard": r["t_create"] * 1e3},
+        "mean_abs_err_vs_truth": r["err"],
+        "north_star_config": extra,
     }
     if rank == 0:
         print(json.dumps(line), flush=True)
-    shard.destroy()
     import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()
