@@ -36,11 +36,22 @@ struct desc_structure {
     std::vector<int64_t> cum_ind;
     std::vector<int32_t> k, e_jk, e_ki, ikj, jki;   // per-cycle arrays on the host (valid iff host_cycles)
     double ms_build = 0.0;
-    // A structure built on the device keeps its per-cycle arrays in HBM (natural order) and copies
-    // them to the host only when somebody asks (desc_structure_get, the gather layout).
+    // A structure built on the device stays there in a lean form: the sampled third vertices `k`
+    // (natural order), per edge-with-cycles the selection threshold (largest selected key and its k;
+    // all ones when the edge was not sampled) -- enough to decide "was cycle (ik;j) sampled?" without
+    // the mirror maps -- plus the CSR adjacency the solver's layout kernels re-use.  e_jk, e_ki, ikj,
+    // jki are derived (device kernels) and copied to the host only when somebody asks
+    // (desc_structure_get, the gather layout).
     bool host_cycles = true;
     int dev = -1;
-    int32_t *d_k = nullptr, *d_ejk = nullptr, *d_eki = nullptr, *d_ikj = nullptr, *d_jki = nullptr;
+    int32_t *d_k = nullptr;
+    unsigned long long* d_tau = nullptr;      // m_pos
+    int32_t* d_ktau = nullptr;                // m_pos
+    int32_t *d_rowptr = nullptr, *d_adj = nullptr, *d_adj_eid = nullptr;   // n+1, 2m, 2m
+    int32_t *d_ii = nullptr, *d_jj = nullptr;                              // m
+    int32_t *d_pos = nullptr, *d_cum = nullptr, *d_poe = nullptr;          // m_pos, m_pos+1, m (edge -> index in pos_edge, -1)
+    int32_t max_deg = 0;
+    uint64_t seed = 0;
 };
 
 namespace desc {

@@ -105,6 +105,18 @@ __device__ __forceinline__ int uniform_load(const int32_t* p, int i) {
     return ((cptr_t)(unsigned long long)p)[i];
 }
 
+// device copy of desc::sample_key (common.h): the cycle-sampling key
+__device__ __forceinline__ uint64_t d_mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+__device__ __forceinline__ uint64_t d_sample_key(uint64_t seed, uint64_t edge, uint64_t k) {
+    const uint64_t a = d_mix64(seed ^ ((edge + 1) * 0x9E3779B97F4A7C15ull));
+    return d_mix64(a ^ ((k + 1) * 0xD1B54A32D192ED03ull));
+}
+
 // Blocks b and b+8 share an XCD (round-robin dispatch, observed; speed only).
 // Give each XCD a contiguous range of logical blocks so neighbouring edge
 // segments -- which gather each other's cycle weights -- share one L2.

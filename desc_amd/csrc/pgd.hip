@@ -735,14 +735,17 @@ __global__ __launch_bounds__(256) void k_layout_node(const int32_t* cum, const i
     }
 }
 
-// The same, reading a device-built structure in place (natural order: k, ikj, jki) and doing the
-// within-segment re-ordering [both mirrors | (ik;j) only | (jk;i) only | none] in the wave
-// (stable: ascending k inside a class, exactly like the host path).  Segments have <= 64 cycles.
+// The same for a device-built structure, in place: reads the sampled k (natural order), decides
+// the two mirror-present bits from the selection thresholds of the partner edges -- cycle (ik;j)
+// was sampled iff (key(e_ik, j), j) <= (tau, ktau) of edge {i,k} -- and does the within-segment
+// re-ordering [both mirrors | (ik;j) only | (jk;i) only | none] in the wave (stable: ascending k
+// inside a class, exactly like the host path).  Segments have <= 64 cycles.
 __global__ __launch_bounds__(256) void k_layout_node_dev(const int32_t* cum, const int32_t* src_start, const int32_t* pos_edge,
                                                          const int32_t* ind_i, const int32_t* ind_j, const int32_t* nat_k,
-                                                         const int32_t* nat_ikj, const int32_t* nat_jki, const int32_t* rowptr,
-                                                         const int32_t* adj, const int32_t* adj_eid, const double* rij, uint32_t* pk,
-                                                         double* S0, uint8_t* seg_perm, uint32_t* seg_counts, int m_pos) {
+                                                         const int32_t* poe, const unsigned long long* tau, const int32_t* ktau,
+                                                         uint64_t seed, const int32_t* rowptr, const int32_t* adj,
+                                                         const int32_t* adj_eid, const double* rij, uint32_t* pk, double* S0,
+                                                         uint8_t* seg_perm, uint32_t* seg_counts, int m_pos) {
     const int lane = threadIdx.x & 63;
     const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * 256) >> 6;
@@ -753,8 +756,27 @@ __global__ __launch_bounds__(256) void k_layout_node_dev(const int32_t* cum, con
         double A[9];
         for (int t = 0; t < 9; ++t) A[t] = rij[9 * (int64_t)e + t];
         const bool on = lane < cnt;
-        int k = 0; bool fi = false, fj = false;
-        if (on) { k = nat_k[(int64_t)src + lane]; fi = nat_ikj[(int64_t)src + lane] >= 0; fj = nat_jki[(int64_t)src + lane] >= 0; }
+        int k = 0, xi = 0, xj = 0, eik = e, ejk = e;
+        bool fi = false, fj = false;
+        if (on) {
+            k = nat_k[(int64_t)src + lane];
+            int lo = 0, hi = di;                                  // idx_i(k): position of k in row i
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (adj[ri + mid] < k) lo = mid + 1; else hi = mid; }
+            xi = min(lo, max(di - 1, 0));
+            lo = 0; hi = dj;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (adj[rj + mid] < k) lo = mid + 1; else hi = mid; }
+            xj = min(lo, max(dj - 1, 0));
+            eik = adj_eid[ri + xi]; ejk = adj_eid[rj + xj];
+            const int lik = poe[eik], ljk = poe[ejk];             // both edges lie on the triangle {i,j,k}: they have cycles
+            if (lik >= 0) {
+                const unsigned long long key = d_sample_key(seed, (uint64_t)eik, (uint64_t)j), th = tau[lik];
+                fi = key < th || (key == th && j <= ktau[lik]);                                // IKJ_appears (:113)
+            }
+            if (ljk >= 0) {
+                const unsigned long long key = d_sample_key(seed, (uint64_t)ejk, (uint64_t)i), th = tau[ljk];
+                fj = key < th || (key == th && i <= ktau[ljk]);                                // JKI_appears (:124)
+            }
+        }
         const int cls = !on ? 4 : fi ? (fj ? 0 : 1) : (fj ? 2 : 3);
         const unsigned long long lt = (1ull << lane) - 1ull;
         const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
@@ -766,17 +788,27 @@ __global__ __launch_bounds__(256) void k_layout_node_dev(const int32_t* cum, con
         else if (cls == 3) o = n0 + n1 + n2 + __popcll(m3 & lt);
         if (lane == 0) seg_counts[l] = (uint32_t)n0 | (uint32_t)(n0 + n1) << 7 | (uint32_t)n2 << 14;
         if (on) {
-            int lo = 0, hi = di;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (adj[ri + mid] < k) lo = mid + 1; else hi = mid; }
-            const int xi = min(lo, max(di - 1, 0));
-            lo = 0; hi = dj;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (adj[rj + mid] < k) lo = mid + 1; else hi = mid; }
-            const int xj = min(lo, max(dj - 1, 0));
             pk[(int64_t)base + o] = (uint32_t)xi | (fi ? 1u : 0u) << 15 | (uint32_t)xj << 16 | (fj ? 1u : 0u) << 31;
             seg_perm[(int64_t)base + o] = (uint8_t)lane;
-            const double tr = cycle_trace(A, rij + 9 * (int64_t)adj_eid[rj + xj], !(j < k), rij + 9 * (int64_t)adj_eid[ri + xi], !(k < i));
+            const double tr = cycle_trace(A, rij + 9 * (int64_t)ejk, !(j < k), rij + 9 * (int64_t)eik, !(k < i));
             S0[(int64_t)base + o] = abs_acos_ext((tr - 1.0) / 2.0) / M_PI;
         }
+    }
+}
+// per-edge slots of the CSR-aligned arrays, on the device (device-built structures): eslot[e] = this
+// edge's slot in its smaller endpoint's row; einfo of the edges with cycles in device order
+__global__ __launch_bounds__(256) void k_edge_slots(const int32_t* ind_i, const int32_t* ind_j, const int32_t* rowptr, const int32_t* adj,
+                                                    const int32_t* pos_edge2, int32_t* eslot, EdgeInfo* einfo, int64_t m, int64_t m_pos) {
+    const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x, nt = (int64_t)gridDim.x * 256;
+    auto slot = [&](int v, int u) {                   // position of u in row v
+        const int r = rowptr[v]; int lo = 0, hi = rowptr[v + 1] - r;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (adj[r + mid] < u) lo = mid + 1; else hi = mid; }
+        return r + lo;
+    };
+    for (int64_t e = t0; e < m; e += nt) eslot[e] = slot(ind_i[e], ind_j[e]);
+    for (int64_t q = t0; q < m_pos; q += nt) {
+        const int e = pos_edge2[q], i = ind_i[e], j = ind_j[e];
+        einfo[q] = EdgeInfo{rowptr[i], rowptr[j], slot(i, j), slot(j, i)};
     }
 }
 // CSR-aligned segment records for the column-sum pass: 16 lanes per node row
@@ -1041,9 +1073,9 @@ int env_int(const char* name, int dflt) {
 }
 
 template <class F>
-void host_parallel(int64_t count, F&& body) {
+void host_parallel(int64_t count, F&& body, int64_t grain = 65536) {
     unsigned hw = std::thread::hardware_concurrency();
-    int nt = (int)std::min<int64_t>(std::max(1u, std::min(hw, 16u)), std::max<int64_t>(1, count / 65536));
+    int nt = (int)std::min<int64_t>(std::max(1u, std::min(hw, 16u)), std::max<int64_t>(1, count / grain));
     if (nt <= 1) { body(0, count); return; }
     std::vector<std::thread> th;
     for (int t = 0; t < nt; ++t) th.emplace_back([=, &body]() { body(count * t / nt, count * (t + 1) / nt); });
@@ -1209,20 +1241,32 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
     if (band <= 0)   // rows of one band should stay in an XCD's 4 MiB L2 next to the streamed arrays: ~1 MiB
         band = (int)std::max<int64_t>(8, std::min<int64_t>(512, (1 << 20) / (8 * (int64_t)std::max(1, max_deg))));
     P.band = band;
-    // order by (band(i), j, i): Ind is sorted by (i, j), so two stable counting sorts (by j, then
-    // by band) give it in O(m_pos + n)
+    // order by (band(i), j, i): Ind -- and with it pos_edge -- is sorted by (i, j), so a band is a
+    // contiguous range of pos_edge and one stable counting sort by j per band (bands in parallel)
+    // gives the order in O(m_pos + bands * n)
     P.order.resize((size_t)mp);
     {
         const int32_t* ii = prob->ind_i; const int32_t* jj = prob->ind_j; const int32_t* pe = s->pos_edge.data();
         const int64_t n = prob->n, nb = n / band + 1;
-        std::vector<int32_t> tmp((size_t)mp), cnt((size_t)std::max(n, nb) + 1, 0);
-        for (int64_t l = 0; l < mp; ++l) cnt[jj[pe[l]] + 1]++;
-        for (int64_t v = 0; v < n; ++v) cnt[v + 1] += cnt[v];
-        for (int64_t l = 0; l < mp; ++l) tmp[cnt[jj[pe[l]]]++] = (int32_t)l;
-        std::fill(cnt.begin(), cnt.end(), 0);
-        for (int64_t l = 0; l < mp; ++l) cnt[ii[pe[l]] / band + 1]++;
-        for (int64_t b = 0; b < nb; ++b) cnt[b + 1] += cnt[b];
-        for (int64_t t = 0; t < mp; ++t) { const int32_t l = tmp[t]; P.order[cnt[ii[pe[l]] / band]++] = l; }
+        std::vector<int64_t> bstart((size_t)nb + 1, mp);       // first position of every band in pos_edge
+        {
+            int64_t l = 0;
+            for (int64_t b = 0; b <= nb; ++b) {
+                while (l < mp && ii[pe[l]] / band < b) ++l;
+                bstart[b] = l;
+            }
+        }
+        host_parallel(nb, [&](int64_t b0, int64_t b1) {
+            std::vector<int32_t> cnt((size_t)n + 1);
+            for (int64_t b = b0; b < b1; ++b) {
+                const int64_t lo = bstart[b], hi = bstart[b + 1];
+                if (lo == hi) continue;
+                std::fill(cnt.begin(), cnt.end(), 0);
+                for (int64_t l = lo; l < hi; ++l) cnt[jj[pe[l]] + 1]++;
+                for (int64_t v = 0; v < n; ++v) cnt[v + 1] += cnt[v];
+                for (int64_t l = lo; l < hi; ++l) P.order[lo + cnt[jj[pe[l]]]++] = (int32_t)l;
+            }
+        }, mp >= (1 << 18) ? 1 : nb + 1);          // small problems: one thread
     }
     P.cum2.assign((size_t)mp + 1, 0);
     for (int64_t q = 0; q < mp; ++q) {
@@ -1273,13 +1317,17 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     const int64_t mcl = h->cyc_hi - h->cyc_lo;            // local cycles
     const int64_t nsl = h->seg_hi - h->seg_lo;            // local segments
 
+    // A structure built on this device brings its CSR, edge tables and sampled k along in HBM: the
+    // per-edge tables and the cycle layout are then made by kernels and the host only plans.
+    const bool dev_cycles = s->dev == h->device && s->d_k != nullptr;
     // CSR adjacency (neighbours ascending; single pass because Ind is sorted by (i,j))
-    std::vector<int32_t> rowptr((size_t)n + 1, 0), adj((size_t)2 * m), adj_eid((size_t)2 * m);
-    for (int64_t e = 0; e < m; ++e) { rowptr[prob->ind_i[e] + 1]++; rowptr[prob->ind_j[e] + 1]++; }
-    for (int64_t v = 0; v < n; ++v) rowptr[v + 1] += rowptr[v];
-    // slot of every edge in its two endpoint rows (eslot: smaller endpoint, for S_vec extraction)
-    std::vector<int32_t> eslot((size_t)m), eslot_b((size_t)m);
-    {
+    std::vector<int32_t> rowptr, adj, adj_eid, eslot, eslot_b;
+    if (!dev_cycles) {
+        rowptr.assign((size_t)n + 1, 0); adj.resize((size_t)2 * m); adj_eid.resize((size_t)2 * m);
+        for (int64_t e = 0; e < m; ++e) { rowptr[prob->ind_i[e] + 1]++; rowptr[prob->ind_j[e] + 1]++; }
+        for (int64_t v = 0; v < n; ++v) rowptr[v + 1] += rowptr[v];
+        // slot of every edge in its two endpoint rows (eslot: smaller endpoint, for S_vec extraction)
+        eslot.resize((size_t)m); eslot_b.resize((size_t)m);
         std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
         for (int64_t e = 0; e < m; ++e) {
             const int32_t i = prob->ind_i[e], j = prob->ind_j[e];
@@ -1290,21 +1338,23 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     }
     lap("csr+eslot");
     std::vector<int32_t> cum_loc((size_t)mp + 1), src_start((size_t)mp), pos_edge2((size_t)mp), devpos((size_t)m, -1);
-    std::vector<EdgeInfo> einfo((size_t)mp);
+    std::vector<EdgeInfo> einfo;
     for (int64_t q = 0; q <= mp; ++q) cum_loc[q] = cum2[q] - (int32_t)h->cyc_lo;   // local cycle numbering (meaningful for owned segments)
     for (int64_t q = 0; q < mp; ++q) {
         const int32_t l = P.order[q], e = s->pos_edge[l];
         src_start[q] = (int32_t)s->cum_ind[l];
         pos_edge2[q] = e; devpos[e] = (int32_t)q;
     }
-    host_parallel(mp, [&](int64_t a, int64_t b) {
-        for (int64_t q = a; q < b; ++q) {
-            const int32_t e = pos_edge2[q], i = prob->ind_i[e], j = prob->ind_j[e];
-            einfo[q] = EdgeInfo{rowptr[i], rowptr[j], eslot[e], eslot_b[e]};
-        }
-    });
+    if (!dev_cycles) {
+        einfo.resize((size_t)mp);
+        host_parallel(mp, [&](int64_t a, int64_t b) {
+            for (int64_t q = a; q < b; ++q) {
+                const int32_t e = pos_edge2[q], i = prob->ind_i[e], j = prob->ind_j[e];
+                einfo[q] = EdgeInfo{rowptr[i], rowptr[j], eslot[e], eslot_b[e]};
+            }
+        });
+    }
     lap("einfo");
-    const bool dev_cycles = s->dev == h->device && s->d_k != nullptr;   // structure built on this device
     std::vector<uint32_t> kf; std::vector<uint8_t> seg_perm; std::vector<uint32_t> seg_counts; std::vector<int2> adj_seg;
     if (!dev_cycles) {
         if ((rc = structure_ensure_host(const_cast<desc_structure*>(s)))) return rc;
@@ -1368,30 +1418,40 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     lap("alloc");
     int32_t *d_ii = nullptr, *d_jj = nullptr, *d_adj = nullptr, *d_adj_eid = nullptr, *d_pos_edge2 = nullptr;
     uint32_t* d_kf = nullptr; double* d_rij = nullptr;
-    if ((rc = dalloc(h, &d_ii, m))) return rc;
-    if ((rc = dalloc(h, &d_jj, m))) return rc;
-    if ((rc = dalloc(h, &d_adj, 2 * m))) return rc;
-    if ((rc = dalloc(h, &d_adj_eid, 2 * m))) return rc;
+    if (dev_cycles) {               // borrowed from the structure for the duration of this call
+        d_ii = s->d_ii; d_jj = s->d_jj; d_adj = s->d_adj; d_adj_eid = s->d_adj_eid;
+    } else {
+        if ((rc = dalloc(h, &d_ii, m))) return rc;
+        if ((rc = dalloc(h, &d_jj, m))) return rc;
+        if ((rc = dalloc(h, &d_adj, 2 * m))) return rc;
+        if ((rc = dalloc(h, &d_adj_eid, 2 * m))) return rc;
+        if ((rc = dalloc(h, &d_kf, mcl))) return rc;
+    }
     if ((rc = dalloc(h, &d_pos_edge2, mp))) return rc;
-    if (!dev_cycles && (rc = dalloc(h, &d_kf, mcl))) return rc;
     if ((rc = dalloc(h, &d_rij, 9 * (size_t)m))) return rc;
     std::vector<int32_t> rank_seg32(h->rank_seg.begin(), h->rank_seg.end());
     if ((rc = upload(h, h->d_cum, cum_loc.data(), (size_t)mp + 1))) return rc;
-    if ((rc = upload(h, h->d_einfo, einfo.data(), (size_t)mp))) return rc;
-    if ((rc = upload(h, h->d_rowptr, rowptr.data(), (size_t)n + 1))) return rc;
-    if (!dev_cycles && (rc = upload(h, h->d_adj_seg, adj_seg.data(), (size_t)2 * m))) return rc;
     if ((rc = upload(h, h->d_src_start, src_start.data(), (size_t)mp))) return rc;
-    if ((rc = upload(h, h->d_eslot, eslot.data(), (size_t)m))) return rc;
     if ((rc = upload(h, h->d_chunk_desc, chunk_desc.data(), chunk_desc.size()))) return rc;
     if ((rc = upload(h, h->d_rank_seg, rank_seg32.data(), rank_seg32.size()))) return rc;
-    if ((rc = upload(h, d_ii, prob->ind_i, (size_t)m))) return rc;
-    if ((rc = upload(h, d_jj, prob->ind_j, (size_t)m))) return rc;
-    if ((rc = upload(h, d_adj, adj.data(), (size_t)2 * m))) return rc;
-    if ((rc = upload(h, d_adj_eid, adj_eid.data(), (size_t)2 * m))) return rc;
     if ((rc = upload(h, d_pos_edge2, pos_edge2.data(), (size_t)mp))) return rc;
-    if (!dev_cycles && (rc = upload(h, d_kf, kf.data(), (size_t)mcl))) return rc;
-    if (!dev_cycles && (rc = upload(h, h->d_seg_perm, seg_perm.data(), (size_t)mcl))) return rc;
     if ((rc = upload(h, d_rij, prob->rij, 9 * (size_t)m))) return rc;
+    if (dev_cycles) {
+        DESC_HIP(hipMemcpyAsync(h->d_rowptr, s->d_rowptr, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToDevice, h->stream));
+        hipLaunchKernelGGL(k_edge_slots, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (m + 255) / 256))), dim3(256), 0, h->stream,
+                           d_ii, d_jj, s->d_rowptr, d_adj, d_pos_edge2, h->d_eslot, h->d_einfo, m, mp);
+    } else {
+        if ((rc = upload(h, h->d_einfo, einfo.data(), (size_t)mp))) return rc;
+        if ((rc = upload(h, h->d_rowptr, rowptr.data(), (size_t)n + 1))) return rc;
+        if ((rc = upload(h, h->d_adj_seg, adj_seg.data(), (size_t)2 * m))) return rc;
+        if ((rc = upload(h, h->d_eslot, eslot.data(), (size_t)m))) return rc;
+        if ((rc = upload(h, d_ii, prob->ind_i, (size_t)m))) return rc;
+        if ((rc = upload(h, d_jj, prob->ind_j, (size_t)m))) return rc;
+        if ((rc = upload(h, d_adj, adj.data(), (size_t)2 * m))) return rc;
+        if ((rc = upload(h, d_adj_eid, adj_eid.data(), (size_t)2 * m))) return rc;
+        if ((rc = upload(h, d_kf, kf.data(), (size_t)mcl))) return rc;
+        if ((rc = upload(h, h->d_seg_perm, seg_perm.data(), (size_t)mcl))) return rc;
+    }
     DESC_HIP(hipStreamSynchronize(h->stream));
     h->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     lap("upload");
@@ -1437,7 +1497,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
         if (nsl > 0) {
             int g = (int)std::min<int64_t>(4096, (nsl + 3) / 4);
             hipLaunchKernelGGL(k_layout_node_dev, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo,
-                               d_pos_edge2 + h->seg_lo, d_ii, d_jj, s->d_k, s->d_ikj, s->d_jki, h->d_rowptr, d_adj, d_adj_eid, d_rij,
+                               d_pos_edge2 + h->seg_lo, d_ii, d_jj, s->d_k, s->d_poe, s->d_tau, s->d_ktau, (uint64_t)s->seed, h->d_rowptr, d_adj, d_adj_eid, d_rij,
                                h->d_pk, h->d_S0, h->d_seg_perm, d_counts + h->seg_lo, (int)nsl);
         }
         hipLaunchKernelGGL(k_adj_seg, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256))), dim3(256), 0, h->stream,
@@ -1452,7 +1512,8 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     h->ms_cycle_d = ms;
     lap("layout kernels");
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    dfree(h, d_ii); dfree(h, d_jj); dfree(h, d_adj); dfree(h, d_adj_eid); dfree(h, d_pos_edge2); dfree(h, d_kf); dfree(h, d_rij);
+    if (!dev_cycles) { dfree(h, d_ii); dfree(h, d_jj); dfree(h, d_adj); dfree(h, d_adj_eid); dfree(h, d_kf); }
+    dfree(h, d_pos_edge2); dfree(h, d_rij);
     if (e != hipSuccess) return fail(DESC_ERR_HIP, "k_layout_node: %s", hipGetErrorString(e));
     return DESC_OK;
 }
@@ -1513,7 +1574,8 @@ int desc_pgd_create_shard(const desc_problem* prob, const desc_structure* s, int
     if (!h) return fail(DESC_ERR_INVALID, "out of host memory");
     h->device = device; h->rank = rank; h->world = world;
     h->n = prob->n; h->m = s->m; h->m_pos = s->m_pos; h->m_cycle = s->m_cycle; h->max_cnt = s->max_cnt; h->n_sample = s->n_sample;
-    {
+    if (s->max_deg > 0) h->max_deg = s->max_deg;          // device-built structures carry it
+    else {
         std::vector<int32_t> deg((size_t)h->n, 0);
         for (int64_t e = 0; e < h->m; ++e) { deg[prob->ind_i[e]]++; deg[prob->ind_j[e]]++; }
         for (int32_t d : deg) h->max_deg = std::max(h->max_deg, d);

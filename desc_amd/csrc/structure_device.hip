@@ -13,7 +13,9 @@
 // once per edge; every lane counts how many keys precede its own).
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "device_utils.h"
@@ -22,17 +24,6 @@ namespace desc {
 namespace {
 
 constexpr int MAX_CODEG_LDS = 1024;      // common neighbours staged per edge when sampling
-
-__device__ __forceinline__ uint64_t d_mix64(uint64_t x) {
-    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
-    x ^= x >> 27; x *= 0x94D049BB133111EBull;
-    x ^= x >> 31;
-    return x;
-}
-__device__ __forceinline__ uint64_t d_sample_key(uint64_t seed, uint64_t edge, uint64_t k) {
-    const uint64_t a = d_mix64(seed ^ ((edge + 1) * 0x9E3779B97F4A7C15ull));
-    return d_mix64(a ^ ((k + 1) * 0xD1B54A32D192ED03ull));
-}
 
 // inclusive prefix sum of an int over the 64 lanes of a wave
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
@@ -51,16 +42,14 @@ __global__ void k_bitmaps(const int32_t* rowptr, const int32_t* adj, unsigned lo
             atomicOr(&row[adj[t] >> 6], 1ull << (adj[t] & 63));
     }
 }
-// rank[v][w] = number of neighbours of v in words < w
-__global__ void k_rank(const unsigned long long* bits, uint32_t* rank, int n, int words) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n) return;
-    uint32_t acc = 0;
-    for (int w = 0; w < words; ++w) { rank[(size_t)v * words + w] = acc; acc += (uint32_t)__popcll(bits[(size_t)v * words + w]); }
-}
-// codegree of every edge: popcount(row_i & row_j), one wave per edge
+// codegree of every edge: popcount(row_i & row_j), one wave per edge; plus the histogram of the
+// codegrees (median and maximum on the host in O(n)): per-workgroup bins in LDS when they fit
+constexpr int HIST_LDS_BINS = 8192;
 __global__ __launch_bounds__(256) void k_codeg(const int32_t* ind_i, const int32_t* ind_j, const unsigned long long* bits,
-                                               int32_t* codeg, int64_t m, int words) {
+                                               int32_t* codeg, int32_t* hist, int64_t m, int words, int nbins) {
+    __shared__ int32_t lh[HIST_LDS_BINS];
+    const bool local = nbins <= HIST_LDS_BINS;
+    if (local) { for (int t = threadIdx.x; t < nbins; t += 256) lh[t] = 0; __syncthreads(); }
     const int lane = threadIdx.x & 63;
     const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
     for (int64_t e = wid; e < m; e += nw) {
@@ -69,56 +58,53 @@ __global__ __launch_bounds__(256) void k_codeg(const int32_t* ind_i, const int32
         int c = 0;
         for (int w = lane; w < words; w += 64) c += __popcll(a[w] & b[w]);
         c = wave_incl_scan(c, lane);
-        if (lane == 63) codeg[e] = c;
+        if (lane == 63) { codeg[e] = c; atomicAdd(local ? &lh[c] : &hist[c], 1); }
+    }
+    if (local) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < nbins; t += 256) if (lh[t]) atomicAdd(&hist[t], lh[t]);
     }
 }
 
-// Cycle lists (DESC_PGD.m:79-96): one wave per edge-with-cycles.
+// Cycle lists (DESC_PGD.m:79-96): one wave per edge-with-cycles.  Writes the sampled third
+// vertices (ascending) and the edge's selection threshold: a common neighbour k of edge e is
+// kept iff (key(e,k), k) <= (tau, ktau) lexicographically (all ones when codeg < n_sample).
 __global__ __launch_bounds__(256) void k_fill_cycles(const int32_t* pos_edge, const int32_t* cum, const int32_t* ind_i,
-                                                     const int32_t* ind_j, const unsigned long long* bits, const uint32_t* rank,
-                                                     const int32_t* rowptr, const int32_t* adj_eid, int32_t* kk, int32_t* e_jk,
-                                                     int32_t* e_ki, int64_t m_pos, int words, int n_sample, uint64_t seed,
-                                                     int lds_cap) {
-    extern __shared__ unsigned long long smem[];      // per wave: keys[lds_cap] then (k, ejk, eki)[lds_cap] as int32
+                                                     const int32_t* ind_j, const unsigned long long* bits, int32_t* kk,
+                                                     unsigned long long* tau, int32_t* ktau, int64_t m_pos, int words,
+                                                     int n_sample, uint64_t seed, int lds_cap) {
+    extern __shared__ unsigned long long smem[];      // per wave: keys[lds_cap] then k[lds_cap] as int32
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned long long* keys = smem + (size_t)wv * lds_cap;
-    int32_t* tri = (int32_t*)(smem + (size_t)4 * lds_cap) + (size_t)wv * 3 * lds_cap;
+    int32_t* ks = (int32_t*)(smem + (size_t)4 * lds_cap) + (size_t)wv * lds_cap;
     const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
     for (int64_t l = wid; l < m_pos; l += nw) {
         const int e = pos_edge[l], i = ind_i[e], j = ind_j[e];
-        const int base = cum[l], cnt = cum[l + 1] - base;
+        const int base = cum[l];
         const unsigned long long* a = bits + (size_t)i * words;
         const unsigned long long* b = bits + (size_t)j * words;
-        const uint32_t* ra = rank + (size_t)i * words;
-        const uint32_t* rb = rank + (size_t)j * words;
-        const int r0i = rowptr[i], r0j = rowptr[j];
         // enumerate the common neighbours in ascending order; `run` = how many precede this word
         int run = 0;
-        bool sampling = false;
         for (int w0 = 0; w0 < words; w0 += 64) {
             const int w = w0 + lane;
-            unsigned long long x = 0, aw = 0, bw = 0;
-            if (w < words) { aw = a[w]; bw = b[w]; x = aw & bw; }
+            unsigned long long x = 0;
+            if (w < words) x = a[w] & b[w];
             const int pc = __popcll(x);
             const int incl = wave_incl_scan(pc, lane);
             int pos = run + incl - pc;
             run += __shfl(incl, 63, 64);
             while (x) {
-                const int bit = __ffsll((long long)x) - 1;
-                const unsigned long long below = (1ull << bit) - 1ull;
-                const int k = w * 64 + bit;
-                const int eki = adj_eid[r0i + ra[w] + __popcll(aw & below)];
-                const int ejk = adj_eid[r0j + rb[w] + __popcll(bw & below)];
-                if (pos < lds_cap) { tri[3 * pos] = k; tri[3 * pos + 1] = ejk; tri[3 * pos + 2] = eki; keys[pos] = d_sample_key(seed, (uint64_t)e, (uint64_t)k); }
+                const int k = w * 64 + __ffsll((long long)x) - 1;
+                if (pos < lds_cap) { ks[pos] = k; keys[pos] = d_sample_key(seed, (uint64_t)e, (uint64_t)k); }
                 ++pos;
                 x &= x - 1;
             }
         }
         const int cd = run;                           // codegree
-        sampling = cd >= n_sample;                    // DESC_PGD.m:83 (>=)
         __builtin_amdgcn_wave_barrier();
-        if (!sampling) {
-            for (int t = lane; t < cd; t += 64) { kk[base + t] = tri[3 * t]; e_jk[base + t] = tri[3 * t + 1]; e_ki[base + t] = tri[3 * t + 2]; }
+        if (cd < n_sample) {                          // DESC_PGD.m:83 samples iff codeg >= n_sample
+            for (int t = lane; t < cd; t += 64) kk[base + t] = ks[t];
+            if (lane == 0) { tau[l] = ~0ull; ktau[l] = 0x7FFFFFFF; }
         } else {
             // keep the n_sample smallest (key, k); common neighbours are distinct, positions ascend with k
             int outbase = 0;
@@ -130,17 +116,38 @@ __global__ __launch_bounds__(256) void k_fill_cycles(const int32_t* pos_edge, co
                     int rk = 0;
                     for (int u = 0; u < cd; ++u) { const unsigned long long ku = keys[u]; rk += (ku < kt) || (ku == kt && u < t); }
                     sel = rk < n_sample;
+                    if (rk == n_sample - 1) { tau[l] = kt; ktau[l] = ks[t]; }     // the last one kept
                 }
                 const unsigned long long mk = __ballot(sel);
-                if (sel) {
-                    const int o = base + outbase + __popcll(mk & ((1ull << lane) - 1ull));
-                    kk[o] = tri[3 * t]; e_jk[o] = tri[3 * t + 1]; e_ki[o] = tri[3 * t + 2];
-                }
+                if (sel) kk[base + outbase + __popcll(mk & ((1ull << lane) - 1ull))] = ks[t];
                 outbase += __popcll(mk);
             }
         }
-        (void)cnt;
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// e_jk / e_ki of every cycle (DESC_PGD.m:87-88) from the sampled k: binary search of k in the CSR
+// rows of j and i.  Only run when the full index structure is exported (desc_structure_get) or
+// the gather layout needs it.
+__global__ __launch_bounds__(256) void k_cycle_edges(const int32_t* pos_edge, const int32_t* cum, const int32_t* ind_i,
+                                                     const int32_t* ind_j, const int32_t* kk, const int32_t* rowptr,
+                                                     const int32_t* adj, const int32_t* adj_eid, int32_t* e_jk, int32_t* e_ki,
+                                                     int64_t m_pos) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t l = wid; l < m_pos; l += nw) {
+        const int e = pos_edge[l], i = ind_i[e], j = ind_j[e];
+        const int ri = rowptr[i], di = rowptr[i + 1] - ri, rj = rowptr[j], dj = rowptr[j + 1] - rj;
+        for (int c = cum[l] + lane; c < cum[l + 1]; c += 64) {
+            const int k = kk[c];
+            int lo = 0, hi = di;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (adj[ri + mid] < k) lo = mid + 1; else hi = mid; }
+            e_ki[c] = adj_eid[ri + lo];
+            lo = 0; hi = dj;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (adj[rj + mid] < k) lo = mid + 1; else hi = mid; }
+            e_jk[c] = adj_eid[rj + lo];
+        }
     }
 }
 
@@ -183,20 +190,31 @@ struct DevBuf {
 
 int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint64_t seed, int32_t device, desc_structure* s) {
     auto t0 = std::chrono::steady_clock::now();
+    auto t_lap = t0;
+    const char* tenv = getenv("DESC_DEBUG_TIMING");
+    const bool timing = tenv && atoi(tenv) != 0;
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        (void)hipDeviceSynchronize();
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[desc_amd] structure_device %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_lap).count());
+        t_lap = now;
+    };
     const int64_t n = prob->n, m = prob->m;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DESC_ERR_HIP, "no HIP device visible for DESC_BUILD_DEVICE");
     if (device < 0 || device >= ndev) return fail(DESC_ERR_INVALID, "device %d out of range", device);
     const int64_t words = (n + 63) / 64;
-    if ((double)n * (double)words * 12.0 > 64.0 * 1073741824.0)
+    if ((double)n * (double)words * 8.0 > 64.0 * 1073741824.0)
         return fail(DESC_ERR_TOO_LARGE, "adjacency bitmaps of n = %lld nodes do not fit the device-build budget; use DESC_BUILD_HOST", (long long)n);
     DESC_HIP(hipSetDevice(device));
-    s->n = n; s->m = m;
+    s->n = n; s->m = m; s->dev = device; s->seed = seed;
 
     // CSR on the host (one pass; Ind is sorted by (i,j), so rows come out ascending)
     std::vector<int32_t> rowptr((size_t)n + 1, 0), adj((size_t)2 * m), adj_eid((size_t)2 * m);
     for (int64_t e = 0; e < m; ++e) { rowptr[prob->ind_i[e] + 1]++; rowptr[prob->ind_j[e] + 1]++; }
-    for (int64_t v = 0; v < n; ++v) rowptr[v + 1] += rowptr[v];
+    s->max_deg = 0;
+    for (int64_t v = 0; v < n; ++v) { s->max_deg = std::max(s->max_deg, rowptr[v + 1]); rowptr[v + 1] += rowptr[v]; }
     {
         std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
         for (int64_t e = 0; e < m; ++e) {
@@ -205,104 +223,127 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
             adj[fill[j]] = i; adj_eid[fill[j]++] = (int32_t)e;
         }
     }
+    lap("host csr");
+    // device arrays that outlive this call are owned by the structure object (structure_free_device)
+    auto keep = [&](auto** out, size_t count) -> int {
+        void* q = nullptr;
+        DESC_HIP(hipMalloc(&q, sizeof(**out) * (count ? count : 1)));
+        *out = (std::remove_reference_t<decltype(*out)>)q;
+        return DESC_OK;
+    };
     DevBuf D;
     int rc;
-    int32_t *d_rowptr, *d_adj, *d_adj_eid, *d_ii, *d_jj, *d_codeg;
-    unsigned long long* d_bits; uint32_t* d_rank;
-    if ((rc = D.alloc(&d_rowptr, n + 1)) || (rc = D.alloc(&d_adj, 2 * m)) || (rc = D.alloc(&d_adj_eid, 2 * m)) ||
-        (rc = D.alloc(&d_ii, m)) || (rc = D.alloc(&d_jj, m)) || (rc = D.alloc(&d_codeg, m)) ||
-        (rc = D.alloc(&d_bits, (size_t)n * words)) || (rc = D.alloc(&d_rank, (size_t)n * words))) return rc;
-    DESC_HIP(hipMemcpy(d_rowptr, rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
+    int32_t *d_codeg, *d_hist;
+    unsigned long long* d_bits;
+    if ((rc = keep(&s->d_rowptr, n + 1)) || (rc = keep(&s->d_adj, 2 * m)) || (rc = keep(&s->d_adj_eid, 2 * m)) ||
+        (rc = keep(&s->d_ii, m)) || (rc = keep(&s->d_jj, m)) || (rc = D.alloc(&d_codeg, m)) || (rc = D.alloc(&d_hist, n + 1)) ||
+        (rc = D.alloc(&d_bits, (size_t)n * words))) return rc;
+    DESC_HIP(hipMemcpy(s->d_rowptr, rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
     if (m) {
-        DESC_HIP(hipMemcpy(d_adj, adj.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_adj_eid, adj_eid.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_ii, prob->ind_i, sizeof(int32_t) * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_jj, prob->ind_j, sizeof(int32_t) * m, hipMemcpyHostToDevice));
+        DESC_HIP(hipMemcpy(s->d_adj, adj.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
+        DESC_HIP(hipMemcpy(s->d_adj_eid, adj_eid.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
+        DESC_HIP(hipMemcpy(s->d_ii, prob->ind_i, sizeof(int32_t) * m, hipMemcpyHostToDevice));
+        DESC_HIP(hipMemcpy(s->d_jj, prob->ind_j, sizeof(int32_t) * m, hipMemcpyHostToDevice));
     }
+    lap("alloc+upload");
     DESC_HIP(hipMemset(d_bits, 0, sizeof(unsigned long long) * (size_t)n * words));
-    if (n > 0) {
-        hipLaunchKernelGGL(k_bitmaps, dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, 0, d_rowptr, d_adj, d_bits, (int)n, (int)words);
-        hipLaunchKernelGGL(k_rank, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_bits, d_rank, (int)n, (int)words);
-    }
+    DESC_HIP(hipMemset(d_hist, 0, sizeof(int32_t) * (n + 1)));
+    if (n > 0)
+        hipLaunchKernelGGL(k_bitmaps, dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, 0, s->d_rowptr, s->d_adj, d_bits, (int)n, (int)words);
     if (m > 0)
-        hipLaunchKernelGGL(k_codeg, dim3((unsigned)std::min<int64_t>(8192, (m + 3) / 4)), dim3(256), 0, 0, d_ii, d_jj, d_bits, d_codeg, m, (int)words);
+        hipLaunchKernelGGL(k_codeg, dim3((unsigned)std::min<int64_t>(2048, (m + 3) / 4)), dim3(256), 0, 0, s->d_ii, s->d_jj, d_bits, d_codeg, d_hist, m, (int)words, (int)(n + 1));
     DESC_HIP(hipGetLastError());
     s->codeg.assign((size_t)m, 0);
+    std::vector<int32_t> hist((size_t)n + 1, 0);
     if (m) DESC_HIP(hipMemcpy(s->codeg.data(), d_codeg, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+    DESC_HIP(hipMemcpy(hist.data(), d_hist, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost));
+    lap("bitmaps+codeg+d2h");
 
-    // edges with cycles, median, n_sample, cum_ind  (DESC_PGD.m:36-51) -- O(m) on the host
-    s->pos_edge.clear();
-    std::vector<int32_t> pos_cd;
+    // edges with cycles, median, n_sample, cum_ind  (DESC_PGD.m:36-51).  The median of the positive
+    // codegrees comes from their histogram (codeg <= n-2): O(n) instead of a selection over m values.
+    int64_t mp = 0;
     int32_t max_codeg = 0;
-    for (int64_t e = 0; e < m; ++e) if (s->codeg[e] > 0) { s->pos_edge.push_back((int32_t)e); pos_cd.push_back(s->codeg[e]); max_codeg = std::max(max_codeg, s->codeg[e]); }
-    s->m_pos = (int64_t)s->pos_edge.size();
+    for (int64_t c = 1; c <= n; ++c) if (hist[c]) { mp += hist[c]; max_codeg = (int32_t)c; }
+    s->m_pos = mp;
     int32_t n_sample = n_sample_min;
-    if (s->m_pos > 0) {
-        const size_t h = pos_cd.size() / 2;
-        std::nth_element(pos_cd.begin(), pos_cd.begin() + h, pos_cd.end());
-        double med = pos_cd[h];
-        if ((pos_cd.size() & 1) == 0) med = 0.5 * ((double)*std::max_element(pos_cd.begin(), pos_cd.begin() + h) + med);
+    if (mp > 0) {
+        auto kth = [&](int64_t r) {        // r-th smallest positive codegree, r = 0-based
+            int64_t acc = 0;
+            for (int64_t c = 1; c <= n; ++c) { acc += hist[c]; if (acc > r) return (double)c; }
+            return (double)max_codeg;
+        };
+        const double med = (mp & 1) ? kth(mp / 2) : 0.5 * (kth(mp / 2 - 1) + kth(mp / 2));     // MATLAB median (:43)
         n_sample = std::max(n_sample_min, (int32_t)std::ceil(med / 4.0));
     }
     s->n_sample = n_sample;
-    s->cum_ind.assign((size_t)s->m_pos + 1, 0);
-    s->max_cnt = 0;
-    for (int64_t l = 0; l < s->m_pos; ++l) {
-        const int32_t cnt = std::min(s->codeg[s->pos_edge[l]], n_sample);
-        s->cum_ind[l + 1] = s->cum_ind[l] + cnt;
-        s->max_cnt = std::max(s->max_cnt, cnt);
+    s->pos_edge.resize((size_t)mp);
+    s->cum_ind.assign((size_t)mp + 1, 0);
+    s->max_cnt = std::min(max_codeg, n_sample);
+    std::vector<int32_t> cum32((size_t)mp + 1, 0), pos_of_edge((size_t)std::max<int64_t>(m, 1), -1);
+    {
+        int64_t l = 0;
+        for (int64_t e = 0; e < m; ++e) {
+            const int32_t cd = s->codeg[e];
+            if (cd <= 0) continue;
+            s->pos_edge[l] = (int32_t)e; pos_of_edge[e] = (int32_t)l;
+            s->cum_ind[l + 1] = s->cum_ind[l] + std::min(cd, n_sample);
+            ++l;
+        }
     }
-    s->m_cycle = s->cum_ind[s->m_pos];
+    s->m_cycle = s->cum_ind[mp];
     if (s->m_cycle >= (1ll << 31) - 1) return fail(DESC_ERR_TOO_LARGE, "m_cycle = %lld exceeds 2^31-2", (long long)s->m_cycle);
     if (max_codeg > MAX_CODEG_LDS)
         return fail(DESC_ERR_TOO_LARGE, "an edge has %d common neighbours (> %d): use DESC_BUILD_HOST", max_codeg, MAX_CODEG_LDS);
-    const int64_t mp = s->m_pos, mc = s->m_cycle;
+    for (int64_t l = 0; l <= mp; ++l) cum32[l] = (int32_t)s->cum_ind[l];
+    lap("host median/cum");
+    const int64_t mc = s->m_cycle;
     s->k.clear(); s->e_jk.clear(); s->e_ki.clear(); s->ikj.clear(); s->jki.clear();
     s->host_cycles = (mp == 0);                       // per-cycle arrays stay in HBM until somebody asks for them
     if (mp > 0) {
-        std::vector<int32_t> cum32((size_t)mp + 1), pos_of_edge((size_t)m, -1);
-        for (int64_t l = 0; l <= mp; ++l) cum32[l] = (int32_t)s->cum_ind[l];
-        for (int64_t l = 0; l < mp; ++l) pos_of_edge[s->pos_edge[l]] = (int32_t)l;
-        int32_t *d_pos, *d_cum, *d_poe, *d_k, *d_ejk, *d_eki, *d_ikj, *d_jki;
-        if ((rc = D.alloc(&d_pos, mp)) || (rc = D.alloc(&d_cum, mp + 1)) || (rc = D.alloc(&d_poe, m))) return rc;
-        // the five per-cycle arrays outlive this call: owned by the structure object
-        s->dev = device;
-        DESC_HIP(hipMalloc((void**)&s->d_k, sizeof(int32_t) * mc));
-        DESC_HIP(hipMalloc((void**)&s->d_ejk, sizeof(int32_t) * mc));
-        DESC_HIP(hipMalloc((void**)&s->d_eki, sizeof(int32_t) * mc));
-        DESC_HIP(hipMalloc((void**)&s->d_ikj, sizeof(int32_t) * mc));
-        DESC_HIP(hipMalloc((void**)&s->d_jki, sizeof(int32_t) * mc));
-        d_k = s->d_k; d_ejk = s->d_ejk; d_eki = s->d_eki; d_ikj = s->d_ikj; d_jki = s->d_jki;
-        DESC_HIP(hipMemcpy(d_pos, s->pos_edge.data(), sizeof(int32_t) * mp, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_cum, cum32.data(), sizeof(int32_t) * (mp + 1), hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_poe, pos_of_edge.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
-        // LDS per wave: keys (8 B) + 3 int32 per staged common neighbour
+        if ((rc = keep(&s->d_pos, mp)) || (rc = keep(&s->d_cum, mp + 1)) || (rc = keep(&s->d_poe, m)) || (rc = keep(&s->d_k, mc)) ||
+            (rc = keep(&s->d_tau, mp)) || (rc = keep(&s->d_ktau, mp))) return rc;
+        DESC_HIP(hipMemcpy(s->d_pos, s->pos_edge.data(), sizeof(int32_t) * mp, hipMemcpyHostToDevice));
+        DESC_HIP(hipMemcpy(s->d_cum, cum32.data(), sizeof(int32_t) * (mp + 1), hipMemcpyHostToDevice));
+        DESC_HIP(hipMemcpy(s->d_poe, pos_of_edge.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
+        lap("alloc cycles+upload");
+        // LDS per wave: key (8 B) + k (4 B) per staged common neighbour
         int cap = 64;
         while (cap < max_codeg) cap <<= 1;
-        const size_t lds = (size_t)4 * cap * (8 + 12);
+        const size_t lds = (size_t)4 * cap * (8 + 4);
         if (lds > 64 * 1024)
             DESC_HIP(hipFuncSetAttribute((const void*)k_fill_cycles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const unsigned g = (unsigned)std::min<int64_t>(8192, (mp + 3) / 4);
-        hipLaunchKernelGGL(k_fill_cycles, dim3(g), dim3(256), lds, 0, d_pos, d_cum, d_ii, d_jj, d_bits, d_rank, d_rowptr, d_adj_eid,
-                           d_k, d_ejk, d_eki, mp, (int)words, (int)n_sample, seed, cap);
-        hipLaunchKernelGGL(k_mirror, dim3(g), dim3(256), 0, 0, d_pos, d_cum, d_poe, d_ii, d_jj, d_k, d_ejk, d_eki, d_ikj, d_jki, mp);
+        hipLaunchKernelGGL(k_fill_cycles, dim3(g), dim3(256), lds, 0, s->d_pos, s->d_cum, s->d_ii, s->d_jj, d_bits, s->d_k, s->d_tau, s->d_ktau,
+                           mp, (int)words, (int)n_sample, seed, cap);
         DESC_HIP(hipGetLastError());
         DESC_HIP(hipDeviceSynchronize());
+        lap("fill");
     }
     s->ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return DESC_OK;
 }
 
+// Full index structure of a device-built structure on the host: derive e_jk / e_ki and the mirror
+// maps on the device, copy everything down once.
 int structure_ensure_host(desc_structure* s) {
     if (!s || s->host_cycles) return DESC_OK;
-    const int64_t mc = s->m_cycle;
+    const int64_t mc = s->m_cycle, mp = s->m_pos;
     DESC_HIP(hipSetDevice(s->dev));
+    DevBuf D;
+    int rc;
+    int32_t *d_ejk, *d_eki, *d_ikj, *d_jki;
+    if ((rc = D.alloc(&d_ejk, mc)) || (rc = D.alloc(&d_eki, mc)) || (rc = D.alloc(&d_ikj, mc)) || (rc = D.alloc(&d_jki, mc))) return rc;
+    const unsigned g = (unsigned)std::min<int64_t>(8192, (mp + 3) / 4);
+    hipLaunchKernelGGL(k_cycle_edges, dim3(g), dim3(256), 0, 0, s->d_pos, s->d_cum, s->d_ii, s->d_jj, s->d_k, s->d_rowptr, s->d_adj, s->d_adj_eid,
+                       d_ejk, d_eki, mp);
+    hipLaunchKernelGGL(k_mirror, dim3(g), dim3(256), 0, 0, s->d_pos, s->d_cum, s->d_poe, s->d_ii, s->d_jj, s->d_k, d_ejk, d_eki, d_ikj, d_jki, mp);
+    DESC_HIP(hipGetLastError());
     s->k.resize((size_t)mc); s->e_jk.resize((size_t)mc); s->e_ki.resize((size_t)mc); s->ikj.resize((size_t)mc); s->jki.resize((size_t)mc);
     DESC_HIP(hipMemcpy(s->k.data(), s->d_k, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
-    DESC_HIP(hipMemcpy(s->e_jk.data(), s->d_ejk, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
-    DESC_HIP(hipMemcpy(s->e_ki.data(), s->d_eki, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
-    DESC_HIP(hipMemcpy(s->ikj.data(), s->d_ikj, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
-    DESC_HIP(hipMemcpy(s->jki.data(), s->d_jki, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
+    DESC_HIP(hipMemcpy(s->e_jk.data(), d_ejk, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
+    DESC_HIP(hipMemcpy(s->e_ki.data(), d_eki, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
+    DESC_HIP(hipMemcpy(s->ikj.data(), d_ikj, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
+    DESC_HIP(hipMemcpy(s->jki.data(), d_jki, sizeof(int32_t) * mc, hipMemcpyDeviceToHost));
     s->host_cycles = true;
     return DESC_OK;
 }
@@ -310,8 +351,11 @@ int structure_ensure_host(desc_structure* s) {
 void structure_free_device(desc_structure* s) {
     if (!s || s->dev < 0) return;
     (void)hipSetDevice(s->dev);
-    for (int32_t* q : {s->d_k, s->d_ejk, s->d_eki, s->d_ikj, s->d_jki}) if (q) (void)hipFree(q);
-    s->d_k = s->d_ejk = s->d_eki = s->d_ikj = s->d_jki = nullptr;
+    for (void* q : {(void*)s->d_k, (void*)s->d_tau, (void*)s->d_ktau, (void*)s->d_rowptr, (void*)s->d_adj, (void*)s->d_adj_eid, (void*)s->d_ii,
+                    (void*)s->d_jj, (void*)s->d_pos, (void*)s->d_cum, (void*)s->d_poe})
+        if (q) (void)hipFree(q);
+    s->d_k = nullptr; s->d_tau = nullptr; s->d_ktau = nullptr;
+    s->d_rowptr = s->d_adj = s->d_adj_eid = s->d_ii = s->d_jj = s->d_pos = s->d_cum = s->d_poe = nullptr;
     s->dev = -1;
 }
 
