@@ -50,6 +50,9 @@ struct desc_structure {
     int32_t *d_rowptr = nullptr, *d_adj = nullptr, *d_adj_eid = nullptr;   // n+1, 2m, 2m
     int32_t *d_ii = nullptr, *d_jj = nullptr;                              // m
     int32_t *d_pos = nullptr, *d_cum = nullptr, *d_poe = nullptr;          // m_pos, m_pos+1, m (edge -> index in pos_edge, -1)
+    unsigned long long* d_bits = nullptr;     // n x words adjacency bitmaps
+    uint32_t* d_rank = nullptr;               // n x words: neighbours of v in words < w (position of k in row v = rank + popcount below)
+    int32_t words = 0;
     int32_t max_deg = 0;
     uint64_t seed = 0;
 };

@@ -743,9 +743,9 @@ __global__ __launch_bounds__(256) void k_layout_node(const int32_t* cum, const i
 __global__ __launch_bounds__(256) void k_layout_node_dev(const int32_t* cum, const int32_t* src_start, const int32_t* pos_edge,
                                                          const int32_t* ind_i, const int32_t* ind_j, const int32_t* nat_k,
                                                          const int32_t* poe, const unsigned long long* tau, const int32_t* ktau,
-                                                         uint64_t seed, const int32_t* rowptr, const int32_t* adj,
-                                                         const int32_t* adj_eid, const double* rij, uint32_t* pk, double* S0,
-                                                         uint8_t* seg_perm, uint32_t* seg_counts, int m_pos) {
+                                                         uint64_t seed, const int32_t* rowptr, const unsigned long long* bits,
+                                                         const uint32_t* rank, int words, const int32_t* adj_eid, const double* rij,
+                                                         uint32_t* pk, double* S0, uint8_t* seg_perm, uint32_t* seg_counts, int m_pos) {
     const int lane = threadIdx.x & 63;
     const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * 256) >> 6;
@@ -760,12 +760,11 @@ __global__ __launch_bounds__(256) void k_layout_node_dev(const int32_t* cum, con
         bool fi = false, fj = false;
         if (on) {
             k = nat_k[(int64_t)src + lane];
-            int lo = 0, hi = di;                                  // idx_i(k): position of k in row i
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (adj[ri + mid] < k) lo = mid + 1; else hi = mid; }
-            xi = min(lo, max(di - 1, 0));
-            lo = 0; hi = dj;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (adj[rj + mid] < k) lo = mid + 1; else hi = mid; }
-            xj = min(lo, max(dj - 1, 0));
+            // idx_i(k), idx_j(k): positions of k in rows i and j = rank of its bit in the adjacency bitmaps
+            const size_t wi = (size_t)i * words + (k >> 6), wj = (size_t)j * words + (k >> 6);
+            const unsigned long long below = (1ull << (k & 63)) - 1ull;
+            xi = min((int)(rank[wi] + __popcll(bits[wi] & below)), max(di - 1, 0));
+            xj = min((int)(rank[wj] + __popcll(bits[wj] & below)), max(dj - 1, 0));
             eik = adj_eid[ri + xi]; ejk = adj_eid[rj + xj];
             const int lik = poe[eik], ljk = poe[ejk];             // both edges lie on the triangle {i,j,k}: they have cycles
             if (lik >= 0) {
@@ -1497,7 +1496,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
         if (nsl > 0) {
             int g = (int)std::min<int64_t>(4096, (nsl + 3) / 4);
             hipLaunchKernelGGL(k_layout_node_dev, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo,
-                               d_pos_edge2 + h->seg_lo, d_ii, d_jj, s->d_k, s->d_poe, s->d_tau, s->d_ktau, (uint64_t)s->seed, h->d_rowptr, d_adj, d_adj_eid, d_rij,
+                               d_pos_edge2 + h->seg_lo, d_ii, d_jj, s->d_k, s->d_poe, s->d_tau, s->d_ktau, (uint64_t)s->seed, h->d_rowptr, s->d_bits, s->d_rank, (int)s->words, d_adj_eid, d_rij,
                                h->d_pk, h->d_S0, h->d_seg_perm, d_counts + h->seg_lo, (int)nsl);
         }
         hipLaunchKernelGGL(k_adj_seg, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256))), dim3(256), 0, h->stream,

@@ -42,6 +42,13 @@ __global__ void k_bitmaps(const int32_t* rowptr, const int32_t* adj, unsigned lo
             atomicOr(&row[adj[t] >> 6], 1ull << (adj[t] & 63));
     }
 }
+// rank[v][w] = number of neighbours of v in words < w
+__global__ void k_rank(const unsigned long long* bits, uint32_t* rank, int n, int words) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    uint32_t acc = 0;
+    for (int w = 0; w < words; ++w) { rank[(size_t)v * words + w] = acc; acc += (uint32_t)__popcll(bits[(size_t)v * words + w]); }
+}
 // codegree of every edge: popcount(row_i & row_j), one wave per edge; plus the histogram of the
 // codegrees (median and maximum on the host in O(n)): per-workgroup bins in LDS when they fit
 constexpr int HIST_LDS_BINS = 8192;
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(256) void k_codeg(const int32_t* ind_i, const int32
 __global__ __launch_bounds__(256) void k_fill_cycles(const int32_t* pos_edge, const int32_t* cum, const int32_t* ind_i,
                                                      const int32_t* ind_j, const unsigned long long* bits, int32_t* kk,
                                                      unsigned long long* tau, int32_t* ktau, int64_t m_pos, int words,
-                                                     int n_sample, uint64_t seed, int lds_cap) {
+                                                     int n_sample, uint64_t seed, int lds_cap, int exact_only) {
     extern __shared__ unsigned long long smem[];      // per wave: keys[lds_cap] then k[lds_cap] as int32
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned long long* keys = smem + (size_t)wv * lds_cap;
@@ -106,21 +113,49 @@ __global__ __launch_bounds__(256) void k_fill_cycles(const int32_t* pos_edge, co
             for (int t = lane; t < cd; t += 64) kk[base + t] = ks[t];
             if (lane == 0) { tau[l] = ~0ull; ktau[l] = 0x7FFFFFFF; }
         } else {
-            // keep the n_sample smallest (key, k); common neighbours are distinct, positions ascend with k
-            int outbase = 0;
-            for (int t0 = 0; t0 < cd; t0 += 64) {
-                const int t = t0 + lane;
-                bool sel = false;
-                if (t < cd) {
-                    const unsigned long long kt = keys[t];
-                    int rk = 0;
-                    for (int u = 0; u < cd; ++u) { const unsigned long long ku = keys[u]; rk += (ku < kt) || (ku == kt && u < t); }
-                    sel = rk < n_sample;
-                    if (rk == n_sample - 1) { tau[l] = kt; ktau[l] = ks[t]; }     // the last one kept
+            // Keep the n_sample smallest keys.  A separator g with exactly n_sample keys <= g is found
+            // by bisection on the key VALUE (keys are uniform 64-bit hashes: the first probe is the
+            // expected quantile, ~log2(cd) probes follow; one probe = one ballot pass over the keys).
+            unsigned long long lo = 0, hi = ~0ull, g = ~0ull;
+            bool have_lo = false, found = (cd == n_sample) && !exact_only;
+            if (!found) g = (unsigned long long)((double)n_sample / (double)cd * 18446744073709549568.0);
+            for (int it = 0; !found && !exact_only && it < 96; ++it) {
+                int c = 0;
+                for (int t0 = 0; t0 < cd; t0 += 64) { const int t = t0 + lane; c += __popcll(__ballot(t < cd && keys[t] <= g)); }
+                if (c == n_sample) { found = true; break; }
+                if (c < n_sample) { lo = g; have_lo = true; } else hi = g;
+                const unsigned long long b = have_lo ? lo : 0ull;
+                if (hi - b <= 1ull) break;                       // no value left in between: duplicate keys straddle the cut
+                g = b + (hi - b) / 2ull;
+            }
+            if (found) {
+                int outbase = 0;
+                for (int t0 = 0; t0 < cd; t0 += 64) {
+                    const int t = t0 + lane;
+                    const bool sel = t < cd && keys[t] <= g;
+                    const unsigned long long mk = __ballot(sel);
+                    if (sel) kk[base + outbase + __popcll(mk & ((1ull << lane) - 1ull))] = ks[t];
+                    outbase += __popcll(mk);
                 }
-                const unsigned long long mk = __ballot(sel);
-                if (sel) kk[base + outbase + __popcll(mk & ((1ull << lane) - 1ull))] = ks[t];
-                outbase += __popcll(mk);
+                if (lane == 0) { tau[l] = g; ktau[l] = 0x7FFFFFFF; }
+            } else {
+                // duplicate keys at the cut (probability ~1e-14 per edge): exact ranking of (key, k) pairs;
+                // common neighbours are distinct, positions ascend with k
+                int outbase = 0;
+                for (int t0 = 0; t0 < cd; t0 += 64) {
+                    const int t = t0 + lane;
+                    bool sel = false;
+                    if (t < cd) {
+                        const unsigned long long kt = keys[t];
+                        int rk = 0;
+                        for (int u = 0; u < cd; ++u) { const unsigned long long ku = keys[u]; rk += (ku < kt) || (ku == kt && u < t); }
+                        sel = rk < n_sample;
+                        if (rk == n_sample - 1) { tau[l] = kt; ktau[l] = ks[t]; }     // the last one kept
+                    }
+                    const unsigned long long mk = __ballot(sel);
+                    if (sel) kk[base + outbase + __popcll(mk & ((1ull << lane) - 1ull))] = ks[t];
+                    outbase += __popcll(mk);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -205,7 +240,7 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DESC_ERR_HIP, "no HIP device visible for DESC_BUILD_DEVICE");
     if (device < 0 || device >= ndev) return fail(DESC_ERR_INVALID, "device %d out of range", device);
     const int64_t words = (n + 63) / 64;
-    if ((double)n * (double)words * 8.0 > 64.0 * 1073741824.0)
+    if ((double)n * (double)words * 12.0 > 64.0 * 1073741824.0)
         return fail(DESC_ERR_TOO_LARGE, "adjacency bitmaps of n = %lld nodes do not fit the device-build budget; use DESC_BUILD_HOST", (long long)n);
     DESC_HIP(hipSetDevice(device));
     s->n = n; s->m = m; s->dev = device; s->seed = seed;
@@ -235,9 +270,11 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
     int rc;
     int32_t *d_codeg, *d_hist;
     unsigned long long* d_bits;
+    s->words = (int32_t)words;
     if ((rc = keep(&s->d_rowptr, n + 1)) || (rc = keep(&s->d_adj, 2 * m)) || (rc = keep(&s->d_adj_eid, 2 * m)) ||
         (rc = keep(&s->d_ii, m)) || (rc = keep(&s->d_jj, m)) || (rc = D.alloc(&d_codeg, m)) || (rc = D.alloc(&d_hist, n + 1)) ||
-        (rc = D.alloc(&d_bits, (size_t)n * words))) return rc;
+        (rc = keep(&s->d_bits, (size_t)n * words)) || (rc = keep(&s->d_rank, (size_t)n * words))) return rc;
+    d_bits = s->d_bits;
     DESC_HIP(hipMemcpy(s->d_rowptr, rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
     if (m) {
         DESC_HIP(hipMemcpy(s->d_adj, adj.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
@@ -248,8 +285,10 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
     lap("alloc+upload");
     DESC_HIP(hipMemset(d_bits, 0, sizeof(unsigned long long) * (size_t)n * words));
     DESC_HIP(hipMemset(d_hist, 0, sizeof(int32_t) * (n + 1)));
-    if (n > 0)
+    if (n > 0) {
         hipLaunchKernelGGL(k_bitmaps, dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, 0, s->d_rowptr, s->d_adj, d_bits, (int)n, (int)words);
+        hipLaunchKernelGGL(k_rank, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_bits, s->d_rank, (int)n, (int)words);
+    }
     if (m > 0)
         hipLaunchKernelGGL(k_codeg, dim3((unsigned)std::min<int64_t>(2048, (m + 3) / 4)), dim3(256), 0, 0, s->d_ii, s->d_jj, d_bits, d_codeg, d_hist, m, (int)words, (int)(n + 1));
     DESC_HIP(hipGetLastError());
@@ -312,9 +351,10 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
         const size_t lds = (size_t)4 * cap * (8 + 4);
         if (lds > 64 * 1024)
             DESC_HIP(hipFuncSetAttribute((const void*)k_fill_cycles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const char* tenv2 = getenv("DESC_DEBUG_EXACT_SELECT");     // tests: force the exact (tie-safe) ranking path
         const unsigned g = (unsigned)std::min<int64_t>(8192, (mp + 3) / 4);
         hipLaunchKernelGGL(k_fill_cycles, dim3(g), dim3(256), lds, 0, s->d_pos, s->d_cum, s->d_ii, s->d_jj, d_bits, s->d_k, s->d_tau, s->d_ktau,
-                           mp, (int)words, (int)n_sample, seed, cap);
+                           mp, (int)words, (int)n_sample, seed, cap, (tenv2 && atoi(tenv2) != 0) ? 1 : 0);
         DESC_HIP(hipGetLastError());
         DESC_HIP(hipDeviceSynchronize());
         lap("fill");
@@ -352,9 +392,9 @@ void structure_free_device(desc_structure* s) {
     if (!s || s->dev < 0) return;
     (void)hipSetDevice(s->dev);
     for (void* q : {(void*)s->d_k, (void*)s->d_tau, (void*)s->d_ktau, (void*)s->d_rowptr, (void*)s->d_adj, (void*)s->d_adj_eid, (void*)s->d_ii,
-                    (void*)s->d_jj, (void*)s->d_pos, (void*)s->d_cum, (void*)s->d_poe})
+                    (void*)s->d_jj, (void*)s->d_pos, (void*)s->d_cum, (void*)s->d_poe, (void*)s->d_bits, (void*)s->d_rank})
         if (q) (void)hipFree(q);
-    s->d_k = nullptr; s->d_tau = nullptr; s->d_ktau = nullptr;
+    s->d_k = nullptr; s->d_tau = nullptr; s->d_ktau = nullptr; s->d_bits = nullptr; s->d_rank = nullptr;
     s->d_rowptr = s->d_adj = s->d_adj_eid = s->d_ii = s->d_jj = s->d_pos = s->d_cum = s->d_poe = nullptr;
     s->dev = -1;
 }

@@ -263,3 +263,25 @@ def test_one_shot_solve(lib, oracle):
         assert out["ms_total"] >= out["ms_pgd"] > 0
     with pytest.raises(lib.DescError):
         lib.solve(lib.ProblemArrays(nn, ii, jj), c_params(10))       # no rotations: must refuse, not crash
+
+
+def test_device_structure_exact_selection_path(lib, oracle, monkeypatch):
+    """The tie-safe ranking path of the device builder's sampler (normally taken only when two
+    64-bit sampling keys of one edge collide at the cut) gives the same structure and thresholds."""
+    mo, nn, ii, jj, rij = make_problem("uniform", n=200, p=0.5, seed=17)
+    ref = oracle.build_structure(nn, ii, jj, seed=3)
+    monkeypatch.setenv("DESC_DEBUG_EXACT_SELECT", "1")
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    st = lib.Structure.build(prob, 30, 3, lib.BUILD_DEVICE, 0)
+    p = c_params(30, lr=0.01, seed=3)
+    solver = lib.Solver(prob, st, 0)
+    out_exact = solver.run(p, want_w=True)
+    solver.destroy()
+    assert_structure_equal(st.arrays(), ref)
+    st.free()
+    monkeypatch.delenv("DESC_DEBUG_EXACT_SELECT")
+    st2 = lib.Structure.build(prob, 30, 3, lib.BUILD_DEVICE, 0)
+    solver = lib.Solver(prob, st2, 0)
+    out_fast = solver.run(p, want_w=True)
+    solver.destroy(); st2.free()
+    assert np.array_equal(out_exact["S_vec"], out_fast["S_vec"]) and np.array_equal(out_exact["w"], out_fast["w"])
