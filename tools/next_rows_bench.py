@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Times the "next" rows on one GPU for a BASELINE workload: Spectral, GCW, CEMP and the
+DESC() refinement tail, each through the C ABI, with accuracy against the synthetic ground truth.
+Prints one JSON object.  Not the bench line (that is bench.py)."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import bench
+from desc_amd import _lib
+from desc_amd.algorithms import Rotation_Alignment
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="C2")
+args = ap.parse_args()
+mo, nn, ii, jj, rij = bench.generate(args.workload)
+prob = _lib.ProblemArrays(nn, ii, jj, rij)
+m = prob.m
+out = {"workload": bench.describe(args.workload), "n": nn, "m": m}
+
+def rot_err(R):
+    _, _, mean_err, med_err = Rotation_Alignment(R, mo.R_orig)
+    return {"mean_deg": float(mean_err), "median_deg": float(med_err)}
+
+_lib.Structure.build(_lib.ProblemArrays(3, np.array([0, 0, 1], dtype=np.int32), np.array([1, 2, 2], dtype=np.int32)), 30, 0, _lib.BUILD_DEVICE, 0).free()   # HIP context
+t0 = time.perf_counter()
+R, info = _lib.spectral_run(prob)
+dt = time.perf_counter() - t0
+# one block-SpMM step streams the 2m blocks (72 B) + block indices (4 B) once and gathers 2m x 144-B operand rows
+spmm_bytes = 2 * m * (72 + 4 + 144) + 2 * nn * 144
+out["spectral"] = dict(ms_wall=dt * 1e3, ms_lib=info["ms_total"], outer_iters=info["iters"], spmm_products=info["products"], residual=info["residual"],
+                       converged=info["converged"], spmm_bytes_per_product=spmm_bytes, **rot_err(R))
+
+p = _lib.default_params(); p.iters = 100; p.lr = 0.01
+t0 = time.perf_counter()
+pg = _lib.solve(prob, p)
+out["desc_pgd_solve"] = dict(ms_wall=(time.perf_counter() - t0) * 1e3, ms_structure=pg["ms_structure"], ms_pgd=pg["ms_pgd"], iters=pg["iters_run"],
+                             mean_abs_err_s=float(np.mean(np.abs(pg["S_vec"] - mo.ErrVec))))
+S = pg["S_vec"]
+t0 = time.perf_counter()
+Rg, info = _lib.spectral_run(prob, weights=1.0 / (S ** 1.5 + 1e-8), normalize_rows=True)
+out["gcw"] = dict(ms_wall=(time.perf_counter() - t0) * 1e3, ms_lib=info["ms_total"], outer_iters=info["iters"], spmm_products=info["products"],
+                  residual=info["residual"], converged=info["converged"], **rot_err(Rg))
+t0 = time.perf_counter()
+Rr, info = _lib.refine_run(prob, S, Rg)
+out["refine"] = dict(ms_wall=(time.perf_counter() - t0) * 1e3, ms_lib=info["ms_total"], iters=info["iters"], cg_iters=info["cg_iters"], score=info["score"], **rot_err(Rr))
+beta = [1, 2, 4, 8, 16, 32]            # Demo/compare_algorithms.m:26-28: reweighting 2.^((1:6)-1), nsample 50
+t0 = time.perf_counter()
+Sc, ms = _lib.cemp_run(prob, beta, len(beta), 50)
+out["cemp"] = dict(ms_wall=(time.perf_counter() - t0) * 1e3, ms_lib=ms, rounds=len(beta), nsample=50, mean_abs_err_s=float(np.mean(np.abs(Sc - mo.ErrVec))))
+print(json.dumps(out))
