@@ -113,14 +113,30 @@ extern "C" int desc_cemp_run(const desc_problem* prob, const double* beta, int32
     if (device < 0 || device >= ndev) return fail(DESC_ERR_INVALID, "device %d out of range", device);
     DESC_HIP(hipSetDevice(device));
     const int64_t m = prob->m;
-    std::vector<int32_t> pos_edge, kk, e_jk, e_ki;
-    if ((rc = build_cemp_samples_host(prob, nsample, seed, pos_edge, kk, e_jk, e_ki))) return rc;
-    const int64_t mp = (int64_t)pos_edge.size(), mc = mp * nsample;
-    if (mc >= (1ll << 31)) return fail(DESC_ERR_TOO_LARGE, "m_pos * nsample exceeds 2^31");
+    // samples: on the device; graphs beyond the device sampler's staging budget fall back to the host sampler
+    int64_t mp = 0;
+    int32_t *d_pos = nullptr, *d_k = nullptr, *d_ejk = nullptr, *d_eki = nullptr;
+    struct Owned { int32_t **a, **b, **c, **d; ~Owned() { for (int32_t** q : {a, b, c, d}) if (*q) (void)hipFree(*q); } } owned{&d_pos, &d_k, &d_ejk, &d_eki};
+    rc = build_cemp_samples_device(prob, nsample, seed, device, &mp, &d_pos, &d_k, &d_ejk, &d_eki);
+    if (rc == DESC_ERR_TOO_LARGE) {
+        std::vector<int32_t> pos_edge, kk, e_jk, e_ki;
+        if ((rc = build_cemp_samples_host(prob, nsample, seed, pos_edge, kk, e_jk, e_ki))) return rc;
+        mp = (int64_t)pos_edge.size();
+        const int64_t mch = mp * nsample;
+        if (mch >= (1ll << 31)) return fail(DESC_ERR_TOO_LARGE, "m_pos * nsample exceeds 2^31");
+        if (mp) {
+            DESC_HIP(hipMalloc((void**)&d_pos, sizeof(int32_t) * mp)); DESC_HIP(hipMalloc((void**)&d_k, sizeof(int32_t) * mch));
+            DESC_HIP(hipMalloc((void**)&d_ejk, sizeof(int32_t) * mch)); DESC_HIP(hipMalloc((void**)&d_eki, sizeof(int32_t) * mch));
+            DESC_HIP(hipMemcpy(d_pos, pos_edge.data(), sizeof(int32_t) * mp, hipMemcpyHostToDevice));
+            DESC_HIP(hipMemcpy(d_k, kk.data(), sizeof(int32_t) * mch, hipMemcpyHostToDevice));
+            DESC_HIP(hipMemcpy(d_ejk, e_jk.data(), sizeof(int32_t) * mch, hipMemcpyHostToDevice));
+            DESC_HIP(hipMemcpy(d_eki, e_ki.data(), sizeof(int32_t) * mch, hipMemcpyHostToDevice));
+        }
+    } else if (rc) return rc;
+    const int64_t mc = mp * nsample;
     DevC D;
-    int32_t *d_pos, *d_ii, *d_jj, *d_k, *d_ejk, *d_eki; double *d_rij, *d_S0, *d_S[2];
-    if ((rc = D.alloc(&d_pos, mp)) || (rc = D.alloc(&d_ii, m)) || (rc = D.alloc(&d_jj, m)) || (rc = D.alloc(&d_k, mc)) ||
-        (rc = D.alloc(&d_ejk, mc)) || (rc = D.alloc(&d_eki, mc)) || (rc = D.alloc(&d_rij, 9 * m)) || (rc = D.alloc(&d_S0, mc)) ||
+    int32_t *d_ii, *d_jj; double *d_rij, *d_S0, *d_S[2];
+    if ((rc = D.alloc(&d_ii, m)) || (rc = D.alloc(&d_jj, m)) || (rc = D.alloc(&d_rij, 9 * m)) || (rc = D.alloc(&d_S0, mc)) ||
         (rc = D.alloc(&d_S[0], m)) || (rc = D.alloc(&d_S[1], m))) return rc;
     if (m) {
         DESC_HIP(hipMemcpy(d_ii, prob->ind_i, sizeof(int32_t) * m, hipMemcpyHostToDevice));
@@ -132,10 +148,6 @@ extern "C" int desc_cemp_run(const desc_problem* prob, const double* beta, int32
     }
     int cur = 0;
     if (mp) {
-        DESC_HIP(hipMemcpy(d_pos, pos_edge.data(), sizeof(int32_t) * mp, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_k, kk.data(), sizeof(int32_t) * mc, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_ejk, e_jk.data(), sizeof(int32_t) * mc, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_eki, e_ki.data(), sizeof(int32_t) * mc, hipMemcpyHostToDevice));
         const int g = (int)std::min<int64_t>(8192, (mp + 3) / 4);
         hipLaunchKernelGGL(k_cemp_s0, dim3(g), dim3(256), 0, 0, d_pos, d_ii, d_jj, d_k, d_ejk, d_eki, d_rij, d_S0, d_S[0], d_S[1], (int)mp, nsample);
         for (int it = 0; it < max_iter; ++it) {                                     // :107

@@ -68,6 +68,10 @@ int validate_problem(const desc_problem* prob, bool need_rij);
 // device-resident structures (structure_device.hip)
 int structure_ensure_host(desc_structure* s);      // copy the per-cycle arrays to the host if they live on the device
 void structure_free_device(desc_structure* s);
+// CEMP.m:44-65 on the device: nsample cycles per edge-with-cycles, with replacement.  The four arrays are
+// hipMalloc'ed on `device` (caller frees); DESC_ERR_TOO_LARGE when a codegree exceeds the LDS staging budget.
+int build_cemp_samples_device(const desc_problem* prob, int32_t nsample, uint64_t seed, int32_t device, int64_t* m_pos,
+                              int32_t** d_pos, int32_t** d_k, int32_t** d_ejk, int32_t** d_eki);
 int build_cemp_samples_host(const desc_problem* prob, int32_t nsample, uint64_t seed, std::vector<int32_t>& pos_edge,
                             std::vector<int32_t>& kk, std::vector<int32_t>& e_jk, std::vector<int32_t>& e_ki);
 }  // namespace desc

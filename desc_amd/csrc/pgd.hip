@@ -423,8 +423,10 @@ struct alignas(16) ChunkBuf {
 // stores too, so gathers and records are consumed (landed) after the arithmetic but before
 // the stores of the iteration that issued them.  Chunk descriptors are prefetched four
 // chunks ahead with one scalar 16-byte load (constant cache: off vmcnt).
+// (the Adam variant carries two more streamed values per cycle through the arithmetic: it gets the
+//  register budget of 3 waves per SIMD instead of spilling)
 template <int E, int STEP>
-__global__ __launch_bounds__(SWEEP_THREADS, 4) void k_sweep_node(NodeSweepArgs a) {
+__global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) void k_sweep_node(NodeSweepArgs a) {
     __shared__ ChunkBuf X[3];
     __shared__ double s_nv[65];
     if (a.state->stop) return;

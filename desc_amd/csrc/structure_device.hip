@@ -162,6 +162,51 @@ __global__ __launch_bounds__(256) void k_fill_cycles(const int32_t* pos_edge, co
     }
 }
 
+// CEMP's sampler (CEMP.m:57-65): nsample draws WITH replacement per edge-with-cycles,
+// draw t = CoInd[key(seed, e, t) mod codeg]; one wave per edge.
+__global__ __launch_bounds__(256) void k_cemp_samples(const int32_t* pos_edge, const int32_t* ind_i, const int32_t* ind_j,
+                                                      const unsigned long long* bits, const uint32_t* rank, const int32_t* rowptr,
+                                                      const int32_t* adj_eid, int32_t* kk, int32_t* e_jk, int32_t* e_ki, int64_t m_pos,
+                                                      int words, int nsample, uint64_t seed, int lds_cap) {
+    extern __shared__ unsigned long long smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int32_t* ks = (int32_t*)smem + (size_t)wv * lds_cap;
+    const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t l = wid; l < m_pos; l += nw) {
+        const int e = pos_edge[l], i = ind_i[e], j = ind_j[e];
+        const unsigned long long* a = bits + (size_t)i * words;
+        const unsigned long long* b = bits + (size_t)j * words;
+        int run = 0;
+        for (int w0 = 0; w0 < words; w0 += 64) {
+            const int w = w0 + lane;
+            unsigned long long x = 0;
+            if (w < words) x = a[w] & b[w];
+            const int pc = __popcll(x);
+            const int incl = wave_incl_scan(pc, lane);
+            int pos = run + incl - pc;
+            run += __shfl(incl, 63, 64);
+            while (x) {
+                if (pos < lds_cap) ks[pos] = w * 64 + __ffsll((long long)x) - 1;
+                ++pos;
+                x &= x - 1;
+            }
+        }
+        const int cd = run;
+        __builtin_amdgcn_wave_barrier();
+        const int r0i = rowptr[i], r0j = rowptr[j];
+        for (int t = lane; t < nsample; t += 64) {
+            const int k = ks[d_sample_key(seed, (uint64_t)e, (uint64_t)t) % (uint64_t)cd];
+            const size_t wi = (size_t)i * words + (k >> 6), wj = (size_t)j * words + (k >> 6);
+            const unsigned long long below = (1ull << (k & 63)) - 1ull;
+            const int64_t c = l * nsample + t;
+            kk[c] = k;
+            e_ki[c] = adj_eid[r0i + rank[wi] + __popcll(bits[wi] & below)];
+            e_jk[c] = adj_eid[r0j + rank[wj] + __popcll(bits[wj] & below)];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // e_jk / e_ki of every cycle (DESC_PGD.m:87-88) from the sampled k: binary search of k in the CSR
 // rows of j and i.  Only run when the full index structure is exported (desc_structure_get) or
 // the gather layout needs it.
@@ -360,6 +405,78 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
         lap("fill");
     }
     s->ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return DESC_OK;
+}
+
+int build_cemp_samples_device(const desc_problem* prob, int32_t nsample, uint64_t seed, int32_t device, int64_t* m_pos,
+                              int32_t** o_pos, int32_t** o_k, int32_t** o_ejk, int32_t** o_eki) {
+    const int64_t n = prob->n, m = prob->m;
+    const int64_t words = (n + 63) / 64;
+    *m_pos = 0; *o_pos = *o_k = *o_ejk = *o_eki = nullptr;
+    if ((double)n * (double)words * 12.0 > 64.0 * 1073741824.0) return fail(DESC_ERR_TOO_LARGE, "adjacency bitmaps do not fit the device budget");
+    DESC_HIP(hipSetDevice(device));
+    std::vector<int32_t> rowptr((size_t)n + 1, 0), adj((size_t)2 * m), adj_eid((size_t)2 * m);
+    for (int64_t e = 0; e < m; ++e) { rowptr[prob->ind_i[e] + 1]++; rowptr[prob->ind_j[e] + 1]++; }
+    for (int64_t v = 0; v < n; ++v) rowptr[v + 1] += rowptr[v];
+    {
+        std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
+        for (int64_t e = 0; e < m; ++e) {
+            const int32_t i = prob->ind_i[e], j = prob->ind_j[e];
+            adj[fill[i]] = j; adj_eid[fill[i]++] = (int32_t)e;
+            adj[fill[j]] = i; adj_eid[fill[j]++] = (int32_t)e;
+        }
+    }
+    DevBuf D;
+    int rc;
+    int32_t *d_rowptr, *d_adj, *d_adj_eid, *d_ii, *d_jj, *d_codeg, *d_hist;
+    unsigned long long* d_bits; uint32_t* d_rank;
+    if ((rc = D.alloc(&d_rowptr, n + 1)) || (rc = D.alloc(&d_adj, 2 * m)) || (rc = D.alloc(&d_adj_eid, 2 * m)) || (rc = D.alloc(&d_ii, m)) ||
+        (rc = D.alloc(&d_jj, m)) || (rc = D.alloc(&d_codeg, m)) || (rc = D.alloc(&d_hist, n + 1)) ||
+        (rc = D.alloc(&d_bits, (size_t)n * words)) || (rc = D.alloc(&d_rank, (size_t)n * words))) return rc;
+    DESC_HIP(hipMemcpy(d_rowptr, rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
+    if (m) {
+        DESC_HIP(hipMemcpy(d_adj, adj.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
+        DESC_HIP(hipMemcpy(d_adj_eid, adj_eid.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
+        DESC_HIP(hipMemcpy(d_ii, prob->ind_i, sizeof(int32_t) * m, hipMemcpyHostToDevice));
+        DESC_HIP(hipMemcpy(d_jj, prob->ind_j, sizeof(int32_t) * m, hipMemcpyHostToDevice));
+    }
+    DESC_HIP(hipMemset(d_bits, 0, sizeof(unsigned long long) * (size_t)n * words));
+    DESC_HIP(hipMemset(d_hist, 0, sizeof(int32_t) * (n + 1)));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_bitmaps, dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, 0, d_rowptr, d_adj, d_bits, (int)n, (int)words);
+        hipLaunchKernelGGL(k_rank, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_bits, d_rank, (int)n, (int)words);
+    }
+    if (m > 0)
+        hipLaunchKernelGGL(k_codeg, dim3((unsigned)std::min<int64_t>(2048, (m + 3) / 4)), dim3(256), 0, 0, d_ii, d_jj, d_bits, d_codeg, d_hist, m, (int)words, (int)(n + 1));
+    DESC_HIP(hipGetLastError());
+    std::vector<int32_t> codeg((size_t)m), pos_edge;
+    if (m) DESC_HIP(hipMemcpy(codeg.data(), d_codeg, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+    int32_t max_codeg = 0;
+    for (int64_t e = 0; e < m; ++e) if (codeg[e] > 0) { pos_edge.push_back((int32_t)e); max_codeg = std::max(max_codeg, codeg[e]); }
+    const int64_t mp = (int64_t)pos_edge.size(), mc = mp * nsample;
+    if (mc >= (1ll << 31)) return fail(DESC_ERR_TOO_LARGE, "m_pos * nsample exceeds 2^31");
+    if (max_codeg > 4 * MAX_CODEG_LDS) return fail(DESC_ERR_TOO_LARGE, "an edge has %d common neighbours: host sampler", max_codeg);
+    *m_pos = mp;
+    if (mp == 0) return DESC_OK;
+    auto keep = [&](int32_t** out, size_t count) -> int {
+        void* q = nullptr;
+        DESC_HIP(hipMalloc(&q, sizeof(int32_t) * (count ? count : 1)));
+        *out = (int32_t*)q;
+        return DESC_OK;
+    };
+    if ((rc = keep(o_pos, mp)) || (rc = keep(o_k, mc)) || (rc = keep(o_ejk, mc)) || (rc = keep(o_eki, mc))) {
+        for (int32_t** q : {o_pos, o_k, o_ejk, o_eki}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+        return rc;
+    }
+    DESC_HIP(hipMemcpy(*o_pos, pos_edge.data(), sizeof(int32_t) * mp, hipMemcpyHostToDevice));
+    int cap = 64;
+    while (cap < max_codeg) cap <<= 1;
+    const size_t lds = (size_t)4 * cap * 4;
+    if (lds > 64 * 1024) DESC_HIP(hipFuncSetAttribute((const void*)k_cemp_samples, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_cemp_samples, dim3((unsigned)std::min<int64_t>(8192, (mp + 3) / 4)), dim3(256), lds, 0, *o_pos, d_ii, d_jj, d_bits, d_rank,
+                       d_rowptr, d_adj_eid, *o_k, *o_ejk, *o_eki, mp, (int)words, (int)nsample, seed, cap);
+    DESC_HIP(hipGetLastError());
+    DESC_HIP(hipDeviceSynchronize());
     return DESC_OK;
 }
 
