@@ -102,6 +102,26 @@ __global__ __launch_bounds__(256) void k_gram(const double* X, const double* Y, 
 
 // Xnew = Y * C  (C: BW x BW row-major, passed by value)
 struct SmallMat { double c[BW * BW]; };
+// blocks[t] (column-major 3x3) of CSR slot t in row v: w_e * dinv[v] * dinv[u] * (v < u ? R_e : R_e')
+// -- Spectral.m:24-33 / GCW.m:14-21 without the dense matrix; one wave per row, lanes over its slots
+__global__ __launch_bounds__(256) void k_assemble_blocks(const int32_t* rowptr, const int32_t* adj, const int32_t* adj_eid, const double* rij,
+                                                         const double* wts, const double* dinv, double* blocks, int n) {
+    const int lane = threadIdx.x & 63;
+    const int w0 = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = (gridDim.x * 256) >> 6;
+    for (int v = w0; v < n; v += nw) {
+        const double dv = dinv[v];
+        for (int t = rowptr[v] + lane; t < rowptr[v + 1]; t += 64) {
+            const int u = adj[t], e = adj_eid[t];
+            const double du = dinv[u];
+            const double w = (wts ? wts[e] : 1.0) * (v < u ? dv : du) * (v < u ? du : dv);     // same rounding in (v,u) and (u,v): exactly symmetric
+            const double* R = rij + 9 * (int64_t)e;
+            double* b = blocks + 9 * (int64_t)t;
+            if (v < u) { for (int q = 0; q < 9; ++q) b[q] = w * R[q]; }
+            else { for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) b[r + 3 * c] = w * R[c + 3 * r]; }
+        }
+    }
+}
+
 struct ResArgs { double z[BW * 3]; double theta[3]; };
 // explicit residuals of the three wanted Ritz pairs: partial sums of |Y z_c - theta_c X z_c|^2
 // (the Gram-matrix form z'G2z - theta^2 cancels catastrophically below ~1e-8 relative)
@@ -236,9 +256,9 @@ extern "C" int desc_spectral_run(const desc_problem* prob, const double* weights
     if (tol <= 0) tol = 1e-13;
     if (max_iters <= 0) max_iters = 500;
 
-    // block CSR: every edge in both endpoint rows
-    std::vector<int32_t> rowptr((size_t)n + 1, 0), adj((size_t)2 * m);
-    std::vector<double> blocks((size_t)18 * m), deg((size_t)n, 0.0);
+    // block CSR: every edge in both endpoint rows (index part on the host, the 2m blocks are assembled on the device)
+    std::vector<int32_t> rowptr((size_t)n + 1, 0), adj((size_t)2 * m), adj_eid((size_t)2 * m);
+    std::vector<double> deg((size_t)n, 0.0);
     for (int64_t e = 0; e < m; ++e) { rowptr[prob->ind_i[e] + 1]++; rowptr[prob->ind_j[e] + 1]++; }
     for (int64_t v = 0; v < n; ++v) rowptr[v + 1] += rowptr[v];
     for (int64_t e = 0; e < m; ++e) {
@@ -258,11 +278,8 @@ extern "C" int desc_spectral_run(const desc_problem* prob, const double* weights
         std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
         for (int64_t e = 0; e < m; ++e) {
             const int32_t i = prob->ind_i[e], j = prob->ind_j[e];
-            const double w = (weights ? weights[e] : 1.0) * dinv[i] * dinv[j];
-            const double* R = prob->rij + 9 * e;             // column-major R_ij
-            double* bi = &blocks[9 * (size_t)fill[i]]; adj[fill[i]++] = j;
-            double* bj = &blocks[9 * (size_t)fill[j]]; adj[fill[j]++] = i;
-            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { bi[r + 3 * c] = w * R[r + 3 * c]; bj[r + 3 * c] = w * R[c + 3 * r]; }   // (i,j) = R, (j,i) = R'
+            adj[fill[i]] = j; adj_eid[fill[i]++] = (int32_t)e;      // (i,j) = R, (j,i) = R'
+            adj[fill[j]] = i; adj_eid[fill[j]++] = (int32_t)e;
         }
     }
     const int64_t rows = 3 * n;
@@ -277,8 +294,18 @@ extern "C" int desc_spectral_run(const desc_problem* prob, const double* weights
         (rc = D.alloc(&d_X, rows * BW)) || (rc = D.alloc(&d_Y, rows * BW)) || (rc = D.alloc(&d_part, (size_t)ggrid * 2 * BW * BW))) return rc;
     DESC_HIP(hipMemcpy(d_rowptr, rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
     if (m) {
+        Dev T;                                               // assembly inputs, released before the iteration starts
+        int32_t* d_eid; double *d_rij, *d_w = nullptr, *d_dinv;
+        if ((rc = T.alloc(&d_eid, 2 * m)) || (rc = T.alloc(&d_rij, 9 * m)) || (rc = T.alloc(&d_dinv, n)) || (weights && (rc = T.alloc(&d_w, m)))) return rc;
         DESC_HIP(hipMemcpy(d_adj, adj.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_blocks, blocks.data(), sizeof(double) * 18 * m, hipMemcpyHostToDevice));
+        DESC_HIP(hipMemcpy(d_eid, adj_eid.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
+        DESC_HIP(hipMemcpy(d_rij, prob->rij, sizeof(double) * 9 * m, hipMemcpyHostToDevice));
+        DESC_HIP(hipMemcpy(d_dinv, dinv.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        if (weights) DESC_HIP(hipMemcpy(d_w, weights, sizeof(double) * m, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_assemble_blocks, dim3((unsigned)std::min<int64_t>(4096, (n + 3) / 4)), dim3(256), 0, 0, d_rowptr, d_adj, d_eid, d_rij, d_w,
+                           d_dinv, d_blocks, (int)n);
+        DESC_HIP(hipGetLastError());
+        DESC_HIP(hipDeviceSynchronize());
     }
     DESC_HIP(hipMemcpy(d_Y, X0.data(), sizeof(double) * rows * BW, hipMemcpyHostToDevice));
 
