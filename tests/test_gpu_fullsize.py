@@ -71,3 +71,41 @@ def test_full_size_properties(lib, name, iters):
         assert np.abs(wn - w[lo:hi]).max() < 1e-13
         assert abs(wn @ d[lo:hi] - S[a["pos_edge"][l]]) < 1e-13
     st.free()
+
+
+@pytest.mark.parametrize("name,iters", [("C4", 10), ("C5", 6)])
+def test_full_size_properties_large(lib, name, iters):
+    """BASELINE configs[3], [4] (n = 5000 / 10000, 1.25e8 / 1.5e8 sampled cycles): same properties as
+    above on the node layout (the gather cross-check is left to C1-C3: it needs the full index
+    structure of 5 x m_cycle ints on the device a second time)."""
+    mo, nn, ii, jj, rij = bench.generate(name)
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    st = lib.Structure.build(prob, 30, 0, lib.BUILD_DEVICE, 0)
+    p = c_params(iters, lr=0.01, seed=0)
+    node = run(lib, prob, st, p, "node")
+    prev = run(lib, prob, st, c_params(iters - 1, lr=0.01, seed=0), "node")
+    again = run(lib, prob, st, p, "node", want_w=False)
+    solver = lib.Solver(prob, st, 0); d = solver.s0(); solver.destroy()
+    a = st.arrays()                                               # lazily derived on the device, then copied
+    st.free()
+    assert "node" in node["kernel"]
+    w, S = node["w"], node["S_vec"]
+    sums = np.add.reduceat(w, a["cum_ind"][:-1])
+    assert np.abs(sums - 1).max() < 1e-12 and w.min() >= 0
+    assert S.min() >= 0 and S.max() <= 1
+    assert (np.diff(node["obj"]) < 0).all()
+    assert np.array_equal(again["S_vec"], S) and np.array_equal(again["obj"], node["obj"])
+    rng = np.random.default_rng(1)
+    cum = a["cum_ind"]
+    for l in rng.choice(a["m_pos"], 200, replace=False):
+        lo, hi = cum[l], cum[l + 1]
+        ikj, jki = a["ikj"][lo:hi], a["jki"][lo:hi]
+        T1 = prev["w"][ikj[ikj >= 0]].sum(); T2 = prev["w"][jki[jki >= 0]].sum()
+        g = prev["S_vec"][a["e_jk"][lo:hi]] + prev["S_vec"][a["e_ki"][lo:hi]] + ((ikj >= 0) * T1 + (jki >= 0) * T2) * d[lo:hi]
+        g = g - g.mean()
+        v = prev["w"][lo:hi] - 0.01 * g
+        u = np.sort(v)[::-1]; css = np.cumsum(u) - 1
+        rho = np.nonzero(u - css / (np.arange(len(u)) + 1) > 0)[0][-1]
+        wn = np.maximum(v - css[rho] / (rho + 1), 0)
+        assert np.abs(wn - w[lo:hi]).max() < 1e-13
+        assert abs(wn @ d[lo:hi] - S[a["pos_edge"][l]]) < 1e-13
