@@ -487,6 +487,8 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
             int si = r.rbi + (int)(p & 0x7FFFu), sj = r.rbj + (int)((p >> 16) & 0x7FFFu);
             if (a.ablate & 1) { si = lane; sj = lane; }     // diagnostics: gathers that always hit L1
             if (a.ablate & 2) { si = (int)(p & 511u); sj = (int)((p >> 16) & 511u); }   // divergent, but inside one 4 KiB window
+            if (a.ablate & 32) si = (int)(p & 511u);                                    // only the i-row gathers redirected
+            if (a.ablate & 16) sj = (int)((p >> 16) & 511u);                            // only the j-row gathers redirected
             g.sjk[e] = a.S_old[sj]; g.ski[e] = a.S_old[si];
         }
         g.T1 = a.Tfull[r.sa];                    // column j of node i = sum(wijk(IKJ(mask)))  (:189)
