@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (GPU box): random graphs / sampling budgets / step plugins, HIP path
+(device-built structure, node and gather layouts) against the CPU oracle.  Test infrastructure,
+like tests/: imports oracle/.  Prints one line per failure and a summary; exit code 1 on any failure."""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch  # noqa: F401  (before libdesc_amd.so, see desc_amd/_lib.py)
+from desc_amd import _lib as lib
+from oracle import oracle as O
+from tests.helpers import make_problem, c_params, STRUCT_KEYS
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=240)
+ap.add_argument("--seed", type=int, default=0)
+args = ap.parse_args()
+rng = np.random.default_rng(args.seed)
+t_end = time.time() + args.seconds
+n_cases = n_fail = 0
+worst = 0.0
+while time.time() < t_end:
+    kind = "uniform" if rng.random() < 0.7 else "nonuniform"
+    n = int(rng.choice([5, 8, 13, 21, 34, 55, 89, 144, 233, 300]))
+    p = float(rng.choice([0.08, 0.15, 0.3, 0.5, 0.7, 0.95]))
+    nmin = int(rng.choice([1, 2, 5, 16, 17, 30, 33, 64]))
+    sk = int(rng.choice([0, 0, 1, 2]))
+    iters = int(rng.choice([1, 2, 7, 40]))
+    seed = int(rng.integers(0, 1 << 30))
+    lr = float(rng.choice([0.01, 0.1, 1.0]))
+    variant = "1" if rng.random() < 0.25 else "0"
+    where = lib.BUILD_DEVICE if rng.random() < 0.8 else lib.BUILD_HOST
+    tag = dict(kind=kind, n=n, p=p, nmin=nmin, sk=sk, iters=iters, seed=seed, lr=lr, variant=variant, where=where)
+    try:
+        mo, nn, ii, jj, rij = make_problem(kind, n=n, p=p, seed=seed % 1000)
+    except Exception as e:                      # generator refuses degenerate graphs
+        continue
+    if ii.shape[0] == 0:
+        continue
+    n_cases += 1
+    try:
+        st = O.build_structure(nn, ii, jj, seed=seed, n_sample_min=nmin)
+        if st["m_pos"] and np.diff(st["cum_ind"]).max() > 64 and variant == "0":
+            pass                                 # node layout not applicable: the library falls back to gather itself
+        S0 = O.cycle_d(ii, jj, rij.reshape(-1, 9), st)
+        step = dict(step_kind=sk, lr=lr, hybrid_strategy=0)
+        ref = O.pgd_run(st, S0, iters, **step)
+        os.environ["DESC_DEBUG_VARIANT"] = variant
+        prob = lib.ProblemArrays(nn, ii, jj, rij)
+        dst = lib.Structure.build(prob, nmin, seed, where, 0)
+        solver = lib.Solver(prob, dst, 0)
+        pr = c_params(iters, seed=seed, **step)
+        out = solver.run(pr, want_w=True)
+        solver.destroy()
+        a = dst.arrays(); dst.free()
+        for key in STRUCT_KEYS:
+            assert np.array_equal(a[key], st[key]), "structure " + key
+        assert out["iters_run"] == ref["iters_run"], "iters_run %d vs %d" % (out["iters_run"], ref["iters_run"])
+        tol = 1e-9 if sk == 2 else 1e-10
+        e1 = float(np.abs(out["S_vec"] - ref["S_vec"]).max()) if nn else 0.0
+        e2 = float(np.abs(out["w"] - ref["w"]).max()) if st["m_cycle"] else 0.0
+        worst = max(worst, e1, e2)
+        assert e1 <= tol and e2 <= tol, "values %g %g" % (e1, e2)
+        assert np.allclose(out["obj"], ref["obj"], rtol=1e-11, atol=1e-9), "objective trace"
+    except Exception as e:
+        n_fail += 1
+        print("FAIL", tag, repr(e)[:300], flush=True)
+    finally:
+        os.environ.pop("DESC_DEBUG_VARIANT", None)
+print("cases %d failures %d worst |diff| %.3g" % (n_cases, n_fail, worst), flush=True)
+sys.exit(1 if n_fail else 0)
