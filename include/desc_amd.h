@@ -83,7 +83,11 @@ typedef struct desc_structure_view {
 /* Build the structure from the edge list.  `datasample` (DESC_PGD.m:84, MATLAB
  * global RNG) is replaced by a counter-based keyed selection: an edge with
  * codeg >= n_sample keeps the n_sample common neighbours k with the smallest
- * desc_sample_key(seed, edge, k).  where = DESC_BUILD_HOST | DESC_BUILD_DEVICE. */
+ * desc_sample_key(seed, edge, k).  where = DESC_BUILD_HOST | DESC_BUILD_DEVICE.
+ * DESC_BUILD_DEVICE keeps the structure in the HBM of `device` in a lean form (sampled
+ * third vertices + per-edge selection thresholds + adjacency); a solver created on the
+ * same device lays it out in place without a host round trip.  DESC_ERR_TOO_LARGE means
+ * the graph exceeds the device builder's staging budget: use DESC_BUILD_HOST. */
 int desc_structure_build(const desc_problem* prob, int32_t n_sample_min, uint64_t seed,
                          int32_t where, int32_t device, desc_structure** out);
 /* Adopt a caller-supplied structure (oracle-parity runs; arrays are copied). */
@@ -91,6 +95,9 @@ int desc_structure_import(int64_t n, int64_t m, int64_t m_pos, int32_t n_sample,
                           const int32_t* pos_edge, const int64_t* cum_ind,
                           const int32_t* k, const int32_t* e_jk, const int32_t* e_ki,
                           const int32_t* ikj, const int32_t* jki, desc_structure** out);
+/* Host view of the full index structure.  For a device-built structure the first call derives
+ * e_jk, e_ki and the mirror maps on the device and copies them down (O(m_cycle)); later calls
+ * are free.  Not thread-safe per structure; the view stays valid until desc_structure_free. */
 int desc_structure_get(const desc_structure* s, desc_structure_view* view);
 void desc_structure_free(desc_structure* s);
 uint64_t desc_sample_key(uint64_t seed, uint64_t edge, uint64_t k);
