@@ -935,20 +935,16 @@ __global__ void k_gather_pairs(const double* sall, int64_t slice_len, int world,
 // Sum the block partials in a fixed order, record the traces and run the early-stop
 // rule of DESC_PGD.m:243-256 for the iteration whose objective just became known.
 // t = 1-based index of the sweep that produced the partials.
-__global__ __launch_bounds__(256) void k_finalize(const double* partials, int nparts, DevState* st,
-                                                  double* obj_trace, double* avg_trace, int t, int64_t m,
-                                                  int patience, double stop_tol, int last_only) {
+__global__ __launch_bounds__(64) void k_finalize(const double* partials, int nparts, DevState* st,
+                                                 double* obj_trace, double* avg_trace, int t, int64_t m,
+                                                 int patience, double stop_tol, int last_only) {
     if (st->stop) return;
-    __shared__ double sh[2][256];
+    // one wave: every lane adds its strided share in index order, then the fixed DPP butterfly
     double o = 0.0, ch = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += 256) { o += partials[2 * i]; ch += partials[2 * i + 1]; }
-    sh[0][threadIdx.x] = o; sh[1][threadIdx.x] = ch;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) { sh[0][threadIdx.x] += sh[0][threadIdx.x + s]; sh[1][threadIdx.x] += sh[1][threadIdx.x + s]; }
-        __syncthreads();
-    }
+    for (int i = threadIdx.x; i < nparts; i += 64) { o += partials[2 * i]; ch += partials[2 * i + 1]; }
+    o = group_sum<64>(o); ch = group_sum<64>(ch);
     if (threadIdx.x != 0) return;
+    const double sh[2][1] = {{o}, {ch}};
     // last_only: the partials come from the objective kernel after the final sweep t and
     // hold obj(t).  Otherwise they come from sweep t: obj(t-1) and sum|dS| of sweep t.
     const int it = last_only ? t : t - 1;          // iteration whose objective is sh[0][0]
@@ -1153,7 +1149,7 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
         if (adam) launch_gather<DESC_STEP_HYBRID>(h, a); else launch_gather<DESC_STEP_CONSTANT>(h, a);
     }
     if (ev1) (void)hipEventRecord(ev1, h->stream);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, h->d_partials, h->grid, h->d_state, h->d_obj,
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, h->d_partials, h->grid, h->d_state, h->d_obj,
                        h->d_avg, t, h->m, p.patience, p.stop_tol, 0);
     DESC_HIP(hipGetLastError());
     return DESC_OK;
@@ -1756,7 +1752,7 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
         else
             hipLaunchKernelGGL(k_objective, dim3(h->obj_grid), dim3(256), 0, h->stream, h->d_w[T & 1], h->d_S[T & 1], h->d_ejk,
                                h->d_eki, h->m_cycle, h->d_partials, h->d_state);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, h->d_partials, h->obj_grid, h->d_state, h->d_obj,
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, h->d_partials, h->obj_grid, h->d_state, h->d_obj,
                            h->d_avg, T, h->m, h->p.patience, h->p.stop_tol, 1);
     }
     DevState st{};
@@ -1913,7 +1909,7 @@ int desc_pgd_shard_finish(desc_pgd* h, int32_t initial) {
     hipLaunchKernelGGL(k_unpack_S, dim3(g), dim3(256), 0, h->stream, h->d_einfo, h->d_rank_seg, h->world, h->x_sall, h->slice_len,
                        h->d_S[initial == 2 ? 0 : wr], initial == 2 ? h->d_S[1] : nullptr, h->d_pairs);
     if (initial != 2)
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, h->d_pairs, h->world, h->d_state, h->d_obj, h->d_avg, t, h->m,
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, h->d_pairs, h->world, h->d_state, h->d_obj, h->d_avg, t, h->m,
                            h->p.patience, h->p.stop_tol, 0);
     DESC_HIP(hipGetLastError());
     return DESC_OK;
@@ -1932,7 +1928,7 @@ int desc_pgd_shard_objective(desc_pgd* h, int32_t phase) {
                            h->x_sall + (int64_t)h->rank * h->slice_len, (int)h->seg_lo, (int)h->seg_lo, h->slice_len);
     } else {
         hipLaunchKernelGGL(k_gather_pairs, dim3(1), dim3(64), 0, h->stream, h->x_sall, h->slice_len, h->world, h->d_pairs);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, h->d_pairs, h->world, h->d_state, h->d_obj, h->d_avg, T, h->m,
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, h->d_pairs, h->world, h->d_state, h->d_obj, h->d_avg, T, h->m,
                            h->p.patience, h->p.stop_tol, 1);
         h->objective_done = true;
     }
