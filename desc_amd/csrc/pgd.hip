@@ -359,7 +359,7 @@ struct EdgeInfo {
 constexpr int SWEEP_THREADS = 512;
 constexpr int CHUNK_LDS = 960;             // entries of the LDS image of a chunk: one 16-byte vector of w per thread
 constexpr int CHUNK_CAP = CHUNK_LDS - 4;   // cycles per chunk: the image starts up to 3 entries before the chunk (16-byte alignment)
-constexpr int CHUNK_SEG = 32;              // segments per chunk: one pass of the 8 waves x 4 groups of 16 lanes
+constexpr int MAX_SEG_CYCLES = 256;         // longest segment the node layout takes (64 lanes x 4 cycles)
 
 // first / end cycle and first / end segment of a chunk, one 16-byte scalar load
 struct alignas(16) ChunkDesc { int32_t c0, c1, l0, l1; };
@@ -401,12 +401,13 @@ struct alignas(16) ChunkBuf {
 };
 
 // The sweep (dominant kernel).  512-thread persistent workgroups take chunks of consecutive
-// segments (<= CHUNK_CAP cycles, <= CHUNK_SEG segments) round-robin: at any moment the
+// segments (<= CHUNK_CAP cycles, <= 8 * 64/LPS segments) round-robin: at any moment the
 // resident workgroups read one contiguous window of the streamed arrays (DRAM row-buffer
 // locality; disjoint far-apart streams per workgroup measured ~half the bandwidth).
 // pk, w and S0 of a chunk arrive with 16-byte loads, two chunks ahead, and are parked in a
 // triple-buffered LDS image.  Everything per segment lives in the registers of the 16 lanes
-// that own the segment (a chunk = one pass of the 8 waves x 4 lane groups): the lane group
+// that own the segment (LPS = 16, 32 or 64 lanes for segments of up to 64, 128, 256 cycles; a
+// chunk = one pass of the 8 waves x 64/LPS lane groups): the lane group
 // that will compute segment t of chunk c+1 loads its records, issues its row gathers
 // (addresses from the packed words already parked in LDS) and keeps their sums until the
 // arithmetic of chunk c+1; E cycles per lane, reductions = E in-lane adds + 4 DPP steps
@@ -425,23 +426,24 @@ struct alignas(16) ChunkBuf {
 // chunks ahead with one scalar 16-byte load (constant cache: off vmcnt).
 // (the Adam variant carries two more streamed values per cycle through the arithmetic: it gets the
 //  register budget of 3 waves per SIMD instead of spilling)
-template <int E, int STEP>
+template <int LPS, int E, int STEP>
 __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) void k_sweep_node(NodeSweepArgs a) {
     __shared__ ChunkBuf X[3];
-    __shared__ double s_nv[65];
+    __shared__ double s_nv[MAX_SEG_CYCLES + 1];
     if (a.state->stop) return;
     constexpr int NT = SWEEP_THREADS;
-    static_assert(NT == 512 && CHUNK_SEG == 32, "8 waves x 4 lane groups = CHUNK_SEG");
+    static_assert(NT == 512 && (LPS == 16 || LPS == 32 || LPS == 64) && LPS * E <= MAX_SEG_CYCLES, "8 waves x 64/LPS lane groups per chunk");
     static_assert(CHUNK_LDS / 2 <= NT, "one 16-byte vector of w per thread");
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const int grp = lane >> 4, r16 = lane & 15;
-    const int ts = wv * 4 + grp;                       // segment slot of this lane group
+    constexpr int SPW = 64 / LPS;                      // segments per wave: a chunk holds at most 8 * SPW segments
+    const int grp = lane / LPS, r16 = lane % LPS;      // LPS lanes per segment, E cycles per lane
+    const int ts = wv * SPW + grp;                     // segment slot of this lane group
     const int nb = gridDim.x, lb = blockIdx.x;         // chunks dealt round-robin (see k_sweep_node)
     const int nk = lb < a.nchunks ? (a.nchunks - lb + nb - 1) / nb : 0;
     double obj_acc = 0.0, chg_acc = 0.0;
     if (nk == 0) { block_partials(obj_acc, chg_acc, a.partials, lb); return; }
-    if (tid <= 64) s_nv[tid] = tid <= a.max_cnt ? a.nv_tab[tid] : 0.0;
+    if (tid <= MAX_SEG_CYCLES) s_nv[tid] = tid <= a.max_cnt ? a.nv_tab[tid] : 0.0;
 
     struct RecRaw { int b0, b1; EdgeInfo ei; };
     struct Rec { int qb, cnt, rbi, rbj, sa, sb; };     // qb: image entry of the segment's first cycle
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
         Gat g;
 #pragma unroll
         for (int e = 0; e < E; ++e) {                // unconditional: idle lanes repeat the segment's first cycle
-            const int idx = r16 + 16 * e;
+            const int idx = r16 + LPS * e;
             const uint32_t p = xb.pk[r.qb + (idx < r.cnt ? idx : 0)];
             int si = r.rbi + (int)(p & 0x7FFFu), sj = r.rbj + (int)((p >> 16) & 0x7FFFu);
             if (a.ablate & 1) { si = lane; sj = lane; }     // diagnostics: gathers that always hit L1
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
         if (__ballot(cnt > 0) != 0ull && !(a.ablate & 64)) {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const int idx = r16 + 16 * e;
+                const int idx = r16 + LPS * e;
                 const bool ok = idx < cnt;
                 const int q = r0.qb + idx;
                 uint32_t p = 0; double w = 0.0, d = 0.0;
@@ -532,10 +534,10 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
                 ws[e] = g;
                 part += ok ? g * nv : 0.0;
             }
-            const double dot = group16_sum(part);                                                    // :199-201
+            const double dot = group_sum<LPS>(part);                                                    // :199-201
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const int q = r0.qb + r16 + 16 * e;
+                const int q = r0.qb + r16 + LPS * e;
                 const double g = ws[e] - dot * nv;
                 ws[e] = ((okm >> e) & 1u) ? apply_step<STEP>(a.st, xc.w[q], g, (int64_t)a0 + q) : 0.0;   // :207
             }
@@ -547,8 +549,14 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
                 double sp = 0.0;
 #pragma unroll
                 for (int e = 0; e < E; ++e) sp += ((act >> e) & 1u) ? ws[e] : 0.0;
-                s1v = group16_sum(sp) - 1.0;
-                na = max(group16_sum((int)__popc(act)), 1);
+                s1v = group_sum<LPS>(sp) - 1.0;
+                if (LPS == 16) na = max(group16_sum((int)__popc(act)), 1);
+                else {                                 // wider groups: count by ballots (scalar popcounts)
+                    na = 0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) na += group_count<LPS>((act >> e) & 1u, lane);
+                    na = max(na, 1);
+                }
                 const double nad = (double)na;
                 uint32_t keep = 0;
 #pragma unroll
@@ -563,9 +571,9 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
             for (int e = 0; e < E; ++e) {
                 const double wn = fmax(ws[e] - T, 0.0);                                              // :224
                 ws[e] = wn;
-                if ((okm >> e) & 1u) sn += wn * xc.d[r0.qb + r16 + 16 * e];
+                if ((okm >> e) & 1u) sn += wn * xc.d[r0.qb + r16 + LPS * e];
             }
-            part = group16_sum(sn);                                                                  // :229
+            part = group_sum<LPS>(sn);                                                                  // :229
         }
         // gathers of chunk k+1 and records of chunk k+2 are consumed before this iteration's stores
         // (see the header); the gathers shrink to their sums
@@ -582,7 +590,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
         if (!(a.ablate & 128)) {
 #pragma unroll
             for (int e = 0; e < E; ++e)
-                if ((okm >> e) & 1u) a.w_new[(int64_t)a0 + r0.qb + r16 + 16 * e] = ws[e];
+                if ((okm >> e) & 1u) a.w_new[(int64_t)a0 + r0.qb + r16 + LPS * e] = ws[e];
             if (cnt > 0 && r16 == 0) {
                 chg_acc += fabs(part - c.g.So);                                                      // :232
                 a.S_new[r0.sa] = part; a.S_new[r0.sb] = part;
@@ -644,7 +652,7 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
     if (st->stop) return;
     extern __shared__ double acc[];                   // [4][stride_cols] doubles, then 2 ints per incident edge
     int* seg_base = (int*)(acc + 4 * stride_cols);
-    int* seg_cf = seg_base + stride_cols;             // n_both | n_i << 7 | n_jonly << 14 | (v is the smaller endpoint) << 31
+    int* seg_cf = seg_base + stride_cols;             // n_both | n_i << 9 | n_jonly << 18 | (v is the smaller endpoint) << 31
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int v = blockIdx.x; v < n; v += gridDim.x) {
         const int r0 = rowptr[v], deg = rowptr[v + 1] - r0;
@@ -666,7 +674,7 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
         for (int g0 = wv; 4 * g0 < deg; g0 += 4 * COLSUM_U) {      // groups of 4 consecutive segments, dealt to waves round-robin
             // pieces 0 and 1 (contributing cycles 0..31 of each segment) are loaded together;
             // segments with more take further rounds
-            for (int round = 0; round < 2; ++round) {
+            for (int round = 0; round < MAX_SEG_CYCLES / 32; ++round) {
                 uint32_t pv[2 * COLSUM_U]; double wvv[2 * COLSUM_U]; uint32_t sh[COLSUM_U];
                 bool more = false;
 #pragma unroll
@@ -675,7 +683,7 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
                     pv[2 * u] = 0; pv[2 * u + 1] = 0; wvv[2 * u] = 0.0; wvv[2 * u + 1] = 0.0; sh[u] = 16;
                     if (tt < deg) {
                         const uint32_t cf = (uint32_t)seg_cf[tt];
-                        const int n_both = cf & 0x7Fu, n_i = (cf >> 7) & 0x7Fu, n_jo = (cf >> 14) & 0x7Fu;
+                        const int n_both = cf & 0x1FFu, n_i = (cf >> 9) & 0x1FFu, n_jo = (cf >> 18) & 0x1FFu;
                         const bool v_is_i = cf & 0x80000000u;
                         sh[u] = v_is_i ? 0u : 16u;
                         const int nact = v_is_i ? n_i : n_both + n_jo;
@@ -743,7 +751,7 @@ __global__ __launch_bounds__(256) void k_layout_node(const int32_t* cum, const i
 // the two mirror-present bits from the selection thresholds of the partner edges -- cycle (ik;j)
 // was sampled iff (key(e_ik, j), j) <= (tau, ktau) of edge {i,k} -- and does the within-segment
 // re-ordering [both mirrors | (ik;j) only | (jk;i) only | none] in the wave (stable: ascending k
-// inside a class, exactly like the host path).  Segments have <= 64 cycles.
+// inside a class, exactly like the host path).  Segments have <= MAX_SEG_CYCLES cycles (pieces of 64).
 __global__ __launch_bounds__(256) void k_layout_node_dev(const int32_t* cum, const int32_t* src_start, const int32_t* pos_edge,
                                                          const int32_t* ind_i, const int32_t* ind_j, const int32_t* nat_k,
                                                          const int32_t* poe, const unsigned long long* tau, const int32_t* ktau,
@@ -753,48 +761,66 @@ __global__ __launch_bounds__(256) void k_layout_node_dev(const int32_t* cum, con
     const int lane = threadIdx.x & 63;
     const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * 256) >> 6;
+    constexpr int NP = MAX_SEG_CYCLES / 64;            // pieces of 64 cycles per segment
     for (int64_t l = wid; l < m_pos; l += nw) {
         const int base = cum[l], cnt = cum[l + 1] - base, src = src_start[l];
         const int e = pos_edge[l], i = ind_i[e], j = ind_j[e];
         const int ri = rowptr[i], di = rowptr[i + 1] - ri, rj = rowptr[j], dj = rowptr[j + 1] - rj;
         double A[9];
         for (int t = 0; t < 9; ++t) A[t] = rij[9 * (int64_t)e + t];
-        const bool on = lane < cnt;
-        int k = 0, xi = 0, xj = 0, eik = e, ejk = e;
-        bool fi = false, fj = false;
-        if (on) {
-            k = nat_k[(int64_t)src + lane];
-            // idx_i(k), idx_j(k): positions of k in rows i and j = rank of its bit in the adjacency bitmaps
-            const size_t wi = (size_t)i * words + (k >> 6), wj = (size_t)j * words + (k >> 6);
-            const unsigned long long below = (1ull << (k & 63)) - 1ull;
-            xi = min((int)(rank[wi] + __popcll(bits[wi] & below)), max(di - 1, 0));
-            xj = min((int)(rank[wj] + __popcll(bits[wj] & below)), max(dj - 1, 0));
-            eik = adj_eid[ri + xi]; ejk = adj_eid[rj + xj];
-            const int lik = poe[eik], ljk = poe[ejk];             // both edges lie on the triangle {i,j,k}: they have cycles
-            if (lik >= 0) {
-                const unsigned long long key = d_sample_key(seed, (uint64_t)eik, (uint64_t)j), th = tau[lik];
-                fi = key < th || (key == th && j <= ktau[lik]);                                // IKJ_appears (:113)
+        // pass 1: per cycle the packed word, the two partner edges and its class; class sizes per piece
+        uint32_t word[NP]; int eik[NP], ejk[NP], kk[NP], cls[NP];
+        unsigned long long cm[NP][4];
+        int ncls[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) {
+            const int t = pc * 64 + lane;
+            const bool on = t < cnt;
+            int k = 0, xi = 0, xj = 0, ei2 = e, ej2 = e;
+            bool fi = false, fj = false;
+            if (on) {
+                k = nat_k[(int64_t)src + t];
+                // idx_i(k), idx_j(k): positions of k in rows i and j = rank of its bit in the adjacency bitmaps
+                const size_t wi = (size_t)i * words + (k >> 6), wj = (size_t)j * words + (k >> 6);
+                const unsigned long long below = (1ull << (k & 63)) - 1ull;
+                xi = min((int)(rank[wi] + __popcll(bits[wi] & below)), max(di - 1, 0));
+                xj = min((int)(rank[wj] + __popcll(bits[wj] & below)), max(dj - 1, 0));
+                ei2 = adj_eid[ri + xi]; ej2 = adj_eid[rj + xj];
+                const int lik = poe[ei2], ljk = poe[ej2];         // both edges lie on the triangle {i,j,k}: they have cycles
+                if (lik >= 0) {
+                    const unsigned long long key = d_sample_key(seed, (uint64_t)ei2, (uint64_t)j), th = tau[lik];
+                    fi = key < th || (key == th && j <= ktau[lik]);                            // IKJ_appears (:113)
+                }
+                if (ljk >= 0) {
+                    const unsigned long long key = d_sample_key(seed, (uint64_t)ej2, (uint64_t)i), th = tau[ljk];
+                    fj = key < th || (key == th && i <= ktau[ljk]);                            // JKI_appears (:124)
+                }
             }
-            if (ljk >= 0) {
-                const unsigned long long key = d_sample_key(seed, (uint64_t)ejk, (uint64_t)i), th = tau[ljk];
-                fj = key < th || (key == th && i <= ktau[ljk]);                                // JKI_appears (:124)
-            }
+            word[pc] = (uint32_t)xi | (fi ? 1u : 0u) << 15 | (uint32_t)xj << 16 | (fj ? 1u : 0u) << 31;
+            eik[pc] = ei2; ejk[pc] = ej2; kk[pc] = k;
+            cls[pc] = !on ? 4 : fi ? (fj ? 0 : 1) : (fj ? 2 : 3);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { cm[pc][c] = __ballot(cls[pc] == c); ncls[c] += __popcll(cm[pc][c]); }
         }
-        const int cls = !on ? 4 : fi ? (fj ? 0 : 1) : (fj ? 2 : 3);
+        if (lane == 0) seg_counts[l] = (uint32_t)ncls[0] | (uint32_t)(ncls[0] + ncls[1]) << 9 | (uint32_t)ncls[2] << 18;
+        // pass 2: stable placement (class, then natural order) and the cycle inconsistency
+        const int cbase[4] = {0, ncls[0], ncls[0] + ncls[1], ncls[0] + ncls[1] + ncls[2]};
         const unsigned long long lt = (1ull << lane) - 1ull;
-        const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
-        const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2);
-        int o = 0;
-        if (cls == 0) o = __popcll(m0 & lt);
-        else if (cls == 1) o = n0 + __popcll(m1 & lt);
-        else if (cls == 2) o = n0 + n1 + __popcll(m2 & lt);
-        else if (cls == 3) o = n0 + n1 + n2 + __popcll(m3 & lt);
-        if (lane == 0) seg_counts[l] = (uint32_t)n0 | (uint32_t)(n0 + n1) << 7 | (uint32_t)n2 << 14;
-        if (on) {
-            pk[(int64_t)base + o] = (uint32_t)xi | (fi ? 1u : 0u) << 15 | (uint32_t)xj << 16 | (fj ? 1u : 0u) << 31;
-            seg_perm[(int64_t)base + o] = (uint8_t)lane;
-            const double tr = cycle_trace(A, rij + 9 * (int64_t)ejk, !(j < k), rij + 9 * (int64_t)eik, !(k < i));
-            S0[(int64_t)base + o] = abs_acos_ext((tr - 1.0) / 2.0) / M_PI;
+        int seen[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) {
+            if (pc * 64 >= cnt) break;                 // wave-uniform
+            const int c = cls[pc];
+            if (c < 4) {
+                const int o = cbase[c] + seen[c] + __popcll(cm[pc][c] & lt);
+                const int k = kk[pc];
+                pk[(int64_t)base + o] = word[pc];
+                seg_perm[(int64_t)base + o] = (uint8_t)(pc * 64 + lane);
+                const double tr = cycle_trace(A, rij + 9 * (int64_t)ejk[pc], !(j < k), rij + 9 * (int64_t)eik[pc], !(k < i));
+                S0[(int64_t)base + o] = abs_acos_ext((tr - 1.0) / 2.0) / M_PI;
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2) seen[c2] += __popcll(cm[pc][c2]);
         }
     }
 }
@@ -986,7 +1012,8 @@ struct desc_pgd {
     int64_t n = 0, m = 0, m_pos = 0, m_cycle = 0;
     int32_t max_cnt = 0, n_sample = 0, max_deg = 0;
     int variant = VARIANT_GATHER;
-    int G = 64;                 // lanes per segment; 0 = big fallback (gather variant only)
+    int G = 64;                 // gather variant: lanes per segment (0 = big fallback); node variant: cycles per lane
+    int lps = 16;               // node variant: lanes per segment
     int grid = 0;               // sweep grid (multiple of 8)
     int obj_grid = 0;
     int colsum_grid = 0, colsum_stride = 0;
@@ -1117,10 +1144,12 @@ void launch_gather(desc_pgd* h, const SweepArgs& a) {
 template <int STEP>
 void launch_node(desc_pgd* h, const NodeSweepArgs& a) {
     dim3 grid(h->grid), block(SWEEP_THREADS);
-    switch (h->G) {              // G = cycles per lane (E) in the node variant
-        case 1: hipLaunchKernelGGL((k_sweep_node<1, STEP>), grid, block, 0, h->stream, a); break;
-        case 2: hipLaunchKernelGGL((k_sweep_node<2, STEP>), grid, block, 0, h->stream, a); break;
-        default: hipLaunchKernelGGL((k_sweep_node<4, STEP>), grid, block, 0, h->stream, a); break;
+    switch (h->lps * 8 + h->G) {              // lps lanes per segment, G = cycles per lane (E)
+        case 16 * 8 + 1: hipLaunchKernelGGL((k_sweep_node<16, 1, STEP>), grid, block, 0, h->stream, a); break;
+        case 16 * 8 + 2: hipLaunchKernelGGL((k_sweep_node<16, 2, STEP>), grid, block, 0, h->stream, a); break;
+        case 16 * 8 + 4: hipLaunchKernelGGL((k_sweep_node<16, 4, STEP>), grid, block, 0, h->stream, a); break;
+        case 32 * 8 + 4: hipLaunchKernelGGL((k_sweep_node<32, 4, STEP>), grid, block, 0, h->stream, a); break;
+        default: hipLaunchKernelGGL((k_sweep_node<64, 4, STEP>), grid, block, 0, h->stream, a); break;
     }
 }
 
@@ -1277,7 +1306,7 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
     for (int64_t q = 0; q < mp;) {     // chunks: <= CHUNK_CAP cycles and <= CHUNK_SEG segments
         int64_t e = q;
         while (e < mp && e - q < max_seg && P.cum2[e + 1] - P.cum2[q] <= CHUNK_CAP) ++e;
-        q = e;                          // max_cnt <= 64 <= CHUNK_CAP: always advances
+        q = e;                          // max_cnt <= MAX_SEG_CYCLES <= CHUNK_CAP: always advances
         P.chunk_seg.push_back((int32_t)q);
     }
     const int64_t nch = (int64_t)P.chunk_seg.size() - 1;
@@ -1299,7 +1328,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     };
     int rc;
     NodePlan P;
-    if ((rc = make_node_plan(prob, s, h->max_deg, h->world, CHUNK_SEG, P))) return rc;
+    if ((rc = make_node_plan(prob, s, h->max_deg, h->world, h->max_cnt <= 64 ? 32 : h->max_cnt <= 128 ? 16 : 8, P))) return rc;
     h->band = P.band;
     lap("plan");
     const std::vector<int32_t>& cum2 = P.cum2;
@@ -1361,7 +1390,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     // the cycles are stored [both mirrors sampled | (ik;j) only | (jk;i) only | none] (ascending k
     // within a class): the column-sum pass then reads only the cycles that contribute
     // (a fraction ~n_sample/codeg of them), the per-segment arithmetic is order independent.
-    kf.assign((size_t)mcl, 0u); seg_perm.assign((size_t)mcl, 0); seg_counts.assign((size_t)mp, 0u);   // counts: n_both | n_i << 7 | n_jonly << 14
+    kf.assign((size_t)mcl, 0u); seg_perm.assign((size_t)mcl, 0); seg_counts.assign((size_t)mp, 0u);   // counts: n_both | n_i << 9 | n_jonly << 18
     host_parallel(nsl, [&](int64_t a, int64_t b) {
         for (int64_t q = h->seg_lo + a; q < h->seg_lo + b; ++q) {
             const int64_t src = src_start[q], dst = cum_loc[q], cnt = cum2[q + 1] - cum2[q];
@@ -1374,7 +1403,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
                 kf[dst + o] = (uint32_t)s->k[src + t] | (s->ikj[src + t] >= 0 ? 1u << 30 : 0u) | (s->jki[src + t] >= 0 ? 1u << 31 : 0u);
                 seg_perm[dst + o] = (uint8_t)t;
             }
-            seg_counts[q] = (uint32_t)n_cls[0] | (uint32_t)(n_cls[0] + n_cls[1]) << 7 | (uint32_t)n_cls[2] << 14;
+            seg_counts[q] = (uint32_t)n_cls[0] | (uint32_t)(n_cls[0] + n_cls[1]) << 9 | (uint32_t)n_cls[2] << 18;
         }
     });
     adj_seg.resize((size_t)2 * m);
@@ -1455,11 +1484,12 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     h->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     lap("upload");
 
-    h->G = h->max_cnt <= 16 ? 1 : h->max_cnt <= 32 ? 2 : 4;   // cycles per lane, 16 lanes per segment
+    // lanes per segment x cycles per lane >= longest segment
+    h->lps = h->max_cnt <= 64 ? 16 : h->max_cnt <= 128 ? 32 : 64;
+    h->G = h->max_cnt <= 16 ? 1 : h->max_cnt <= 32 ? 2 : 4;
     {   // persistent grid: exactly the workgroups that are co-resident (registers / LDS decide)
         int per_cu = 0, ncu = 256;
-        const void* kfn = h->G == 1 ? (const void*)k_sweep_node<1, DESC_STEP_CONSTANT> : h->G == 2 ? (const void*)k_sweep_node<2, DESC_STEP_CONSTANT>
-                        : (const void*)k_sweep_node<4, DESC_STEP_CONSTANT>;
+        const void* kfn = (const void*)k_sweep_node<16, 4, DESC_STEP_CONSTANT>;    // the largest-register instance
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, SWEEP_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
@@ -1475,7 +1505,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
             DESC_HIP(hipFuncSetAttribute((const void*)k_colsum_node, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     char nm[64];
-    snprintf(nm, sizeof nm, "k_sweep_node<%d,", h->G);
+    snprintf(nm, sizeof nm, "k_sweep_node<%d,%d,", h->lps, h->G);
     h->kname = nm;
 
     lap("occupancy/attrs");
@@ -1586,7 +1616,7 @@ int desc_pgd_create_shard(const desc_problem* prob, const desc_structure* s, int
 
     // variant: NODE unless the packed per-cycle word or the LDS column copies do not fit
     const int forced = env_int("DESC_DEBUG_VARIANT", 0);
-    const bool node_ok = h->max_deg < 32768 && (size_t)(h->max_deg + 2) * 40 <= 150 * 1024 && h->max_cnt <= 64 && h->m_pos > 0;
+    const bool node_ok = h->max_deg < 32768 && (size_t)(h->max_deg + 2) * 40 <= 150 * 1024 && h->max_cnt <= MAX_SEG_CYCLES && h->m_pos > 0;
     h->variant = (forced == VARIANT_GATHER || !node_ok) ? VARIANT_GATHER : VARIANT_NODE;
     if (world > 1 && h->variant != VARIANT_NODE) {
         rc = fail(DESC_ERR_INVALID, "multi-GPU sharding needs the node layout (max degree < 2^15, segments <= 64 cycles)");

@@ -76,13 +76,61 @@ def test_nonuniform_self_consistent(lib, oracle, variant):
     check(out, ref, s0, S0)
 
 
-def test_long_segments_fallback(lib, oracle):
-    """codegree ~ 280 -> n_sample = 70 > 64: multi-pass wave-per-edge kernel."""
+@pytest.mark.parametrize("variant", ["node", "gather"])
+def test_long_segments(lib, oracle, variant):
+    """codegree ~ 280 -> n_sample = 70 > 64: 32 lanes per segment in the node layout, the multi-pass
+    wave-per-edge kernel in the gather layout."""
     mo, nn, ii, jj, rij = make_problem("uniform", n=310, p=0.95, q=0.2, sigma=0.1, seed=7)
     st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=3, iters=25, lr=0.01)
     assert st["n_sample"] > 64
-    arrays, s0, out = run_gpu(lib, nn, ii, jj, rij, c_params(25, lr=0.01, seed=3))
-    assert "big" in out["kernel"]
+    arrays, s0, out = run_gpu(lib, nn, ii, jj, rij, c_params(25, lr=0.01, seed=3), variant=variant)
+    assert ("node<32,4" in out["kernel"]) if variant == "node" else ("big" in out["kernel"])
+    check(out, ref, s0, S0)
+
+
+@pytest.mark.parametrize("where", ["host", "device"])
+@pytest.mark.parametrize("n,p,nmin,kind,kern", [(150, 0.9, 100, 0, "node<32,4"), (260, 0.92, 250, 0, "node<64,4"), (260, 0.92, 250, 2, "node<64,4"),
+                                                (330, 0.97, 30, 1, "node<32,4"), (200, 0.8, 128, 0, "node<32,4")])
+def test_segments_up_to_256_cycles(lib, oracle, n, p, nmin, kind, kern, where):
+    """Segments of 65..256 cycles stay in the node layout (32 / 64 lanes per segment, 4 cycles per lane),
+    with and without sampling, host- and device-built structure."""
+    mo, nn, ii, jj, rij = make_problem("uniform", n=n, p=p, q=0.25, sigma=0.1, seed=n)
+    st = oracle.build_structure(nn, ii, jj, seed=9, n_sample_min=nmin)
+    S0 = oracle.cycle_d(ii, jj, rij.reshape(-1, 9), st)
+    step = dict(step_kind=kind, lr=0.01)
+    ref = oracle.pgd_run(st, S0, 30, **step)
+    mx = int(np.diff(st["cum_ind"]).max())
+    assert 64 < mx <= 256
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    dst = lib.Structure.build(prob, nmin, 9, lib.BUILD_DEVICE if where == "device" else lib.BUILD_HOST, 0)
+    solver = lib.Solver(prob, dst, 0)
+    try:
+        assert kern in solver.kernel_name()
+        s0 = solver.s0()
+        out = solver.run(c_params(30, seed=9, **step), want_w=True)
+    finally:
+        solver.destroy()
+    assert_structure_equal(dst.arrays(), st)
+    dst.free()
+    check(out, ref, s0, S0, tol=1e-9 if kind == 2 else TOL)
+
+
+def test_segments_longer_than_256_fall_back(lib, oracle):
+    """> 256 cycles per segment: gather layout, multi-pass kernel."""
+    mo, nn, ii, jj, rij = make_problem("uniform", n=330, p=0.97, q=0.2, sigma=0.1, seed=3)
+    st = oracle.build_structure(nn, ii, jj, seed=1, n_sample_min=300)
+    assert int(np.diff(st["cum_ind"]).max()) > 256
+    S0 = oracle.cycle_d(ii, jj, rij.reshape(-1, 9), st)
+    ref = oracle.pgd_run(st, S0, 10, lr=0.01)
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    dst = lib.Structure.build(prob, 300, 1, lib.BUILD_HOST, 0)
+    solver = lib.Solver(prob, dst, 0)
+    try:
+        assert "big" in solver.kernel_name()
+        s0 = solver.s0()
+        out = solver.run(c_params(10, seed=1), want_w=True)
+    finally:
+        solver.destroy(); dst.free()
     check(out, ref, s0, S0)
 
 

@@ -23,7 +23,7 @@ while time.time() < t_end:
     kind = "uniform" if rng.random() < 0.7 else "nonuniform"
     n = int(rng.choice([5, 8, 13, 21, 34, 55, 89, 144, 233, 300]))
     p = float(rng.choice([0.08, 0.15, 0.3, 0.5, 0.7, 0.95]))
-    nmin = int(rng.choice([1, 2, 5, 16, 17, 30, 33, 64]))
+    nmin = int(rng.choice([1, 2, 5, 16, 17, 30, 33, 64, 65, 100, 129, 200, 256, 300]))
     sk = int(rng.choice([0, 0, 1, 2]))
     iters = int(rng.choice([1, 2, 7, 40]))
     seed = int(rng.integers(0, 1 << 30))
@@ -56,7 +56,7 @@ while time.time() < t_end:
         for key in STRUCT_KEYS:
             assert np.array_equal(a[key], st[key]), "structure " + key
         assert out["iters_run"] == ref["iters_run"], "iters_run %d vs %d" % (out["iters_run"], ref["iters_run"])
-        tol = 1e-9 if sk == 2 else 1e-10
+        tol = (1e-8 if lr >= 0.1 else 1e-9) if sk == 2 else 1e-10     # Adam divides by sqrt(v) + 1e-8: round-off is amplified
         e1 = float(np.abs(out["S_vec"] - ref["S_vec"]).max()) if nn else 0.0
         e2 = float(np.abs(out["w"] - ref["w"]).max()) if st["m_cycle"] else 0.0
         worst = max(worst, e1, e2)
