@@ -64,6 +64,27 @@ __global__ __launch_bounds__(256) void k_cemp_round(const int32_t* pos_edge, con
     const int lane = threadIdx.x & 63;
     const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
     for (int64_t l = wid; l < m_pos; l += nw) {
+        if (nsample <= 4 * 64) {                       // weights stay in registers: one pass over the samples
+            double wr[4] = {0.0, 0.0, 0.0, 0.0}, dr[4] = {0.0, 0.0, 0.0, 0.0};
+            double wsum = 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = lane + 64 * u;
+                if (s < nsample) {
+                    const int64_t c = l * nsample + s;
+                    wr[u] = exp(-beta * (S_old[e_ki[c]] + S_old[e_jk[c]]));      // :118-120
+                    dr[u] = S0[c];
+                    wsum += wr[u];
+                }
+            }
+            wsum = group_sum<64>(wsum);
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (lane + 64 * u < nsample) acc += (wr[u] / wsum) * dr[u];   // :122-125
+            acc = group_sum<64>(acc);
+            if (lane == 0) S_new[pos_edge[l]] = acc;
+            continue;
+        }
         double wsum = 0.0;
         for (int s = lane; s < nsample; s += 64) {
             const int64_t c = l * nsample + s;
