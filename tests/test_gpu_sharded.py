@@ -14,11 +14,11 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
 
-def _emulate(lib, nn, ii, jj, rij, p, world, check_every=5):
+def _emulate(lib, nn, ii, jj, rij, p, world, check_every=5, where=None, nmin=30):
     import torch
     from desc_amd.sharded import HipShard
     prob = lib.ProblemArrays(nn, ii, jj, rij)
-    st = lib.Structure.build(prob, 30, p.seed, lib.BUILD_HOST, 0)
+    st = lib.Structure.build(prob, nmin, p.seed, lib.BUILD_HOST if where is None else where, 0)
     stream = torch.cuda.Stream(torch.device("cuda", 0))      # one stream for every emulated rank
     shards = [HipShard(prob, st, 0, r, world, stream=stream) for r in range(world)]
     st.free()
@@ -124,3 +124,19 @@ def test_two_processes_one_gpu_gloo(oracle):
         assert it == ref["iters_run"]
         assert np.abs(S - ref["S_vec"]).max() <= TOL
         assert np.allclose(obj, ref["obj"], rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("n,p,nmin", [(150, 0.6, 30), (150, 0.9, 100)])
+def test_sharded_emulated_device_built_structure(lib, oracle, world, n, p, nmin):
+    """The bench's N > 1 configuration: structure built on the device, laid out per shard in place
+    (segment ranges of the ranks, 16 and 32 lanes per segment)."""
+    mo, nn, ii, jj, rij = make_problem("uniform", n=n, p=p, q=0.2, sigma=0.1, seed=6)
+    st = oracle.build_structure(nn, ii, jj, seed=4, n_sample_min=nmin)
+    S0 = oracle.cycle_d(ii, jj, rij.reshape(-1, 9), st)
+    ref = oracle.pgd_run(st, S0, 30, lr=0.01)
+    outs, segs = _emulate(lib, nn, ii, jj, rij, c_params(30, lr=0.01, seed=4), world, where=lib.BUILD_DEVICE, nmin=nmin)
+    for o in outs:
+        assert o["iters_run"] == ref["iters_run"]
+        assert np.abs(o["S_vec"] - ref["S_vec"]).max() <= TOL
+        assert np.allclose(o["obj"], ref["obj"], rtol=1e-12, atol=1e-9)
