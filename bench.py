@@ -81,8 +81,15 @@ def cpu_baseline(nn, ii, jj, rij, arrays, budget_s=20.0, max_iters=50):
     t = time.perf_counter()
     ref = O.pgd_run(st, S0, iters, lr=0.01, patience=1 << 30)
     dt = time.perf_counter() - t
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
     return dict(value=iters / dt, unit="iters/s", cores=O.num_threads(), kind="port",
-                sample=f"{iters} PGD iterations of the same workload (oracle/desc_oracle.c, OpenMP)"), ref, iters
+                sample=f"{iters} PGD iterations of the same workload (oracle/desc_oracle.c, OpenMP)",
+                host_cpus=os.cpu_count(), cpu_model=model), ref, iters
 
 
 def main():
