@@ -1,0 +1,137 @@
+"""Known-answer tests that pin the NumPy restatements of the "next" rows:
+Spectral / GCW / Rotation_Alignment, CEMP, and the DESC refinement tail.  The reference ships no
+fixtures for them either, so these are properties the MATLAB text implies: exact recovery on
+noise-free measurements, zero inconsistency on consistent cycles, quaternion round trips, the
+grounded incidence matrix, MATLAB's quantile definition."""
+import numpy as np
+import pytest
+
+from oracle.cemp_oracle import cemp_oracle
+from oracle.refine_oracle import Build_Amatrix, R2Q, Weighted_LAA, desc_refine_oracle, q2R
+from oracle.spectral_oracle import gcw_oracle, rotation_alignment, spectral_oracle
+
+
+def _rand_rot(rng):
+    U, _, Vt = np.linalg.svd(rng.standard_normal((3, 3)))
+    R = U @ Vt
+    if np.linalg.det(R) < 0:
+        U[:, -1] = -U[:, -1]; R = U @ Vt
+    return R
+
+
+def _clean_problem(n=12, p=0.6, seed=0):
+    """connected Erdos-Renyi graph with exact relative rotations R_ij = R_i R_j' (Uniform_Topology.m:48-51)."""
+    rng = np.random.default_rng(seed)
+    while True:
+        A = np.triu(rng.random((n, n)) < p, 1)
+        Ind = np.argwhere(A) + 1                                  # (i, j), i < j, 1-based, sorted by (i, j)
+        deg = np.bincount(Ind.reshape(-1) - 1, minlength=n)
+        if deg.min() >= 2:
+            break
+    R = np.stack([_rand_rot(rng) for _ in range(n)], axis=2)
+    Rij = np.stack([R[:, :, i - 1] @ R[:, :, j - 1].T for i, j in Ind], axis=2)
+    return Ind, Rij, R
+
+
+def test_spectral_recovers_noise_free_rotations():
+    Ind, Rij, R = _clean_problem()
+    R_est = spectral_oracle(Ind, Rij)
+    _, _, mean_err, med_err = rotation_alignment(R_est, R)
+    assert mean_err < 1e-5 and med_err < 1e-5                    # degrees
+    for i in range(R.shape[2]):                                  # every block is a proper rotation
+        assert abs(np.linalg.det(R_est[:, :, i]) - 1) < 1e-12
+        assert np.abs(R_est[:, :, i] @ R_est[:, :, i].T - np.eye(3)).max() < 1e-12
+
+
+def test_gcw_recovers_noise_free_rotations_and_downweights_bad_edges():
+    Ind, Rij, R = _clean_problem(seed=1)
+    m = Ind.shape[0]
+    R_est = gcw_oracle(Ind, Rij, np.full(m, 0.05))
+    assert rotation_alignment(R_est, R)[2] < 1e-5
+    # corrupt a few edges: with S_vec flagging them (s = 1 vs 1e-3) GCW still recovers the rotations
+    rng = np.random.default_rng(2)
+    bad = rng.choice(m, 4, replace=False)
+    Rc = Rij.copy()
+    for e in bad:
+        Rc[:, :, e] = _rand_rot(rng)
+    S = np.full(m, 1e-3); S[bad] = 1.0
+    assert rotation_alignment(gcw_oracle(Ind, Rc, S), R)[2] < 0.05
+    assert rotation_alignment(spectral_oracle(Ind, Rc), R)[2] > 0.5      # the unweighted solve is visibly perturbed
+
+
+def test_rotation_alignment_removes_the_gauge():
+    rng = np.random.default_rng(3)
+    R = np.stack([_rand_rot(rng) for _ in range(7)], axis=2)
+    G = _rand_rot(rng)
+    R_est = np.stack([R[:, :, i] @ G for i in range(7)], axis=2)         # same rotations in another global frame
+    R_out, R_align, mean_err, med_err = rotation_alignment(R_est, R)
+    assert mean_err < 1e-5 and np.abs(R_align - G.T).max() < 1e-10 and np.abs(R_out - R).max() < 1e-10
+
+
+def test_cemp_is_zero_on_consistent_cycles_and_one_without_cycles():
+    Ind, Rij, R = _clean_problem(n=10, p=0.7, seed=4)
+    # add a pendant edge (no triangle): CEMP.m:103 forces its estimate to 1
+    n = int(Ind.max())
+    Ind2 = np.vstack([Ind, [1, n + 1]])
+    Ind2 = Ind2[np.lexsort((Ind2[:, 1], Ind2[:, 0]))]
+    Rn = _rand_rot(np.random.default_rng(5))
+    Rs = np.concatenate([R, Rn[:, :, None]], axis=2)
+    Rij2 = np.stack([Rs[:, :, i - 1] @ Rs[:, :, j - 1].T for i, j in Ind2], axis=2)
+    S = cemp_oracle(Ind2, Rij2, 6, 2.0 ** np.arange(6), 20, seed=0)
+    pend = np.flatnonzero((Ind2[:, 0] == 1) & (Ind2[:, 1] == n + 1))[0]
+    assert S[pend] == 1.0
+    assert np.abs(np.delete(S, pend)).max() < 1e-7              # acos near 1 loses half the digits
+
+
+def test_cemp_single_corrupted_edge_is_ranked_worst():
+    Ind, Rij, R = _clean_problem(n=14, p=0.8, seed=6)
+    Rc = Rij.copy()
+    Rc[:, :, 5] = _rand_rot(np.random.default_rng(7))
+    S = cemp_oracle(Ind, Rc, 6, 2.0 ** np.arange(6), 30, seed=1)
+    assert np.argmax(S) == 5 and S[5] > 0.2
+    others = np.delete(S, 5)
+    assert others.max() < 0.5 * S[5]
+
+
+def test_quaternion_round_trip_and_incidence_matrix():
+    rng = np.random.default_rng(8)
+    R = np.stack([_rand_rot(rng) for _ in range(20)], axis=2)
+    q = R2Q(R)
+    assert np.abs(np.linalg.norm(q, axis=1) - 1).max() < 1e-12
+    for i in range(20):
+        assert np.abs(q2R(q[i]) - R[:, :, i]).max() < 1e-10
+    assert np.array_equal(q2R(np.array([1.0, 0, 0, 0])), np.eye(3))
+    A = Build_Amatrix(np.array([[1, 1, 2], [2, 3, 3]]))          # edges (1,2), (1,3), (2,3); node 1 grounded
+    assert np.array_equal(A, np.array([[1.0, 0], [0, 1], [-1, 1]]))
+
+
+def test_weighted_laa_fixed_point_and_refinement_on_clean_data():
+    Ind, Rij, R = _clean_problem(n=9, p=0.7, seed=9)
+    I = Ind.T
+    A = Build_Amatrix(I)
+    # gauge: the refinement keeps node 1 fixed; start at the exact solution expressed in that gauge
+    Q = R2Q(R)
+    QQ = R2Q(np.transpose(Rij, (1, 0, 2)))
+    Q2, W, B, score = Weighted_LAA(I, Q, QQ, A, np.ones(I.shape[1]))
+    assert score < 1e-7 and np.abs(B).max() < 1e-7                # zero residual: the exact solution is a fixed point
+    # perturbed start: the full tail converges back
+    rng = np.random.default_rng(10)
+    Rp = np.stack([R[:, :, i] @ _small_rot(rng) for i in range(9)], axis=2)
+    R_est, iters, score = desc_refine_oracle(Ind, Rij, np.full(Ind.shape[0], 0.05), Rp)
+    assert rotation_alignment(R_est, R)[2] < 0.05
+
+
+def _small_rot(rng, scale=0.05):
+    v = scale * rng.standard_normal(3)
+    th = np.linalg.norm(v)
+    K = np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]]) / th
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def test_matlab_quantile_definition():
+    # MATLAB quantile: piecewise linear through ((k - 0.5)/n, x_(k)), clamped (DESC.m:276,301)
+    x = np.array([4.0, 1.0, 3.0, 2.0])
+    assert np.quantile(x, 0.5, method="hazen") == 2.5
+    assert np.quantile(x, 1.0, method="hazen") == 4.0
+    assert np.quantile(np.arange(1.0, 6.0), 0.3, method="hazen") == 2.0
+    assert np.isclose(np.quantile(np.arange(1.0, 6.0), 0.8, method="hazen"), 4.5)
