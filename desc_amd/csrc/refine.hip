@@ -286,18 +286,10 @@ extern "C" int desc_refine_run(const desc_problem* prob, const double* s_vec, co
             adj[fill[j]] = i; eid[fill[j]] = (int32_t)e; sgn[fill[j]++] = +1;
         }
     }
-    // initial weights (DESC.m:274-282): quantile(S_vec, 1) = max -> nothing is truncated yet
-    std::vector<double> wts((size_t)m), tmp;
-    {
-        tmp.assign(s_vec, s_vec + m);
-        const double thresh = matlab_quantile(tmp, 1.0);
-        for (int64_t e = 0; e < m; ++e) {
-            double w = 1.0 / std::pow(s_vec[e], 0.75);
-            if (w > weight_max) w = weight_max;
-            if (s_vec[e] > thresh) w = weight_min;
-            wts[e] = w;
-        }
-    }
+    // initial weights (DESC.m:274-282): quantile(S_vec, 1) = max -> nothing is truncated yet; evaluated on
+    // the device by the same kernel as the re-weighting steps
+    double thresh0 = -INFINITY;
+    for (int64_t e = 0; e < m; ++e) thresh0 = std::max(thresh0, s_vec[e]);
     DevR D;
     int32_t *d_rowptr, *d_adj, *d_eid, *d_ii, *d_jj; int8_t* d_sgn;
     double *d_rij, *d_Rinit, *d_w, *d_S, *d_B, *d_RS, *d_rhs, *d_diag, *d_x, *d_r, *d_z, *d_p, *d_q, *d_Wv, *d_score, *d_Rout;
@@ -319,10 +311,10 @@ extern "C" int desc_refine_run(const desc_problem* prob, const double* s_vec, co
         DESC_HIP(hipMemcpy(d_ii, prob->ind_i, sizeof(int32_t) * m, hipMemcpyHostToDevice));
         DESC_HIP(hipMemcpy(d_jj, prob->ind_j, sizeof(int32_t) * m, hipMemcpyHostToDevice));
         DESC_HIP(hipMemcpy(d_rij, prob->rij, sizeof(double) * 9 * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_w, wts.data(), sizeof(double) * m, hipMemcpyHostToDevice));
         DESC_HIP(hipMemcpy(d_S, s_vec, sizeof(double) * m, hipMemcpyHostToDevice));
     }
     const int egrid = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (m + 255) / 256));
+    if (m) hipLaunchKernelGGL(k_weights, dim3(egrid), dim3(256), 0, 0, d_S, d_w, m, thresh0, weight_max, weight_min);
     const int ngrid = (int)std::max<int64_t>(1, std::min<int64_t>(512, (n + 255) / 256));
     const int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256));
     hipLaunchKernelGGL(k_r2q, dim3(ngrid), dim3(256), 0, 0, d_Rinit, d_Q, n, 0);            // Q = R2Q(R_init)        (DESC.m:270)
