@@ -65,6 +65,10 @@ int build_structure_host(const desc_problem* prob, int32_t n_sample_min, uint64_
 int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint64_t seed,
                            int32_t device, desc_structure* out);
 int validate_problem(const desc_problem* prob, bool need_rij);
+// CSR adjacency of the undirected graph (neighbours ascending, edge id per slot); Ind must be sorted by (i,j).
+// Multithreaded for large m; the result does not depend on the thread count.
+void build_csr(int64_t n, int64_t m, const int32_t* ii, const int32_t* jj, std::vector<int32_t>& rowptr, std::vector<int32_t>& adj,
+               std::vector<int32_t>& adj_eid);
 // device-resident structures (structure_device.hip)
 int structure_ensure_host(desc_structure* s);      // copy the per-cycle arrays to the host if they live on the device
 void structure_free_device(desc_structure* s);

@@ -274,18 +274,11 @@ extern "C" int desc_refine_run(const desc_problem* prob, const double* s_vec, co
     const double weight_max = 1e4, weight_min = 1e-4;    // DESC.m:280-281
 
     // CSR with edge ids and incidence signs
-    std::vector<int32_t> rowptr((size_t)n + 1, 0), adj((size_t)2 * m), eid((size_t)2 * m);
+    std::vector<int32_t> rowptr, adj, eid;
+    build_csr(n, m, prob->ind_i, prob->ind_j, rowptr, adj, eid);
     std::vector<int8_t> sgn((size_t)2 * m);
-    for (int64_t e = 0; e < m; ++e) { rowptr[prob->ind_i[e] + 1]++; rowptr[prob->ind_j[e] + 1]++; }
-    for (int64_t v = 0; v < n; ++v) rowptr[v + 1] += rowptr[v];
-    {
-        std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
-        for (int64_t e = 0; e < m; ++e) {
-            const int32_t i = prob->ind_i[e], j = prob->ind_j[e];
-            adj[fill[i]] = j; eid[fill[i]] = (int32_t)e; sgn[fill[i]++] = -1;      // Build_Amatrix.m:10: -1 at i, +1 at j
-            adj[fill[j]] = i; eid[fill[j]] = (int32_t)e; sgn[fill[j]++] = +1;
-        }
-    }
+    for (int64_t v = 0; v < n; ++v)                      // Build_Amatrix.m:10: -1 at the smaller endpoint i, +1 at j
+        for (int32_t t = rowptr[v]; t < rowptr[v + 1]; ++t) sgn[t] = v < adj[t] ? -1 : +1;
     // initial weights (DESC.m:274-282): quantile(S_vec, 1) = max -> nothing is truncated yet; evaluated on
     // the device by the same kernel as the re-weighting steps
     double thresh0 = -INFINITY;

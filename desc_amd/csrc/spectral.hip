@@ -257,10 +257,9 @@ extern "C" int desc_spectral_run(const desc_problem* prob, const double* weights
     if (max_iters <= 0) max_iters = 500;
 
     // block CSR: every edge in both endpoint rows (index part on the host, the 2m blocks are assembled on the device)
-    std::vector<int32_t> rowptr((size_t)n + 1, 0), adj((size_t)2 * m), adj_eid((size_t)2 * m);
+    std::vector<int32_t> rowptr, adj, adj_eid;             // (i,j) slot = R, (j,i) slot = R'
+    build_csr(n, m, prob->ind_i, prob->ind_j, rowptr, adj, adj_eid);
     std::vector<double> deg((size_t)n, 0.0);
-    for (int64_t e = 0; e < m; ++e) { rowptr[prob->ind_i[e] + 1]++; rowptr[prob->ind_j[e] + 1]++; }
-    for (int64_t v = 0; v < n; ++v) rowptr[v + 1] += rowptr[v];
     for (int64_t e = 0; e < m; ++e) {
         const double w = weights ? weights[e] : 1.0;
         if (!(w >= 0) || !std::isfinite(w)) return fail(DESC_ERR_INVALID, "weight %lld is not a finite non-negative number", (long long)e);
@@ -273,14 +272,6 @@ extern "C" int desc_spectral_run(const desc_problem* prob, const double* weights
         sigma = 1.0;                                        // spectrum of D^-1/2 A D^-1/2 lies in [-1,1]
     } else {
         for (int64_t v = 0; v < n; ++v) sigma = std::max(sigma, deg[v]);   // ||A||_2 <= max weighted degree (orthogonal blocks)
-    }
-    {
-        std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
-        for (int64_t e = 0; e < m; ++e) {
-            const int32_t i = prob->ind_i[e], j = prob->ind_j[e];
-            adj[fill[i]] = j; adj_eid[fill[i]++] = (int32_t)e;      // (i,j) = R, (j,i) = R'
-            adj[fill[j]] = i; adj_eid[fill[j]++] = (int32_t)e;
-        }
     }
     const int64_t rows = 3 * n;
     // deterministic start: hashed pseudo-random entries in [-1,1)

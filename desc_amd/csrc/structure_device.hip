@@ -291,18 +291,10 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
     s->n = n; s->m = m; s->dev = device; s->seed = seed;
 
     // CSR on the host (one pass; Ind is sorted by (i,j), so rows come out ascending)
-    std::vector<int32_t> rowptr((size_t)n + 1, 0), adj((size_t)2 * m), adj_eid((size_t)2 * m);
-    for (int64_t e = 0; e < m; ++e) { rowptr[prob->ind_i[e] + 1]++; rowptr[prob->ind_j[e] + 1]++; }
+    std::vector<int32_t> rowptr, adj, adj_eid;
+    build_csr(n, m, prob->ind_i, prob->ind_j, rowptr, adj, adj_eid);
     s->max_deg = 0;
-    for (int64_t v = 0; v < n; ++v) { s->max_deg = std::max(s->max_deg, rowptr[v + 1]); rowptr[v + 1] += rowptr[v]; }
-    {
-        std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
-        for (int64_t e = 0; e < m; ++e) {
-            const int32_t i = prob->ind_i[e], j = prob->ind_j[e];
-            adj[fill[i]] = j; adj_eid[fill[i]++] = (int32_t)e;
-            adj[fill[j]] = i; adj_eid[fill[j]++] = (int32_t)e;
-        }
-    }
+    for (int64_t v = 0; v < n; ++v) s->max_deg = std::max(s->max_deg, rowptr[v + 1] - rowptr[v]);
     lap("host csr");
     // device arrays that outlive this call are owned by the structure object (structure_free_device)
     auto keep = [&](auto** out, size_t count) -> int {
@@ -415,17 +407,8 @@ int build_cemp_samples_device(const desc_problem* prob, int32_t nsample, uint64_
     *m_pos = 0; *o_pos = *o_k = *o_ejk = *o_eki = nullptr;
     if ((double)n * (double)words * 12.0 > 64.0 * 1073741824.0) return fail(DESC_ERR_TOO_LARGE, "adjacency bitmaps do not fit the device budget");
     DESC_HIP(hipSetDevice(device));
-    std::vector<int32_t> rowptr((size_t)n + 1, 0), adj((size_t)2 * m), adj_eid((size_t)2 * m);
-    for (int64_t e = 0; e < m; ++e) { rowptr[prob->ind_i[e] + 1]++; rowptr[prob->ind_j[e] + 1]++; }
-    for (int64_t v = 0; v < n; ++v) rowptr[v + 1] += rowptr[v];
-    {
-        std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
-        for (int64_t e = 0; e < m; ++e) {
-            const int32_t i = prob->ind_i[e], j = prob->ind_j[e];
-            adj[fill[i]] = j; adj_eid[fill[i]++] = (int32_t)e;
-            adj[fill[j]] = i; adj_eid[fill[j]++] = (int32_t)e;
-        }
-    }
+    std::vector<int32_t> rowptr, adj, adj_eid;
+    build_csr(n, m, prob->ind_i, prob->ind_j, rowptr, adj, adj_eid);
     DevBuf D;
     int rc;
     int32_t *d_rowptr, *d_adj, *d_adj_eid, *d_ii, *d_jj, *d_codeg, *d_hist;

@@ -157,6 +157,59 @@ int build_cemp_samples_host(const desc_problem* prob, int32_t nsample, uint64_t 
     return DESC_OK;
 }
 
+void build_csr(int64_t n, int64_t m, const int32_t* ii, const int32_t* jj, std::vector<int32_t>& rowptr, std::vector<int32_t>& adj,
+               std::vector<int32_t>& adj_eid) {
+    rowptr.assign((size_t)n + 1, 0); adj.resize((size_t)2 * m); adj_eid.resize((size_t)2 * m);
+    unsigned hw = std::thread::hardware_concurrency();
+    int T = (int)std::min<int64_t>(std::max(1u, std::min(hw, 16u)), std::max<int64_t>(1, (int64_t)(16 << 20) / std::max<int64_t>(n, 1)));
+    if (m < (1 << 18)) T = 1;
+    if (T <= 1) {
+        // Edges are sorted by (i,j): a row receives its smaller neighbours (from edges (x,v), x<v)
+        // before its larger ones (edges (v,x)), each run ascending.
+        for (int64_t e = 0; e < m; ++e) { rowptr[ii[e] + 1]++; rowptr[jj[e] + 1]++; }
+        for (int64_t v = 0; v < n; ++v) rowptr[v + 1] += rowptr[v];
+        std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
+        for (int64_t e = 0; e < m; ++e) {
+            const int32_t i = ii[e], j = jj[e];
+            adj[fill[i]] = j; adj_eid[fill[i]++] = (int32_t)e;
+            adj[fill[j]] = i; adj_eid[fill[j]++] = (int32_t)e;
+        }
+        return;
+    }
+    // T contiguous chunks of edges; per chunk the number of edges ending (lo) / starting (up) at every node,
+    // turned into per-chunk start offsets inside the lower / upper part of each row: the same slots as the
+    // serial pass, whatever T is
+    std::vector<int32_t> lo((size_t)T * n, 0), up((size_t)T * n, 0), lowtot((size_t)n);
+    auto run = [&](auto&& body) {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back([=, &body]() { body(t, m * t / T, m * (t + 1) / T); });
+        for (auto& x : th) x.join();
+    };
+    run([&](int t, int64_t a, int64_t b) {
+        int32_t* l = &lo[(size_t)t * n]; int32_t* u = &up[(size_t)t * n];
+        for (int64_t e = a; e < b; ++e) { u[ii[e]]++; l[jj[e]]++; }
+    });
+    for (int64_t v = 0; v < n; ++v) {
+        int32_t accl = 0, accu = 0;
+        for (int t = 0; t < T; ++t) {
+            const int32_t cl = lo[(size_t)t * n + v], cu = up[(size_t)t * n + v];
+            lo[(size_t)t * n + v] = accl; up[(size_t)t * n + v] = accu;
+            accl += cl; accu += cu;
+        }
+        lowtot[v] = accl;
+        rowptr[v + 1] = rowptr[v] + accl + accu;
+    }
+    run([&](int t, int64_t a, int64_t b) {
+        int32_t* l = &lo[(size_t)t * n]; int32_t* u = &up[(size_t)t * n];
+        for (int64_t e = a; e < b; ++e) {
+            const int32_t i = ii[e], j = jj[e];
+            const int32_t pu = rowptr[i] + lowtot[i] + u[i]++, pl = rowptr[j] + l[j]++;
+            adj[pu] = j; adj_eid[pu] = (int32_t)e;
+            adj[pl] = i; adj_eid[pl] = (int32_t)e;
+        }
+    });
+}
+
 int validate_problem(const desc_problem* prob, bool need_rij) {
     if (!prob) return fail(DESC_ERR_INVALID, "problem is NULL");
     if (prob->n < 0 || prob->m < 0) return fail(DESC_ERR_INVALID, "negative n or m");
