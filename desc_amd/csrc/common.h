@@ -45,8 +45,8 @@ struct desc_structure {
     bool host_cycles = true;
     int dev = -1;
     int32_t *d_k = nullptr;
-    unsigned long long* d_tau = nullptr;      // m_pos
-    int32_t* d_ktau = nullptr;                // m_pos
+    unsigned long long* d_tau = nullptr;      // m, indexed by edge id (defined for edges with cycles)
+    int32_t* d_ktau = nullptr;                // m
     int32_t *d_rowptr = nullptr, *d_adj = nullptr, *d_adj_eid = nullptr;   // n+1, 2m, 2m
     int32_t *d_ii = nullptr, *d_jj = nullptr;                              // m
     int32_t *d_pos = nullptr, *d_cum = nullptr, *d_poe = nullptr;          // m_pos, m_pos+1, m (edge -> index in pos_edge, -1)

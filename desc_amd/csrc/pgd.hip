@@ -752,16 +752,16 @@ __global__ __launch_bounds__(256) void k_layout_node(const int32_t* cum, const i
 // was sampled iff (key(e_ik, j), j) <= (tau, ktau) of edge {i,k} -- and does the within-segment
 // re-ordering [both mirrors | (ik;j) only | (jk;i) only | none] in the wave (stable: ascending k
 // inside a class, exactly like the host path).  Segments have <= MAX_SEG_CYCLES cycles (pieces of 64).
+template <int NP>                                    // pieces of 64 cycles per segment: 1, 2 or 4
 __global__ __launch_bounds__(256) void k_layout_node_dev(const int32_t* cum, const int32_t* src_start, const int32_t* pos_edge,
                                                          const int32_t* ind_i, const int32_t* ind_j, const int32_t* nat_k,
-                                                         const int32_t* poe, const unsigned long long* tau, const int32_t* ktau,
+                                                         const unsigned long long* tau, const int32_t* ktau,
                                                          uint64_t seed, const int32_t* rowptr, const unsigned long long* bits,
                                                          const uint32_t* rank, int words, const int32_t* adj_eid, const double* rij,
                                                          uint32_t* pk, double* S0, uint8_t* seg_perm, uint32_t* seg_counts, int m_pos) {
     const int lane = threadIdx.x & 63;
     const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * 256) >> 6;
-    constexpr int NP = MAX_SEG_CYCLES / 64;            // pieces of 64 cycles per segment
     for (int64_t l = wid; l < m_pos; l += nw) {
         const int base = cum[l], cnt = cum[l + 1] - base, src = src_start[l];
         const int e = pos_edge[l], i = ind_i[e], j = ind_j[e];
@@ -786,14 +786,13 @@ __global__ __launch_bounds__(256) void k_layout_node_dev(const int32_t* cum, con
                 xi = min((int)(rank[wi] + __popcll(bits[wi] & below)), max(di - 1, 0));
                 xj = min((int)(rank[wj] + __popcll(bits[wj] & below)), max(dj - 1, 0));
                 ei2 = adj_eid[ri + xi]; ej2 = adj_eid[rj + xj];
-                const int lik = poe[ei2], ljk = poe[ej2];         // both edges lie on the triangle {i,j,k}: they have cycles
-                if (lik >= 0) {
-                    const unsigned long long key = d_sample_key(seed, (uint64_t)ei2, (uint64_t)j), th = tau[lik];
-                    fi = key < th || (key == th && j <= ktau[lik]);                            // IKJ_appears (:113)
+                {   // both partner edges lie on the triangle {i,j,k}: they have cycles, their thresholds are defined
+                    const unsigned long long key = d_sample_key(seed, (uint64_t)ei2, (uint64_t)j), th = tau[ei2];
+                    fi = key < th || (key == th && j <= ktau[ei2]);                            // IKJ_appears (:113)
                 }
-                if (ljk >= 0) {
-                    const unsigned long long key = d_sample_key(seed, (uint64_t)ej2, (uint64_t)i), th = tau[ljk];
-                    fj = key < th || (key == th && i <= ktau[ljk]);                            // JKI_appears (:124)
+                {
+                    const unsigned long long key = d_sample_key(seed, (uint64_t)ej2, (uint64_t)i), th = tau[ej2];
+                    fj = key < th || (key == th && i <= ktau[ej2]);                            // JKI_appears (:124)
                 }
             }
             word[pc] = (uint32_t)xi | (fi ? 1u : 0u) << 15 | (uint32_t)xj << 16 | (fj ? 1u : 0u) << 31;
@@ -1525,8 +1524,14 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
         DESC_HIP(hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * std::max<int64_t>(1, mp), h->stream));
         if (nsl > 0) {
             int g = (int)std::min<int64_t>(4096, (nsl + 3) / 4);
-            hipLaunchKernelGGL(k_layout_node_dev, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo,
-                               d_pos_edge2 + h->seg_lo, d_ii, d_jj, s->d_k, s->d_poe, s->d_tau, s->d_ktau, (uint64_t)s->seed, h->d_rowptr, s->d_bits, s->d_rank, (int)s->words, d_adj_eid, d_rij,
+            if (h->max_cnt <= 64) hipLaunchKernelGGL(k_layout_node_dev<1>, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo,
+                               d_pos_edge2 + h->seg_lo, d_ii, d_jj, s->d_k, s->d_tau, s->d_ktau, (uint64_t)s->seed, h->d_rowptr, s->d_bits, s->d_rank, (int)s->words, d_adj_eid, d_rij,
+                               h->d_pk, h->d_S0, h->d_seg_perm, d_counts + h->seg_lo, (int)nsl);
+            else if (h->max_cnt <= 128) hipLaunchKernelGGL(k_layout_node_dev<2>, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo,
+                               d_pos_edge2 + h->seg_lo, d_ii, d_jj, s->d_k, s->d_tau, s->d_ktau, (uint64_t)s->seed, h->d_rowptr, s->d_bits, s->d_rank, (int)s->words, d_adj_eid, d_rij,
+                               h->d_pk, h->d_S0, h->d_seg_perm, d_counts + h->seg_lo, (int)nsl);
+            else hipLaunchKernelGGL(k_layout_node_dev<4>, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo,
+                               d_pos_edge2 + h->seg_lo, d_ii, d_jj, s->d_k, s->d_tau, s->d_ktau, (uint64_t)s->seed, h->d_rowptr, s->d_bits, s->d_rank, (int)s->words, d_adj_eid, d_rij,
                                h->d_pk, h->d_S0, h->d_seg_perm, d_counts + h->seg_lo, (int)nsl);
         }
         hipLaunchKernelGGL(k_adj_seg, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256))), dim3(256), 0, h->stream,

@@ -74,8 +74,9 @@ __global__ __launch_bounds__(256) void k_codeg(const int32_t* ind_i, const int32
 }
 
 // Cycle lists (DESC_PGD.m:79-96): one wave per edge-with-cycles.  Writes the sampled third
-// vertices (ascending) and the edge's selection threshold: a common neighbour k of edge e is
-// kept iff (key(e,k), k) <= (tau, ktau) lexicographically (all ones when codeg < n_sample).
+// vertices (ascending) and the edge's selection threshold, indexed by edge id: a common neighbour k
+// of edge e is kept iff (key(e,k), k) <= (tau[e], ktau[e]) lexicographically (all ones when
+// codeg < n_sample).
 __global__ __launch_bounds__(256) void k_fill_cycles(const int32_t* pos_edge, const int32_t* cum, const int32_t* ind_i,
                                                      const int32_t* ind_j, const unsigned long long* bits, int32_t* kk,
                                                      unsigned long long* tau, int32_t* ktau, int64_t m_pos, int words,
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void k_fill_cycles(const int32_t* pos_edge, co
         __builtin_amdgcn_wave_barrier();
         if (cd < n_sample) {                          // DESC_PGD.m:83 samples iff codeg >= n_sample
             for (int t = lane; t < cd; t += 64) kk[base + t] = ks[t];
-            if (lane == 0) { tau[l] = ~0ull; ktau[l] = 0x7FFFFFFF; }
+            if (lane == 0) { tau[e] = ~0ull; ktau[e] = 0x7FFFFFFF; }
         } else {
             // Keep the n_sample smallest keys.  A separator g with exactly n_sample keys <= g is found
             // by bisection on the key VALUE (keys are uniform 64-bit hashes: the first probe is the
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void k_fill_cycles(const int32_t* pos_edge, co
                     if (sel) kk[base + outbase + __popcll(mk & ((1ull << lane) - 1ull))] = ks[t];
                     outbase += __popcll(mk);
                 }
-                if (lane == 0) { tau[l] = g; ktau[l] = 0x7FFFFFFF; }
+                if (lane == 0) { tau[e] = g; ktau[e] = 0x7FFFFFFF; }
             } else {
                 // duplicate keys at the cut (probability ~1e-14 per edge): exact ranking of (key, k) pairs;
                 // common neighbours are distinct, positions ascend with k
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void k_fill_cycles(const int32_t* pos_edge, co
                         int rk = 0;
                         for (int u = 0; u < cd; ++u) { const unsigned long long ku = keys[u]; rk += (ku < kt) || (ku == kt && u < t); }
                         sel = rk < n_sample;
-                        if (rk == n_sample - 1) { tau[l] = kt; ktau[l] = ks[t]; }     // the last one kept
+                        if (rk == n_sample - 1) { tau[e] = kt; ktau[e] = ks[t]; }     // the last one kept
                     }
                     const unsigned long long mk = __ballot(sel);
                     if (sel) kk[base + outbase + __popcll(mk & ((1ull << lane) - 1ull))] = ks[t];
@@ -377,7 +378,7 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
     s->host_cycles = (mp == 0);                       // per-cycle arrays stay in HBM until somebody asks for them
     if (mp > 0) {
         if ((rc = keep(&s->d_pos, mp)) || (rc = keep(&s->d_cum, mp + 1)) || (rc = keep(&s->d_poe, m)) || (rc = keep(&s->d_k, mc)) ||
-            (rc = keep(&s->d_tau, mp)) || (rc = keep(&s->d_ktau, mp))) return rc;
+            (rc = keep(&s->d_tau, m)) || (rc = keep(&s->d_ktau, m))) return rc;
         DESC_HIP(hipMemcpy(s->d_pos, s->pos_edge.data(), sizeof(int32_t) * mp, hipMemcpyHostToDevice));
         DESC_HIP(hipMemcpy(s->d_cum, cum32.data(), sizeof(int32_t) * (mp + 1), hipMemcpyHostToDevice));
         DESC_HIP(hipMemcpy(s->d_poe, pos_of_edge.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
