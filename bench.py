@@ -10,7 +10,7 @@ inconsistencies are already resident in HBM when the timed region starts.
 
 Every N runs BASELINE.json configs[1] (C2: Uniform n=1000 p=0.5 q=0.3, sigma=0.1) -- strong
 scaling: the total work is fixed, at N > 1 the edges-with-cycles are sharded over the ranks with
-an all-reduce and an all-gather per iteration (desc_amd/sharded.py).  C2 is small enough that a
+a reduce-scatter and an all-gather per iteration (desc_amd/sharded.py).  C2 is small enough that a
 single GPU is about as fast as any sharding, so the N > 1 line additionally carries
 `north_star_config`: the same measurement on C4 (configs[3], n=5000 p=0.2).
 Prints ONE JSON line (rank 0) with the contract's fields plus `roofline` (dominant

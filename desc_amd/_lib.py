@@ -62,7 +62,7 @@ class Result(C.Structure):
 
 
 class ShardInfo(C.Structure):
-    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("t_len", C.c_int64), ("slice_len", C.c_int64),
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("t_len", C.c_int64), ("t_part", C.c_int64), ("slice_len", C.c_int64),
                 ("seg_lo", C.c_int64), ("seg_hi", C.c_int64), ("cyc_lo", C.c_int64), ("cyc_hi", C.c_int64),
                 ("m_pos", C.c_int64), ("m_cycle", C.c_int64)]
 
@@ -128,7 +128,7 @@ def load():
     L.desc_pgd_solve.argtypes = [C.POINTER(Problem), C.POINTER(Params), C.POINTER(Result)]
     L.desc_pgd_create_shard.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.desc_pgd_shard_info.argtypes = [C.c_void_p, C.POINTER(ShardInfo)]
-    L.desc_pgd_shard_bind.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.desc_pgd_shard_bind.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.desc_pgd_shard_colsum.argtypes = [C.c_void_p]
     L.desc_pgd_shard_sweep.argtypes = [C.c_void_p]
     L.desc_pgd_shard_finish.argtypes = [C.c_void_p, C.c_int32]
@@ -302,8 +302,8 @@ class Solver:
         check(load().desc_pgd_shard_info(self.handle, C.byref(info)))
         return info
 
-    def shard_bind(self, t_ptr, sall_ptr, stream_ptr=None):
-        check(load().desc_pgd_shard_bind(self.handle, t_ptr, sall_ptr, stream_ptr))
+    def shard_bind(self, t_send_ptr, t_recv_ptr, sall_ptr, stream_ptr=None):
+        check(load().desc_pgd_shard_bind(self.handle, t_send_ptr, t_recv_ptr, sall_ptr, stream_ptr))
 
     def shard_colsum(self):
         check(load().desc_pgd_shard_colsum(self.handle))

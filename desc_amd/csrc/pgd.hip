@@ -379,7 +379,8 @@ struct NodeSweepArgs {
     double* w_new;
     const double* S_old;       // Sfull, 2m
     double* S_new;
-    const double* Tfull;       // 2m: Tfull[rowptr[v]+t] = sum_k w(v,k; nbr_t), masked
+    const double* Tfull;       // 2m: Tfull[rowptr[v]+t] = sum_k w(v,k; nbr_t), masked; sharded runs: T1, T2 per owned segment
+    int32_t t_seg_lo;          // >= 0: Tfull holds {T1, T2} of segment l at 2*(l - t_seg_lo) (after the reduce-scatter)
     const double* nv_tab;
     double* partials;
     const DevState* state;
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
     if (tid <= MAX_SEG_CYCLES) s_nv[tid] = tid <= a.max_cnt ? a.nv_tab[tid] : 0.0;
 
     struct RecRaw { int b0, b1; EdgeInfo ei; };
-    struct Rec { int qb, cnt, rbi, rbj, sa, sb; };     // qb: image entry of the segment's first cycle
+    struct Rec { int qb, cnt, rbi, rbj, sa, sb, seg; };   // qb: image entry of the segment's first cycle
     struct Gat { double sjk[E], ski[E], T1, T2, So; };
     struct Landed { double ss[E], T1, T2, So; };       // S(jk)+S(ki) per cycle, mirror sums, old S of the segment
     struct Carry { StreamRegs s; Landed g; Rec r; };
@@ -464,6 +465,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
         r.qb = q.b0 - (d.c0 & ~3);
         r.cnt = ts < d.l1 - d.l0 ? q.b1 - q.b0 : 0;
         r.rbi = q.ei.rb_i; r.rbj = q.ei.rb_j; r.sa = q.ei.slot_a; r.sb = q.ei.slot_b;
+        r.seg = d.l0 + min(ts, d.l1 - d.l0 - 1);
         return r;
     };
     auto load_stream = [&](const ChunkDesc d) -> StreamRegs {   // 16-byte loads; image entry 0 = cycle a0 = c0 & ~3
@@ -493,8 +495,9 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
             if (a.ablate & 16) sj = (int)((p >> 16) & 511u);                            // only the j-row gathers redirected
             g.sjk[e] = a.S_old[sj]; g.ski[e] = a.S_old[si];
         }
-        g.T1 = a.Tfull[r.sa];                    // column j of node i = sum(wijk(IKJ(mask)))  (:189)
-        g.T2 = a.Tfull[r.sb];                    // column i of node j = sum(wijk(JKI(mask)))  (:190)
+        const int ta = a.t_seg_lo >= 0 ? 2 * (r.seg - a.t_seg_lo) : r.sa, tb = a.t_seg_lo >= 0 ? ta + 1 : r.sb;
+        g.T1 = a.Tfull[ta];                      // column j of node i = sum(wijk(IKJ(mask)))  (:189)
+        g.T2 = a.Tfull[tb];                      // column i of node j = sum(wijk(JKI(mask)))  (:190)
         g.So = a.S_old[r.sa];
         return g;
     };
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
 #pragma unroll
         for (int e = 0; e < E; ++e) asm volatile("" : "+v"(o.g.ss[e]));
         asm volatile("" : "+v"(o.g.T1), "+v"(o.g.T2), "+v"(o.g.So));
-        asm volatile("" : "+v"(o.r.qb), "+v"(o.r.cnt), "+v"(o.r.rbi), "+v"(o.r.rbj), "+v"(o.r.sa), "+v"(o.r.sb));
+        asm volatile("" : "+v"(o.r.qb), "+v"(o.r.cnt), "+v"(o.r.rbi), "+v"(o.r.rbj), "+v"(o.r.sa), "+v"(o.r.sb), "+v"(o.r.seg));
         __builtin_amdgcn_sched_barrier(0);
         if (!(a.ablate & 128)) {
 #pragma unroll
@@ -648,7 +651,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
 // flight per wave at once.
 constexpr int COLSUM_U = 8;
 __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, const int2* adj_seg, const uint32_t* pk, const double* w,
-                                                     double* Tfull, int n, int stride_cols, const DevState* st) {
+                                                     double* Tfull, int n, int stride_cols, const DevState* st, const int32_t* xpos) {
     if (st->stop) return;
     extern __shared__ double acc[];                   // [4][stride_cols] doubles, then 2 ints per incident edge
     int* seg_base = (int*)(acc + 4 * stride_cols);
@@ -710,7 +713,7 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
         }
         __syncthreads();
         for (int t = threadIdx.x; t < deg; t += 256)
-            Tfull[r0 + t] = (acc[t] + acc[stride_cols + t]) + (acc[2 * stride_cols + t] + acc[3 * stride_cols + t]);
+            Tfull[xpos ? xpos[r0 + t] : r0 + t] = (acc[t] + acc[stride_cols + t]) + (acc[2 * stride_cols + t] + acc[3 * stride_cols + t]);   // xpos: owner-sorted exchange layout
         __syncthreads();
     }
 }
@@ -850,6 +853,26 @@ __global__ __launch_bounds__(256) void k_adj_seg(const int32_t* rowptr, const in
             int2 rec{0, 0};
             if (q >= seg_lo && q < seg_hi) { rec.x = cum[q]; rec.y = (int)(seg_counts[q] | (v < adj[t] ? 0x80000000u : 0u)); }
             adj_seg[t] = rec;
+        }
+}
+
+// exchange position of every CSR slot for the sharded runs: slot (v,u) of edge e owned by rank r lands at
+// r*t_part + 2*(q - rank_seg[r]) + (v is the larger endpoint), q = device position of e; edges without
+// cycles go to the spare last element
+__global__ __launch_bounds__(256) void k_xpos(const int32_t* rowptr, const int32_t* adj, const int32_t* adj_eid, const int32_t* devpos,
+                                              const int32_t* rank_seg, int world, int64_t t_part, int32_t* xpos, int n) {
+    const int l16 = threadIdx.x & 15;
+    const int row0 = (blockIdx.x * 256 + threadIdx.x) >> 4, nrows = (gridDim.x * 256) >> 4;
+    for (int v = row0; v < n; v += nrows)
+        for (int t = rowptr[v] + l16; t < rowptr[v + 1]; t += 16) {
+            const int q = devpos[adj_eid[t]];
+            int64_t pos = (int64_t)world * t_part;
+            if (q >= 0) {
+                int r = 0;
+                while (r + 1 < world && q >= rank_seg[r + 1]) ++r;
+                pos = (int64_t)r * t_part + 2 * (int64_t)(q - rank_seg[r]) + (v < adj[t] ? 0 : 1);
+            }
+            xpos[t] = (int32_t)pos;
         }
 }
 
@@ -1042,7 +1065,10 @@ struct desc_pgd {
     int ch_lo = 0;                      // first chunk owned
     int64_t slice_len = 0;              // doubles per rank in the S exchange buffer
     std::vector<int64_t> rank_seg;      // world+1 segment boundaries
-    double* x_T = nullptr;              // caller-bound exchange buffers (device): column sums, 2m
+    double* x_T = nullptr;              // caller-bound exchange buffers (device): owner-sorted partial mirror sums (send)
+    double* x_Trecv = nullptr;          // reduce-scattered mirror sums of the owned segments
+    int32_t* d_xpos = nullptr;          // 2m: CSR slot -> position in x_T
+    int64_t t_part = 0;
     double* x_sall = nullptr;           //   world * slice_len
     double* d_pairs = nullptr;          // 2*world gathered scalars
     bool borrowed_stream = false, objective_done = false;
@@ -1161,11 +1187,11 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
     if (ev0) (void)hipEventRecord(ev0, h->stream);
     if (h->variant == VARIANT_NODE) {
         hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 2 * sizeof(int)), h->stream,
-                           h->d_rowptr, h->d_adj_seg, h->d_pk, h->d_w[rd], h->x_T ? h->x_T : h->d_T, (int)h->n,
-                           h->colsum_stride, h->d_state);
+                           h->d_rowptr, h->d_adj_seg, h->d_pk, h->d_w[rd], h->d_T, (int)h->n,
+                           h->colsum_stride, h->d_state, (const int32_t*)nullptr);
         NodeSweepArgs a{};
         a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
-        a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_T ? h->x_T : h->d_T; a.nv_tab = h->d_nv; a.partials = h->d_partials;
+        a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->d_T; a.t_seg_lo = -1; a.nv_tab = h->d_nv; a.partials = h->d_partials;
         a.state = h->d_state; a.st = st; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks; a.max_cnt = h->max_cnt; a.ablate = h->ablate;
         if (adam) launch_node<DESC_STEP_HYBRID>(h, a); else launch_node<DESC_STEP_CONSTANT>(h, a);
     } else {
@@ -1341,6 +1367,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     for (int r = 0; r <= h->world; ++r) h->rank_seg[r] = P.chunk_seg[P.rank_chunk[r]];
     for (int r = 0; r < h->world; ++r) max_local = std::max(max_local, h->rank_seg[r + 1] - h->rank_seg[r]);
     h->slice_len = max_local + 2;
+    h->t_part = 2 * std::max<int64_t>(max_local, 1);
     const int64_t mcl = h->cyc_hi - h->cyc_lo;            // local cycles
     const int64_t nsl = h->seg_hi - h->seg_lo;            // local segments
 
@@ -1419,6 +1446,23 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
             }
     });
     }
+    std::vector<int32_t> xpos;                          // host path: exchange positions of the CSR slots (k_xpos on the device path)
+    if (!dev_cycles) {
+        xpos.resize((size_t)2 * m);
+        host_parallel(n, [&](int64_t a, int64_t b) {
+            for (int64_t v = a; v < b; ++v)
+                for (int32_t t = rowptr[v]; t < rowptr[v + 1]; ++t) {
+                    const int32_t q = devpos[adj_eid[t]];
+                    int64_t pos = (int64_t)h->world * h->t_part;
+                    if (q >= 0) {
+                        int r = 0;
+                        while (r + 1 < h->world && q >= h->rank_seg[r + 1]) ++r;
+                        pos = (int64_t)r * h->t_part + 2 * (int64_t)(q - h->rank_seg[r]) + (v < adj[t] ? 0 : 1);
+                    }
+                    xpos[t] = (int32_t)pos;
+                }
+        });
+    }
     lap("host pack");
     // chunk tables: all chunks, local cycle numbering
     std::vector<ChunkDesc> chunk_desc((size_t)std::max<int64_t>(nch_all, 1));
@@ -1442,6 +1486,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     if ((rc = dalloc(h, &h->d_chunk_desc, chunk_desc.size()))) return rc;
     if ((rc = dalloc(h, &h->d_pairs, 2 * (size_t)h->world))) return rc;
     if ((rc = dalloc(h, &h->d_rank_seg, (size_t)h->world + 1))) return rc;
+    if ((rc = dalloc(h, &h->d_xpos, 2 * m))) return rc;
     lap("alloc");
     int32_t *d_ii = nullptr, *d_jj = nullptr, *d_adj = nullptr, *d_adj_eid = nullptr, *d_pos_edge2 = nullptr;
     uint32_t* d_kf = nullptr; double* d_rij = nullptr;
@@ -1478,6 +1523,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
         if ((rc = upload(h, d_adj_eid, adj_eid.data(), (size_t)2 * m))) return rc;
         if ((rc = upload(h, d_kf, kf.data(), (size_t)mcl))) return rc;
         if ((rc = upload(h, h->d_seg_perm, seg_perm.data(), (size_t)mcl))) return rc;
+        if ((rc = upload(h, h->d_xpos, xpos.data(), (size_t)2 * m))) return rc;
     }
     DESC_HIP(hipStreamSynchronize(h->stream));
     h->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1536,6 +1582,8 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
         }
         hipLaunchKernelGGL(k_adj_seg, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256))), dim3(256), 0, h->stream,
                            h->d_rowptr, d_adj, d_adj_eid, d_devpos, h->d_cum, d_counts, (int)h->seg_lo, (int)h->seg_hi, h->d_adj_seg, (int)n);
+        hipLaunchKernelGGL(k_xpos, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256))), dim3(256), 0, h->stream,
+                           h->d_rowptr, d_adj, d_adj_eid, d_devpos, h->d_rank_seg, h->world, h->t_part, h->d_xpos, (int)n);
         DESC_HIP(hipStreamSynchronize(h->stream));
         dfree(h, d_devpos); dfree(h, d_counts);
     }
@@ -1871,19 +1919,19 @@ int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r) {
 int desc_pgd_shard_info(const desc_pgd* h, desc_shard_info* info) {
     if (!h || !info) return fail(DESC_ERR_INVALID, "NULL argument");
     info->rank = h->rank; info->world = h->world;
-    info->t_len = 2 * h->m; info->slice_len = h->slice_len;
+    info->t_len = (int64_t)h->world * h->t_part + 1; info->t_part = h->t_part; info->slice_len = h->slice_len;
     info->seg_lo = h->seg_lo; info->seg_hi = h->seg_hi; info->cyc_lo = h->cyc_lo; info->cyc_hi = h->cyc_hi;
     info->m_pos = h->m_pos; info->m_cycle = h->m_cycle;
     return DESC_OK;
 }
 
-int desc_pgd_shard_bind(desc_pgd* h, double* T, double* sall, void* hip_stream) {
+int desc_pgd_shard_bind(desc_pgd* h, double* T_send, double* T_recv, double* sall, void* hip_stream) {
     if (!h) return fail(DESC_ERR_INVALID, "NULL handle");
     if (h->variant != VARIANT_NODE) return fail(DESC_ERR_STATE, "sharding needs the node layout");
-    if (!T || !sall) return fail(DESC_ERR_INVALID, "NULL exchange buffer");
+    if (!T_send || !T_recv || !sall) return fail(DESC_ERR_INVALID, "NULL exchange buffer");
     int rc = set_device(h); if (rc) return rc;
     DESC_HIP(hipStreamSynchronize(h->stream));
-    h->x_T = T; h->x_sall = sall;
+    h->x_T = T_send; h->x_Trecv = T_recv; h->x_sall = sall;
     if (hip_stream) {          // run on the caller's stream so collectives and kernels are ordered
         if (h->stream) (void)hipStreamDestroy(h->stream);
         h->stream = (hipStream_t)hip_stream;
@@ -1892,13 +1940,14 @@ int desc_pgd_shard_bind(desc_pgd* h, double* T, double* sall, void* hip_stream) 
     return DESC_OK;
 }
 
-// step 1 of an iteration: partial column sums of the segments this rank owns -> T (then: all-reduce T)
+// step 1 of an iteration: partial column sums of the segments this rank owns -> T_send, grouped by the
+// rank that owns each edge (then: reduce-scatter(sum) T_send -> T_recv)
 int desc_pgd_shard_colsum(desc_pgd* h) {
     if (!h || !h->armed || !h->x_T) return fail(DESC_ERR_STATE, "shard not armed / bound");
     int rc = set_device(h); if (rc) return rc;
     const int rd = h->t_done & 1;
     hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 2 * sizeof(int)), h->stream,
-                       h->d_rowptr, h->d_adj_seg, h->d_pk, h->d_w[rd], h->x_T, (int)h->n, h->colsum_stride, h->d_state);
+                       h->d_rowptr, h->d_adj_seg, h->d_pk, h->d_w[rd], h->x_T, (int)h->n, h->colsum_stride, h->d_state, h->d_xpos);
     DESC_HIP(hipGetLastError());
     return DESC_OK;
 }
@@ -1914,7 +1963,7 @@ int desc_pgd_shard_sweep(desc_pgd* h) {
     const StepArgs st = make_step(h, &adam);
     NodeSweepArgs a{};
     a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
-    a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_T; a.nv_tab = h->d_nv; a.partials = h->d_partials;
+    a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_Trecv; a.t_seg_lo = (int32_t)h->seg_lo; a.nv_tab = h->d_nv; a.partials = h->d_partials;
     a.state = h->d_state; a.st = st; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks;
     a.max_cnt = h->max_cnt; a.ablate = 0;
     if (adam) launch_node<DESC_STEP_HYBRID>(h, a); else launch_node<DESC_STEP_CONSTANT>(h, a);

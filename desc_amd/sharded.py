@@ -2,9 +2,11 @@
 O(m) exchange per iteration with torch.distributed (backend "nccl" = RCCL over xGMI).
 
 Per iteration (node form):
-    1. every rank: column sums of its own segments' weights        -> T (2m doubles, partial)
-    2. all-reduce(sum) of T                                         (the mirror-weight sums
-       T1/T2 of DESC_PGD.m:185-191 couple edges of different ranks)
+    1. every rank: column sums of its own segments' weights        -> T_send (partial sums for
+       every edge-with-cycles, grouped by the rank that owns the edge)
+    2. reduce-scatter(sum) of T_send -> T_recv                      (the mirror-weight sums
+       T1/T2 of DESC_PGD.m:185-191 couple edges of different ranks; a rank only needs the
+       totals of its own edges)
     3. every rank: sweep of its own chunks (gradient, projection, new S of its edges);
        packs S of its edges + its two scalar partials into its slice of `sall`
     4. all-gather of sall                                           (S_vec is read by every
@@ -29,7 +31,7 @@ from . import _lib
 
 
 class TorchComm:
-    """all-reduce / all-gather over a torch.distributed process group.  With the gloo
+    """reduce-scatter / all-gather over a torch.distributed process group.  With the gloo
     backend device tensors are staged through host memory (functional tests only)."""
 
     def __init__(self, group=None):
@@ -40,13 +42,17 @@ class TorchComm:
         self.world = dist.get_world_size(group)
         self.staged = dist.get_backend(group) == "gloo"
 
-    def all_reduce_sum(self, t):
-        if self.staged and t.is_cuda:
-            h = t.cpu()
+    def reduce_scatter_sum(self, recv, send):
+        """recv (t_part) = sum over ranks of their send[rank*t_part:(rank+1)*t_part]; send has one spare
+        element at the end.  gloo has no reduce-scatter: all-reduce on the host, keep this rank's part."""
+        L = recv.numel()
+        body = send[:self.world * L]
+        if self.staged:
+            h = body.cpu() if body.is_cuda else body.clone()
             self.dist.all_reduce(h, group=self.group)
-            t.copy_(h)
+            recv.copy_(h.view(self.world, L)[self.rank])
         else:
-            self.dist.all_reduce(t, group=self.group)
+            self.dist.reduce_scatter_tensor(recv, body, group=self.group)
 
     def all_gather_slices(self, full, slice_len):
         """full = world slices of slice_len; every rank has filled its own slice."""
@@ -83,7 +89,7 @@ class SingleComm:
     """world_size 1 without torch."""
     rank, world = 0, 1
 
-    def all_reduce_sum(self, t): pass
+    def reduce_scatter_sum(self, recv, send): recv.copy_(send[:recv.numel()])
     def all_gather_slices(self, full, slice_len): pass
     def barrier(self): pass
     def max_float(self, x): return x
@@ -103,10 +109,11 @@ class HipShard:
         # stream_ctx) the collectives, so they are ordered without host synchronisation.
         self.stream = stream if stream is not None else torch.cuda.Stream(dev)
         with torch.cuda.stream(self.stream):
-            self.T = torch.zeros(self.info.t_len, dtype=torch.float64, device=dev)
+            self.T = torch.zeros(self.info.t_len, dtype=torch.float64, device=dev)        # send: zero padding stays zero
+            self.T_recv = torch.zeros(self.info.t_part, dtype=torch.float64, device=dev)
             self.sall = torch.zeros(self.info.world * self.info.slice_len, dtype=torch.float64, device=dev)
         self.stream.synchronize()
-        self.solver.shard_bind(self.T.data_ptr(), self.sall.data_ptr(), self.stream.cuda_stream)
+        self.solver.shard_bind(self.T.data_ptr(), self.T_recv.data_ptr(), self.sall.data_ptr(), self.stream.cuda_stream)
         self.slice_len = self.info.slice_len
 
     def stream_ctx(self):
@@ -146,7 +153,7 @@ class ShardedDriver:
         with self._ctx():
             for _ in range(n):
                 s.colsum()
-                c.all_reduce_sum(s.T)
+                c.reduce_scatter_sum(s.T_recv, s.T)
                 s.sweep()
                 c.all_gather_slices(s.sall, s.slice_len)
                 s.finish(0)
@@ -237,7 +244,7 @@ def bench_sharded(args, WORKLOADS, describe, generate, cpu_baseline):
     """bench.py body for --gpus N > 1 (launched by torch.distributed.run, one rank per GPU).
 
     The bench line is the same workload as at N = 1 (C2, strong scaling: total work fixed, edges
-    sharded over the ranks, all-reduce + all-gather per iteration).  C2 is small enough that one
+    sharded over the ranks, reduce-scatter + all-gather per iteration).  C2 is small enough that one
     GPU is about as fast as any sharding; the line therefore also carries
     `north_star_config`: the same measurement on C4 (BASELINE.json configs[3], n = 5000)."""
     import torch                                         # before libdesc_amd.so: see _lib.load()
@@ -262,7 +269,7 @@ def bench_sharded(args, WORKLOADS, describe, generate, cpu_baseline):
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": r["workload"], "n": r["nn"], "m": r["m"], "m_pos": r["m_pos"], "m_cycle": r["m_cycle"],
                    "n_sample": r["n_sample"], "sampling_seed": args.seed,
-                   "parallelism": f"edges sharded over {world} GPUs; all-reduce T (2m f64) + all-gather S per iteration"},
+                   "parallelism": f"edges sharded over {world} GPUs; reduce-scatter of the mirror sums (2 m_pos f64) + all-gather S per iteration"},
         "roofline": {"bound": "hbm", "achieved": bytes_iter / (dt / K) / 1e9, "peak": 8000.0 * world, "unit": "GB/s",
                      "frac": bytes_iter / (dt / K) / 1e9 / (8000.0 * world), "traffic": None,
                      "kernel": "whole iteration incl. collectives (aggregate over ranks)", "bytes_per_launch": bytes_iter},

@@ -172,7 +172,8 @@ const char* desc_pgd_kernel_name(const desc_pgd* h);
  * every rank adds the gathered scalar partials in rank order. */
 typedef struct desc_shard_info {
     int32_t rank, world;
-    int64_t t_len;            /* doubles in T     = 2*m                                       */
+    int64_t t_len;            /* doubles in T_send = world*t_part + 1 (owner-sorted mirror sums, last = unused slot) */
+    int64_t t_part;           /* doubles in T_recv: T1, T2 of every owned edge-with-cycles, padded to the largest shard */
     int64_t slice_len;        /* doubles per rank in sall (owned edges + 2 scalars, padded)   */
     int64_t seg_lo, seg_hi;   /* owned range of edges-with-cycles (library order)             */
     int64_t cyc_lo, cyc_hi;   /* owned range of cycles                                        */
@@ -181,9 +182,11 @@ typedef struct desc_shard_info {
 int desc_pgd_create_shard(const desc_problem* prob, const desc_structure* s, int32_t device,
                           int32_t rank, int32_t world, desc_pgd** out);
 int desc_pgd_shard_info(const desc_pgd* h, desc_shard_info* info);
-/* T: t_len doubles, sall: world*slice_len doubles, both on `device`; hip_stream: the stream
- * the caller's collectives are ordered on (NULL keeps the handle's own stream). */
-int desc_pgd_shard_bind(desc_pgd* h, double* T, double* sall, void* hip_stream);
+/* T_send: t_len doubles, zero-initialised by the caller (this rank's partial mirror sums, grouped by
+ * owning rank: part r = [r*t_part, (r+1)*t_part)); T_recv: t_part doubles (the caller's
+ * reduce-scatter(sum) of every rank's T_send); sall: world*slice_len doubles; all on `device`.
+ * hip_stream: the stream the caller's collectives are ordered on (NULL keeps the handle's own). */
+int desc_pgd_shard_bind(desc_pgd* h, double* T_send, double* T_recv, double* sall, void* hip_stream);
 int desc_pgd_shard_colsum(desc_pgd* h);
 int desc_pgd_shard_sweep(desc_pgd* h);
 /* initial: 0 = after an iteration's all-gather; 1 = pack the initial S_vec (after reset,

@@ -22,7 +22,12 @@ class NumpyShard:
         self.lo, self.hi = self.rank_seg[rank], self.rank_seg[rank + 1]
         self.c_lo, self.c_hi = int(cyc[self.lo]), int(cyc[self.hi])
         self.slice_len = max(self.rank_seg[r + 1] - self.rank_seg[r] for r in range(world)) + 2
-        self.T = torch.zeros(2 * mp, dtype=torch.float64)           # [T1 | T2] per edge-with-cycles
+        # exchange layout of the mirror sums: part r = {T1, T2} of the edges rank r owns, padded to the largest shard
+        self.t_part = 2 * max(max(self.rank_seg[r + 1] - self.rank_seg[r] for r in range(world)), 1)
+        self.T = torch.zeros(world * self.t_part + 1, dtype=torch.float64)      # send
+        self.T_recv = torch.zeros(self.t_part, dtype=torch.float64)
+        owner = np.searchsorted(np.asarray(self.rank_seg[1:]), np.arange(mp), side="right")
+        self.xpos = owner * self.t_part + 2 * (np.arange(mp) - np.asarray(self.rank_seg)[owner])     # position of T1 of every edge
         self.sall = torch.zeros(world * self.slice_len, dtype=torch.float64)
         self.seg = np.repeat(np.arange(mp), np.diff(cyc))
         self.m = m
@@ -94,14 +99,18 @@ class NumpyShard:
             idx = st[key]
             ok = (idx >= self.c_lo) & (idx < self.c_hi)
             T[col * st["m_pos"]:(col + 1) * st["m_pos"]] = np.bincount(self.seg[ok], self.w[idx[ok]], minlength=st["m_pos"])
-        self.T.numpy()[:] = T
+        out = self.T.numpy(); out[:] = 0.0
+        out[self.xpos] = T[:st["m_pos"]]; out[self.xpos + 1] = T[st["m_pos"]:]
 
     def sweep(self):
         if self.stop:
             return
         st, p = self.st, self.p
         self.t += 1; self.tp += 1
-        T = self.T.numpy(); mp = st["m_pos"]
+        mp = st["m_pos"]
+        T = np.zeros(2 * mp)                                            # totals of the owned edges, from the reduce-scatter
+        nl = self.hi - self.lo
+        T[self.lo:self.hi] = self.T_recv.numpy()[0:2 * nl:2]; T[mp + self.lo:mp + self.hi] = self.T_recv.numpy()[1:2 * nl:2]
         step = p.lr
         if p.step_kind == 1:
             step = p.lr / (np.trunc(self.tp / p.decay_interval) + 1)

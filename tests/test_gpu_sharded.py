@@ -32,12 +32,13 @@ def _emulate(lib, nn, ii, jj, rij, p, world, check_every=5, where=None, nmin=30)
             for s in shards:
                 s.sall.view(world, L)[r].copy_(piece)
 
-    def all_reduce():
-        tot = torch.zeros_like(shards[0].T)
+    def reduce_scatter():
+        Lp = shards[0].info.t_part
+        tot = torch.zeros(world * Lp, dtype=torch.float64, device=shards[0].T.device)
         for s in shards:
-            tot += s.T
-        for s in shards:
-            s.T.copy_(tot)
+            tot += s.T[:world * Lp]
+        for r, s in enumerate(shards):
+            s.T_recv.copy_(tot.view(world, Lp)[r])
 
     for s in shards: s.reset(p)
     for s in shards: s.finish(1)
@@ -48,7 +49,7 @@ def _emulate(lib, nn, ii, jj, rij, p, world, check_every=5, where=None, nmin=30)
         n = min(left, check_every)
         for _ in range(n):
             for s in shards: s.colsum()
-            all_reduce()
+            reduce_scatter()
             for s in shards: s.sweep()
             all_gather()
             for s in shards: s.finish(0)
