@@ -1172,7 +1172,7 @@ void launch_node(desc_pgd* h, const NodeSweepArgs& a) {
     switch (h->lps * 8 + h->G) {              // lps lanes per segment, G = cycles per lane (E)
         case 16 * 8 + 1: hipLaunchKernelGGL((k_sweep_node<16, 1, STEP>), grid, block, 0, h->stream, a); break;
         case 16 * 8 + 2: hipLaunchKernelGGL((k_sweep_node<16, 2, STEP>), grid, block, 0, h->stream, a); break;
-        case 16 * 8 + 4: hipLaunchKernelGGL((k_sweep_node<16, 4, STEP>), grid, block, 0, h->stream, a); break;
+        case 32 * 8 + 2: hipLaunchKernelGGL((k_sweep_node<32, 2, STEP>), grid, block, 0, h->stream, a); break;
         case 32 * 8 + 4: hipLaunchKernelGGL((k_sweep_node<32, 4, STEP>), grid, block, 0, h->stream, a); break;
         default: hipLaunchKernelGGL((k_sweep_node<64, 4, STEP>), grid, block, 0, h->stream, a); break;
     }
@@ -1353,7 +1353,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     };
     int rc;
     NodePlan P;
-    if ((rc = make_node_plan(prob, s, h->max_deg, h->world, h->max_cnt <= 64 ? 32 : h->max_cnt <= 128 ? 16 : 8, P))) return rc;
+    if ((rc = make_node_plan(prob, s, h->max_deg, h->world, h->max_cnt <= 32 ? 32 : h->max_cnt <= 128 ? 16 : 8, P))) return rc;   // 8 waves x 64/lps segments
     h->band = P.band;
     lap("plan");
     const std::vector<int32_t>& cum2 = P.cum2;
@@ -1530,11 +1530,13 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     lap("upload");
 
     // lanes per segment x cycles per lane >= longest segment
-    h->lps = h->max_cnt <= 64 ? 16 : h->max_cnt <= 128 ? 32 : 64;
-    h->G = h->max_cnt <= 16 ? 1 : h->max_cnt <= 32 ? 2 : 4;
+    // (33..64 cycles: 32 lanes x 2 cycles keeps all 8 waves of the workgroup busy in the arithmetic --
+    //  measured 2 % faster than 16 lanes x 4 cycles at C2 and C4)
+    h->lps = h->max_cnt <= 32 ? 16 : h->max_cnt <= 128 ? 32 : 64;
+    h->G = h->max_cnt <= 16 ? 1 : h->max_cnt <= 64 ? 2 : 4;
     {   // persistent grid: exactly the workgroups that are co-resident (registers / LDS decide)
         int per_cu = 0, ncu = 256;
-        const void* kfn = (const void*)k_sweep_node<16, 4, DESC_STEP_CONSTANT>;    // the largest-register instance
+        const void* kfn = (const void*)k_sweep_node<32, 4, DESC_STEP_CONSTANT>;    // the largest-register instance
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, SWEEP_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
