@@ -407,7 +407,7 @@ struct alignas(16) ChunkBuf {
 // locality; disjoint far-apart streams per workgroup measured ~half the bandwidth).
 // pk, w and S0 of a chunk arrive with 16-byte loads, two chunks ahead, and are parked in a
 // triple-buffered LDS image.  Everything per segment lives in the registers of the 16 lanes
-// that own the segment (LPS = 16, 32 or 64 lanes for segments of up to 64, 128, 256 cycles; a
+// that own the segment (LPS lanes x E cycles per lane = 16x1, 16x2, 32x2, 32x4, 64x4 for segments of up to 16, 32, 64, 128, 256 cycles; a
 // chunk = one pass of the 8 waves x 64/LPS lane groups): the lane group
 // that will compute segment t of chunk c+1 loads its records, issues its row gathers
 // (addresses from the packed words already parked in LDS) and keeps their sums until the
