@@ -1393,12 +1393,15 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     lap("csr+eslot");
     std::vector<int32_t> cum_loc((size_t)mp + 1), src_start((size_t)mp), pos_edge2((size_t)mp), devpos((size_t)m, -1);
     std::vector<EdgeInfo> einfo;
-    for (int64_t q = 0; q <= mp; ++q) cum_loc[q] = cum2[q] - (int32_t)h->cyc_lo;   // local cycle numbering (meaningful for owned segments)
-    for (int64_t q = 0; q < mp; ++q) {
-        const int32_t l = P.order[q], e = s->pos_edge[l];
-        src_start[q] = (int32_t)s->cum_ind[l];
-        pos_edge2[q] = e; devpos[e] = (int32_t)q;
-    }
+    cum_loc[mp] = cum2[mp] - (int32_t)h->cyc_lo;
+    host_parallel(mp, [&](int64_t a, int64_t b) {
+        for (int64_t q = a; q < b; ++q) {
+            cum_loc[q] = cum2[q] - (int32_t)h->cyc_lo;                              // local cycle numbering (meaningful for owned segments)
+            const int32_t l = P.order[q], e = s->pos_edge[l];
+            src_start[q] = (int32_t)s->cum_ind[l];
+            pos_edge2[q] = e; devpos[e] = (int32_t)q;
+        }
+    });
     if (!dev_cycles) {
         einfo.resize((size_t)mp);
         host_parallel(mp, [&](int64_t a, int64_t b) {

@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cmath>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -357,15 +358,32 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
     s->cum_ind.assign((size_t)mp + 1, 0);
     s->max_cnt = std::min(max_codeg, n_sample);
     std::vector<int32_t> cum32((size_t)mp + 1, 0), pos_of_edge((size_t)std::max<int64_t>(m, 1), -1);
-    {
-        int64_t l = 0;
-        for (int64_t e = 0; e < m; ++e) {
-            const int32_t cd = s->codeg[e];
-            if (cd <= 0) continue;
-            s->pos_edge[l] = (int32_t)e; pos_of_edge[e] = (int32_t)l;
-            s->cum_ind[l + 1] = s->cum_ind[l] + std::min(cd, n_sample);
-            ++l;
-        }
+    {   // compaction of the edges with cycles + prefix sum of their cycle counts, in chunks (threads for large m)
+        unsigned hw = std::thread::hardware_concurrency();
+        const int T = m >= (1 << 20) ? (int)std::max(1u, std::min(hw, 16u)) : 1;
+        std::vector<int64_t> c_pos((size_t)T + 1, 0), c_cyc((size_t)T + 1, 0);
+        auto run = [&](auto&& body) {
+            if (T == 1) { body(0, (int64_t)0, m); return; }
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t) th.emplace_back([=, &body]() { body(t, m * t / T, m * (t + 1) / T); });
+            for (auto& x : th) x.join();
+        };
+        run([&](int t, int64_t a, int64_t b) {
+            int64_t np = 0, nc = 0;
+            for (int64_t e = a; e < b; ++e) { const int32_t cd = s->codeg[e]; if (cd > 0) { ++np; nc += std::min(cd, n_sample); } }
+            c_pos[t + 1] = np; c_cyc[t + 1] = nc;
+        });
+        for (int t = 0; t < T; ++t) { c_pos[t + 1] += c_pos[t]; c_cyc[t + 1] += c_cyc[t]; }
+        run([&](int t, int64_t a, int64_t b) {
+            int64_t l = c_pos[t], c = c_cyc[t];
+            for (int64_t e = a; e < b; ++e) {
+                const int32_t cd = s->codeg[e];
+                if (cd <= 0) continue;
+                s->pos_edge[l] = (int32_t)e; pos_of_edge[e] = (int32_t)l;
+                c += std::min(cd, n_sample);
+                s->cum_ind[++l] = c;
+            }
+        });
     }
     s->m_cycle = s->cum_ind[mp];
     if (s->m_cycle >= (1ll << 31) - 1) return fail(DESC_ERR_TOO_LARGE, "m_cycle = %lld exceeds 2^31-2", (long long)s->m_cycle);
