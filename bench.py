@@ -116,8 +116,14 @@ def main():
     mo, nn, ii, jj, rij = generate(name)
     t_gen = time.perf_counter() - t0
     prob = _lib.ProblemArrays(nn, ii, jj, rij)
-    _lib.Structure.build(_lib.ProblemArrays(3, np.array([0, 0, 1], dtype=np.int32), np.array([1, 2, 2], dtype=np.int32)),
-                         30, 0, _lib.BUILD_DEVICE, 0).free()          # HIP context / code-object load, outside the timers
+    # one warm-up call on a 200-node complete graph, outside the timers: HIP context, code-object load, the
+    # runtime's pinned staging buffers and first-use kernel attributes are per-process one-time costs
+    wi, wj = np.triu_indices(200, 1)
+    wprob = _lib.ProblemArrays(200, wi.astype(np.int32), wj.astype(np.int32), np.tile(np.eye(3).reshape(-1), wi.shape[0]))
+    wst = _lib.Structure.build(wprob, 30, 0, _lib.BUILD_DEVICE, 0)
+    wsol = _lib.Solver(wprob, wst, 0)
+    wp = _lib.default_params(); wp.iters = 2
+    wsol.run(wp); wsol.destroy(); wst.free()
     t0 = time.perf_counter()
     st = _lib.Structure.build(prob, 30, args.seed, _lib.BUILD_DEVICE, 0)
     t_struct = time.perf_counter() - t0

@@ -314,7 +314,9 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
         (rc = keep(&s->d_ii, m)) || (rc = keep(&s->d_jj, m)) || (rc = D.alloc(&d_codeg, m)) || (rc = D.alloc(&d_hist, n + 1)) ||
         (rc = keep(&s->d_bits, (size_t)n * words)) || (rc = keep(&s->d_rank, (size_t)n * words))) return rc;
     d_bits = s->d_bits;
+    lap("alloc");
     DESC_HIP(hipMemcpy(s->d_rowptr, rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
+    lap("first memcpy");
     if (m) {
         DESC_HIP(hipMemcpy(s->d_adj, adj.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
         DESC_HIP(hipMemcpy(s->d_adj_eid, adj_eid.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
