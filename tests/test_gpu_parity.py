@@ -333,3 +333,11 @@ def test_device_structure_exact_selection_path(lib, oracle, monkeypatch):
     out_fast = solver.run(p, want_w=True)
     solver.destroy(); st2.free()
     assert np.array_equal(out_exact["S_vec"], out_fast["S_vec"]) and np.array_equal(out_exact["w"], out_fast["w"])
+
+
+def test_c_client(lib, tmp_path):
+    """examples/desc_pgd_example.c (gcc, C99, links libdesc_amd.so): the corrupted edge of a consistent K8 stands out."""
+    from tests.test_host import _build_c_example
+    r = _build_c_example(tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "iterations" in r.stdout and "s(corrupted edge" in r.stdout

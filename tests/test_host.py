@@ -210,3 +210,31 @@ def test_golden_structure_and_c_oracle(lib, oracle, path):
     assert np.abs(res["w"] - g["wijk"]).max() < 1e-12
     assert np.allclose(res["obj"], g["obj_vals"], rtol=1e-13)
     assert np.allclose(res["avg"], g["avg_changes"], rtol=1e-10, atol=1e-16)
+
+
+def _build_c_example(tmp_path):
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "desc_example")
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(root, "include", "desc_amd.h")])
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "desc_pgd_example.c"),
+                           "-L", os.path.join(root, "desc_amd"), "-ldesc_amd", "-lm", "-o", exe])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(root, "desc_amd") + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    return subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+
+
+def test_header_is_c99_and_c_client_fails_loudly_without_gpu(lib, tmp_path):
+    """include/desc_amd.h is plain C; a gcc-built client links against the library and, with no GPU,
+    gets an error code and a message -- never a silent CPU result."""
+    try:
+        ndev = lib.device_count()
+    except lib.DescError:
+        ndev = 0
+    if ndev > 0:
+        pytest.skip("a GPU is visible: see tests/test_gpu_parity.py::test_c_client")
+    r = _build_c_example(tmp_path)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
