@@ -12,6 +12,8 @@
 #include <string.h>
 
 #include "mex.h"
+#include <math.h>
+
 #include "desc_amd.h"
 
 static void problem_from(const mxArray* ind, const mxArray* rij, desc_problem* p) {

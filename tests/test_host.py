@@ -238,3 +238,17 @@ def test_header_is_c99_and_c_client_fails_loudly_without_gpu(lib, tmp_path):
         pytest.skip("a GPU is visible: see tests/test_gpu_parity.py::test_c_client")
     r = _build_c_example(tmp_path)
     assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+@pytest.mark.parametrize("shim", ["desc_pgd_mex.c", "desc_amd_mex.c"])
+def test_mex_shims_are_syntactically_valid_c(shim):
+    """The MEX shims cannot be built without MATLAB; they are at least syntax- and type-checked against the
+    documented prototypes of the MEX / C Matrix API functions they call (tests/mock_mex/mex.h, a test mock)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Werror", "-fsyntax-only",
+                           "-I", os.path.join(root, "tests", "mock_mex"), "-I", os.path.join(root, "include"), os.path.join(root, "matlab", shim)])
