@@ -20,7 +20,8 @@ BUILD_HOST, BUILD_DEVICE = 0, 1
 # every symbol include/desc_amd.h declares (tests check that the library exports them)
 EXPORTS = [
     "desc_last_error", "desc_version", "desc_device_count",
-    "desc_structure_build", "desc_structure_import", "desc_structure_get", "desc_structure_free",
+    "desc_structure_build", "desc_structure_import", "desc_structure_get", "desc_structure_sizes",
+    "desc_structure_host_exports", "desc_structure_free",
     "desc_sample_key", "desc_params_default",
     "desc_pgd_create", "desc_pgd_destroy", "desc_pgd_run", "desc_pgd_reset", "desc_pgd_iterate",
     "desc_pgd_iterate_timed", "desc_pgd_sync", "desc_pgd_download", "desc_pgd_get_s0",
@@ -43,6 +44,12 @@ class StructureView(C.Structure):
                 ("n_sample", C.c_int32), ("max_cnt", C.c_int32),
                 ("codeg", I32P), ("pos_edge", I32P), ("cum_ind", I64P),
                 ("k", I32P), ("e_jk", I32P), ("e_ki", I32P), ("ikj", I32P), ("jki", I32P)]
+
+
+class StructureInfo(C.Structure):
+    _fields_ = [("n", C.c_int64), ("m", C.c_int64), ("m_pos", C.c_int64), ("m_cycle", C.c_int64),
+                ("n_sample", C.c_int32), ("max_cnt", C.c_int32), ("built_where", C.c_int32),
+                ("host_resident", C.c_int32), ("ms_build", C.c_double)]
 
 
 class Params(C.Structure):
@@ -73,12 +80,19 @@ class SpectralInfo(C.Structure):
 
 
 class RefineInfo(C.Structure):
-    _fields_ = [("iters", C.c_int32), ("cg_iters", C.c_int32), ("verbose", C.c_int32), ("reserved", C.c_int32),
-                ("score", C.c_double), ("ms_total", C.c_double)]
+    _fields_ = [("iters", C.c_int32), ("cg_iters", C.c_int32), ("verbose", C.c_int32), ("cg_unconverged", C.c_int32),
+                ("score", C.c_double), ("ms_total", C.c_double), ("cg_residual", C.c_double)]
+
+
+ERR_INVALID, ERR_HIP, ERR_TOO_LARGE, ERR_STATE = -1, -2, -3, -4
 
 
 class DescError(RuntimeError):
-    pass
+    """Carries the C return code (``code``): callers branch on it, not on the message text."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
 
 
 _lib = None
@@ -112,6 +126,9 @@ def load():
     L.desc_structure_import.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int32, I32P, I64P, I32P, I32P,
                                         I32P, I32P, I32P, C.POINTER(C.c_void_p)]
     L.desc_structure_get.argtypes = [C.c_void_p, C.POINTER(StructureView)]
+    L.desc_structure_sizes.argtypes = [C.c_void_p, C.POINTER(StructureInfo)]
+    L.desc_structure_host_exports.restype = C.c_int64
+    L.desc_structure_host_exports.argtypes = []
     L.desc_structure_free.argtypes = [C.c_void_p]
     L.desc_structure_free.restype = None
     L.desc_pgd_create.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
@@ -142,7 +159,7 @@ def load():
 
 def check(rc):
     if rc != DESC_OK:
-        raise DescError(f"desc_amd error {rc}: {load().desc_last_error().decode()}")
+        raise DescError(f"desc_amd error {rc}: {load().desc_last_error().decode()}", rc)
 
 
 def ptr(a, t):
@@ -210,9 +227,11 @@ class Structure:
         return _view_arrays(v)
 
     def sizes(self):
-        v = StructureView()
-        check(load().desc_structure_get(self.handle, C.byref(v)))
-        return dict(n=v.n, m=v.m, m_pos=v.m_pos, m_cycle=v.m_cycle, n_sample=v.n_sample, max_cnt=v.max_cnt)
+        """O(1): never exports a device-built structure to the host (desc_structure_sizes)."""
+        v = StructureInfo()
+        check(load().desc_structure_sizes(self.handle, C.byref(v)))
+        return dict(n=v.n, m=v.m, m_pos=v.m_pos, m_cycle=v.m_cycle, n_sample=v.n_sample, max_cnt=v.max_cnt,
+                    built_where=v.built_where, host_resident=bool(v.host_resident), ms_build=v.ms_build)
 
     def free(self):
         if self.handle:
@@ -381,7 +400,13 @@ def refine_run(prob: ProblemArrays, s_vec, R_init, stop_threshold=1e-3, max_iter
     L = load()
     L.desc_refine_run.argtypes = [C.POINTER(Problem), F64P, F64P, C.c_double, C.c_int32, C.c_int32, F64P, C.POINTER(RefineInfo)]
     check(L.desc_refine_run(C.byref(prob.c), ptr(S, F64P), ptr(Ri, F64P), stop_threshold, max_iters, device, ptr(Ro, F64P), C.byref(info)))
-    return Ro[:9 * n].reshape((3, 3, n), order="F"), dict(iters=info.iters, cg_iters=info.cg_iters, score=info.score, ms_total=info.ms_total)
+    return Ro[:9 * n].reshape((3, 3, n), order="F"), dict(iters=info.iters, cg_iters=info.cg_iters, score=info.score, ms_total=info.ms_total,
+                                                        cg_unconverged=info.cg_unconverged, cg_residual=info.cg_residual)
+
+
+def host_exports():
+    """How often this process exported a device-built structure to host memory (diagnostics)."""
+    return int(load().desc_structure_host_exports())
 
 
 def device_count():

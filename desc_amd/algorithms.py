@@ -143,13 +143,13 @@ def DESC_PGD(Ind, RijMat, params, return_info=False):
         st = _lib.Structure.build(prob, p.n_sample_min, p.seed, p.build_where, p.device)
     except _lib.DescError as e:
         # the device builder refuses graphs whose bitmaps / per-edge staging exceed its budget
-        if p.build_where != _lib.BUILD_DEVICE or "DESC_BUILD_HOST" not in str(e):
+        if p.build_where != _lib.BUILD_DEVICE or e.code != _lib.ERR_TOO_LARGE:
             raise
         st = _lib.Structure.build(prob, p.n_sample_min, p.seed, _lib.BUILD_HOST, p.device)
     try:
+        sizes = st.sizes()                    # O(1): the structure stays on the device
+        ms_structure = sizes.pop("ms_build")
         solver = _lib.Solver(prob, st, p.device)
-        sizes = st.sizes()
-        ms_structure = 0.0
     finally:
         st.free()
     try:

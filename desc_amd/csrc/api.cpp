@@ -117,6 +117,16 @@ int desc_structure_get(const desc_structure* cs, desc_structure_view* v) {
     return DESC_OK;
 }
 
+int desc_structure_sizes(const desc_structure* s, desc_structure_info* info) {
+    if (!s || !info) return fail(DESC_ERR_INVALID, "NULL argument");
+    info->n = s->n; info->m = s->m; info->m_pos = s->m_pos; info->m_cycle = s->m_cycle;
+    info->n_sample = s->n_sample; info->max_cnt = s->max_cnt;
+    info->built_where = s->d_k ? DESC_BUILD_DEVICE : DESC_BUILD_HOST;
+    info->host_resident = s->host_cycles ? 1 : 0;
+    info->ms_build = s->ms_build;
+    return DESC_OK;
+}
+
 void desc_structure_free(desc_structure* s) { if (s) { structure_free_device(s); delete s; } }
 
 int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* r) {

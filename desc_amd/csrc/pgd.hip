@@ -56,11 +56,15 @@ struct DevState {
     int32_t misses;        // DESC_PGD.m:181
     int32_t iters_run;     // iteration at which the loop broke
     int32_t final_parity;  // which double buffer holds the final iterate
+    int32_t last_tested;   // last iteration whose stop test (:243-256) has been applied: a download between
+                           // iterations evaluates the objective early, the next sweep must not count it again
 };
 
 struct StepArgs {
-    double* adam_m;
-    double* adam_v;
+    const double* adam_m;                 // HybridGradient.m_t / v_t before this GetStep call ...
+    const double* adam_v;
+    double* adam_m_out;                   // ... and after it: double-buffered like w, because the stop decision for
+    double* adam_v_out;                   // iteration t falls during sweep t+1, whose update must be discardable
     double step;                          // step size of this GetStep call
     double lr, beta1, beta2, bc1, bc2;    // Adam (HybridGradient.m:28-35)
 };
@@ -77,7 +81,7 @@ __device__ __forceinline__ double apply_step(const StepArgs& a, double w, double
     if (STEP == DESC_STEP_HYBRID) {               // HybridGradient.m:28-35 (strategy 0)
         double mt = (a.beta1 * a.adam_m[c]) + (1.0 - a.beta1) * g;
         double vt = (a.beta2 * a.adam_v[c]) + (1.0 - a.beta2) * (g * g);
-        a.adam_m[c] = mt; a.adam_v[c] = vt;
+        a.adam_m_out[c] = mt; a.adam_v_out[c] = vt;
         double cm = mt / a.bc1, cv = vt / a.bc2;
         return w + (-a.lr * cm / (sqrt(cv) + 1e-8));
     }
@@ -999,6 +1003,8 @@ __global__ __launch_bounds__(64) void k_finalize(const double* partials, int npa
     if (!last_only) avg_trace[t - 1] = sh[1][0] / (double)m;                          // :232
     if (it >= 1) {
         obj_trace[it - 1] = sh[0][0];                                                 // :233
+        if (it <= st->last_tested) return;          // already tested (objective evaluated early by a download)
+        st->last_tested = it;
         if (it > 1 && obj_trace[it - 2] - obj_trace[it - 1] < stop_tol) {             // :243
             st->misses += 1;
             if (st->misses >= patience) {                                             // :245-246
@@ -1044,7 +1050,7 @@ struct desc_pgd {
     // common
     int32_t* d_cum = nullptr;
     double *d_S0 = nullptr, *d_w[2] = {nullptr, nullptr}, *d_S[2] = {nullptr, nullptr};
-    double *d_adam_m = nullptr, *d_adam_v = nullptr, *d_nv = nullptr, *d_partials = nullptr;
+    double *d_adam_m[2] = {nullptr, nullptr}, *d_adam_v[2] = {nullptr, nullptr}, *d_nv = nullptr, *d_partials = nullptr;
     double *d_obj = nullptr, *d_avg = nullptr, *d_scratch = nullptr;
     DevState* d_state = nullptr;
     // gather variant
@@ -1072,6 +1078,7 @@ struct desc_pgd {
     double* x_sall = nullptr;           //   world * slice_len
     double* d_pairs = nullptr;          // 2*world gathered scalars
     bool borrowed_stream = false, objective_done = false;
+    int final_obj_T = -1;               // sweep count for which download already evaluated the objective
     int32_t* d_rank_seg = nullptr;
     int trace_cap = 0;
     // run state
@@ -1133,10 +1140,10 @@ void host_parallel(int64_t count, F&& body, int64_t grain = 65536) {
     for (auto& x : th) x.join();
 }
 
-StepArgs make_step(desc_pgd* h, bool* adam) {
+StepArgs make_step(desc_pgd* h, bool* adam, int rd, int wr) {
     const desc_params& p = h->p;
     StepArgs s{};
-    s.adam_m = h->d_adam_m; s.adam_v = h->d_adam_v;
+    s.adam_m = h->d_adam_m[rd]; s.adam_v = h->d_adam_v[rd]; s.adam_m_out = h->d_adam_m[wr]; s.adam_v_out = h->d_adam_v[wr];
     // one GetStep call per iteration (DESC_PGD.m:207): the plugin counter advances first
     const int tp = ++h->t_plugin;
     s.lr = p.lr; s.beta1 = p.beta1; s.beta2 = p.beta2; s.bc1 = 1.0; s.bc2 = 1.0;
@@ -1183,7 +1190,7 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
     const desc_params& p = h->p;
     const int rd = (t - 1) & 1, wr = t & 1;
     bool adam = false;
-    const StepArgs st = make_step(h, &adam);
+    const StepArgs st = make_step(h, &adam, rd, wr);
     if (ev0) (void)hipEventRecord(ev0, h->stream);
     if (h->variant == VARIANT_NODE) {
         hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 2 * sizeof(int)), h->stream,
@@ -1738,7 +1745,7 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
             rc = dalloc(h, &h->d_partials, 2 * (size_t)std::max(h->grid, h->obj_grid)); if (rc) return rc;
         }
     }
-    h->t_done = 0; h->t_plugin = p->t0; h->ms_pgd = 0; h->objective_done = false;
+    h->t_done = 0; h->t_plugin = p->t0; h->ms_pgd = 0; h->objective_done = false; h->final_obj_T = -1;
     const int cap = std::max(1, p->iters);
     if (cap > h->trace_cap) {
         dfree(h, h->d_obj); dfree(h, h->d_avg);
@@ -1747,17 +1754,19 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
         rc = dalloc(h, &h->d_avg, cap); if (rc) return rc;
         h->trace_cap = cap;
     }
-    if (p->step_kind == DESC_STEP_HYBRID && p->hybrid_strategy == 0 && !h->d_adam_m) {
-        rc = dalloc(h, &h->d_adam_m, local_cycles(h)); if (rc) return rc;
-        rc = dalloc(h, &h->d_adam_v, local_cycles(h)); if (rc) return rc;
-    }
+    if (p->step_kind == DESC_STEP_HYBRID && p->hybrid_strategy == 0 && !h->d_adam_m[0])
+        for (int q = 0; q < 2; ++q) {
+            rc = dalloc(h, &h->d_adam_m[q], local_cycles(h)); if (rc) return rc;
+            rc = dalloc(h, &h->d_adam_v[q], local_cycles(h)); if (rc) return rc;
+        }
     DESC_HIP(hipMemsetAsync(h->d_state, 0, sizeof(DevState), h->stream));
     DESC_HIP(hipMemsetAsync(h->d_obj, 0, sizeof(double) * h->trace_cap, h->stream));
     DESC_HIP(hipMemsetAsync(h->d_avg, 0, sizeof(double) * h->trace_cap, h->stream));
-    if (h->d_adam_m) {
-        DESC_HIP(hipMemsetAsync(h->d_adam_m, 0, sizeof(double) * std::max<int64_t>(1, local_cycles(h)), h->stream));
-        DESC_HIP(hipMemsetAsync(h->d_adam_v, 0, sizeof(double) * std::max<int64_t>(1, local_cycles(h)), h->stream));
-    }
+    if (h->d_adam_m[0])
+        for (int q = 0; q < 2; ++q) {
+            DESC_HIP(hipMemsetAsync(h->d_adam_m[q], 0, sizeof(double) * std::max<int64_t>(1, local_cycles(h)), h->stream));
+            DESC_HIP(hipMemsetAsync(h->d_adam_v[q], 0, sizeof(double) * std::max<int64_t>(1, local_cycles(h)), h->stream));
+        }
     const int64_t slen = h->variant == VARIANT_NODE ? 2 * h->m : h->m;
     if (slen > 0) {                                                       // S_vec = ones(1,m)  (:148)
         int g = (int)std::min<int64_t>(1024, (slen + 255) / 256);
@@ -1833,7 +1842,8 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
     int rc = set_device(h); if (rc) return rc;
     const int T = h->t_done;
     // objective of the last sweep (DESC_PGD.m:233) and its stop test
-    if (h->m_pos > 0 && T >= 1 && h->world == 1) {
+    if (h->m_pos > 0 && T >= 1 && h->world == 1 && h->final_obj_T != T) {
+        h->final_obj_T = T;
         if (h->variant == VARIANT_NODE)
             hipLaunchKernelGGL(k_objective_node, dim3(h->obj_grid), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_einfo + h->seg_lo, h->d_pk,
                                h->d_w[T & 1], h->d_S[T & 1], (int)(h->seg_hi - h->seg_lo), h->d_partials, h->d_state);
@@ -1869,7 +1879,7 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
     }
     if (h->world > 1 && (r->w || r->adam_m || r->adam_v))
         return fail(DESC_ERR_INVALID, "per-cycle outputs (w, Adam state) are not gathered across ranks");
-    if (r->w || (h->d_adam_m && r->adam_m && r->adam_v)) { rc = ensure_scratch(h); if (rc) return rc; }
+    if (r->w || (h->d_adam_m[0] && r->adam_m && r->adam_v)) { rc = ensure_scratch(h); if (rc) return rc; }
     if (r->w) { rc = cycles_to_host(h, h->d_w[par], r->w); if (rc) return rc; }
     if (r->obj_trace && iters_run > 0) {
         if (h->m_pos > 0) DESC_HIP(hipMemcpy(r->obj_trace, h->d_obj, sizeof(double) * iters_run, hipMemcpyDeviceToHost));
@@ -1879,9 +1889,9 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
         if (h->m_pos > 0) DESC_HIP(hipMemcpy(r->avg_change_trace, h->d_avg, sizeof(double) * iters_run, hipMemcpyDeviceToHost));
         else std::memset(r->avg_change_trace, 0, sizeof(double) * iters_run);
     }
-    if (h->d_adam_m && r->adam_m && r->adam_v) {
-        rc = cycles_to_host(h, h->d_adam_m, r->adam_m); if (rc) return rc;
-        rc = cycles_to_host(h, h->d_adam_v, r->adam_v); if (rc) return rc;
+    if (h->d_adam_m[0] && r->adam_m && r->adam_v) {          // the state after exactly iters_run GetStep calls
+        rc = cycles_to_host(h, h->d_adam_m[par], r->adam_m); if (rc) return rc;
+        rc = cycles_to_host(h, h->d_adam_v[par], r->adam_v); if (rc) return rc;
     }
     r->ms_upload = h->ms_upload; r->ms_cycle_d = h->ms_cycle_d; r->ms_pgd = h->ms_pgd;
     return DESC_OK;
@@ -1894,9 +1904,9 @@ int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r) {
     if (p->step_kind == DESC_STEP_HYBRID && p->hybrid_strategy == 0 && p->t0 > 0 && r->adam_m && r->adam_v && h->m_cycle > 0) {
         // HybridGradient keeps m_t / v_t between calls (handle object)
         rc = ensure_scratch(h); if (rc) return rc;
-        rc = cycles_to_device(h, r->adam_m, h->d_adam_m); if (rc) return rc;
+        rc = cycles_to_device(h, r->adam_m, h->d_adam_m[0]); if (rc) return rc;      // sweep 1 reads parity 0
         DESC_HIP(hipStreamSynchronize(h->stream));
-        rc = cycles_to_device(h, r->adam_v, h->d_adam_v); if (rc) return rc;
+        rc = cycles_to_device(h, r->adam_v, h->d_adam_v[0]); if (rc) return rc;
         DESC_HIP(hipStreamSynchronize(h->stream));
     }
     const int chunk = p->check_every > 0 ? p->check_every : 32;
@@ -1965,7 +1975,7 @@ int desc_pgd_shard_sweep(desc_pgd* h) {
     int rc = set_device(h); if (rc) return rc;
     const int t = ++h->t_done, rd = (t - 1) & 1, wr = t & 1;
     bool adam = false;
-    const StepArgs st = make_step(h, &adam);
+    const StepArgs st = make_step(h, &adam, rd, wr);
     NodeSweepArgs a{};
     a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
     a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_Trecv; a.t_seg_lo = (int32_t)h->seg_lo; a.nv_tab = h->d_nv; a.partials = h->d_partials;

@@ -315,7 +315,8 @@ extern "C" int desc_refine_run(const desc_problem* prob, const double* s_vec, co
 
     double score = INFINITY, quant_ratio = 1.0;
     const double quant_ratio_min = 0.8;
-    int Iteration = 1, cg_total = 0;
+    int Iteration = 1, cg_total = 0, cg_unconverged = 0;
+    double cg_worst = 0.0;
     std::vector<double> part(sgrid), rs((size_t)m);
     CgScal hs;
     while (score > stop_threshold && Iteration < max_iters) {                               // DESC.m:287
@@ -340,7 +341,11 @@ extern "C" int desc_refine_run(const desc_problem* prob, const double* s_vec, co
                 DESC_HIP(hipMemcpy(&hs, d_sc, sizeof hs, hipMemcpyDeviceToHost));
                 bool done = true;
                 for (int c = 0; c < 3; ++c) if (hs.rnorm[c] > 1e-26 * hs.bnorm[c] && hs.rnorm[c] > 1e-300) done = false;   // |r| <= 1e-13 |b|
-                if (done) break;
+                if (done || k == cg_max) {
+                    for (int c = 0; c < 3; ++c) if (hs.bnorm[c] > 0) cg_worst = std::max(cg_worst, std::sqrt(hs.rnorm[c] / hs.bnorm[c]));
+                    if (!done) ++cg_unconverged;
+                    break;
+                }
             }
         }
         cg_total += std::min(k, cg_max);
@@ -360,11 +365,15 @@ extern "C" int desc_refine_run(const desc_problem* prob, const double* s_vec, co
         if (info && info->verbose) printf("Iter %d: ||\xce\x94R||= %f\n", Iteration, score);                 // DESC.m:305
         ++Iteration;
     }
+    if (cg_unconverged)
+        fprintf(stderr, "[desc_amd] warning: %d of %d Weighted_LAA solves stopped at the PCG iteration cap (relative residual up to %.3e)\n",
+                cg_unconverged, Iteration - 1, cg_worst);
     hipLaunchKernelGGL(k_q2r, dim3(ngrid), dim3(256), 0, 0, d_Q, d_Rout, n);                // DESC.m:309-312
     DESC_HIP(hipDeviceSynchronize());
     DESC_HIP(hipMemcpy(R_out, d_Rout, sizeof(double) * 9 * n, hipMemcpyDeviceToHost));
     if (info) {
         info->iters = Iteration - 1; info->score = score; info->cg_iters = cg_total;
+        info->cg_unconverged = cg_unconverged; info->cg_residual = cg_worst;
         info->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return DESC_OK;

@@ -12,6 +12,7 @@
 // the n_sample smallest desc_sample_key values by rank counting in LDS (keys are staged
 // once per edge; every lane counts how many keys precede its own).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cmath>
@@ -486,8 +487,11 @@ int build_cemp_samples_device(const desc_problem* prob, int32_t nsample, uint64_
 
 // Full index structure of a device-built structure on the host: derive e_jk / e_ki and the mirror
 // maps on the device, copy everything down once.
+static std::atomic<int64_t> g_host_exports{0};
+
 int structure_ensure_host(desc_structure* s) {
     if (!s || s->host_cycles) return DESC_OK;
+    g_host_exports.fetch_add(1);
     const int64_t mc = s->m_cycle, mp = s->m_pos;
     DESC_HIP(hipSetDevice(s->dev));
     DevBuf D;
@@ -521,3 +525,6 @@ void structure_free_device(desc_structure* s) {
 }
 
 }  // namespace desc
+
+extern "C" int64_t desc_structure_host_exports(void) { return desc::g_host_exports.load(); }
+

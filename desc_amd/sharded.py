@@ -208,7 +208,9 @@ def _bench_one(name, args, rank, world, device, comm, describe, generate):
     t0 = time.perf_counter()
     try:
         st = _lib.Structure.build(prob, 30, args.seed, _lib.BUILD_DEVICE, device)
-    except _lib.DescError:
+    except _lib.DescError as e:
+        if e.code != _lib.ERR_TOO_LARGE:
+            raise
         st = _lib.Structure.build(prob, 30, args.seed, _lib.BUILD_HOST, device)
     t_struct = time.perf_counter() - t0
     n_sample = st.sizes()["n_sample"]

@@ -97,8 +97,26 @@ int desc_structure_import(int64_t n, int64_t m, int64_t m_pos, int32_t n_sample,
                           const int32_t* ikj, const int32_t* jki, desc_structure** out);
 /* Host view of the full index structure.  For a device-built structure the first call derives
  * e_jk, e_ki and the mirror maps on the device and copies them down (O(m_cycle)); later calls
- * are free.  Not thread-safe per structure; the view stays valid until desc_structure_free. */
+ * are free.  Not thread-safe per structure; the view stays valid until desc_structure_free.
+ * Callers that only need the sizes use desc_structure_sizes, which never touches the device. */
 int desc_structure_get(const desc_structure* s, desc_structure_view* view);
+/* Sizes and build facts of a structure (DESC_PGD.m:43,50,51) without materialising anything: O(1), no
+ * device work, no host copy -- what a binding needs to size the per-cycle in/out vectors
+ * (HybridGradient.m_t / v_t) before desc_pgd_create. */
+typedef struct desc_structure_info {
+    int64_t n, m;
+    int64_t m_pos;            /* edges with >=1 triangle                       DESC_PGD.m:50 */
+    int64_t m_cycle;          /* sampled cycles in total                       DESC_PGD.m:51 */
+    int32_t n_sample;         /* DESC_PGD.m:43 */
+    int32_t max_cnt;          /* longest segment */
+    int32_t built_where;      /* DESC_BUILD_HOST | DESC_BUILD_DEVICE (imported structures: HOST) */
+    int32_t host_resident;    /* 1 when the per-cycle index arrays exist in host memory */
+    double  ms_build;         /* wall clock of desc_structure_build, milliseconds */
+} desc_structure_info;
+int desc_structure_sizes(const desc_structure* s, desc_structure_info* info);
+/* Number of times, in this process, a device-built structure was exported to host memory
+ * (k_cycle_edges + k_mirror + five O(m_cycle) copies).  Diagnostics: the solver path must not need it. */
+int64_t desc_structure_host_exports(void);
 void desc_structure_free(desc_structure* s);
 uint64_t desc_sample_key(uint64_t seed, uint64_t edge, uint64_t k);
 
@@ -165,8 +183,8 @@ const char* desc_pgd_kernel_name(const desc_pgd* h);
 /* One process per GPU.  The edges with cycles (in the library's band-major order) are cut
  * into `world` contiguous ranges of equal cycle count; rank r keeps the per-cycle state
  * (weights, inconsistencies, packed indices) of its range only, and a full replica of the
- * O(m) vectors.  One PGD iteration = desc_pgd_shard_colsum -> all-reduce(sum) of T ->
- * desc_pgd_shard_sweep -> all-gather of sall -> desc_pgd_shard_finish.  The collectives are
+ * O(m) vectors.  One PGD iteration = desc_pgd_shard_colsum -> reduce-scatter(sum) of T_send
+ * into T_recv -> desc_pgd_shard_sweep -> all-gather of sall -> desc_pgd_shard_finish.  The collectives are
  * the caller's (torch.distributed over RCCL in desc_amd/sharded.py); T and sall are device
  * buffers the caller allocates and binds.  All ranks take identical stop decisions because
  * every rank adds the gathered scalar partials in rank order. */
@@ -230,14 +248,18 @@ int desc_cemp_run(const desc_problem* prob, const double* beta, int32_t n_beta, 
 /* Reweighted Lie-algebraic averaging, Algorithms/DESC.m:265-313 with Utils/Weighted_LAA.m,
  * Build_Amatrix.m, R2Q.m, q2R.m.  s_vec: m (the PGD output), R_init: n*9 (3x3xn column-major, the
  * GCW output, DESC.m:263), R_out: n*9.  stop_threshold <= 0 -> 1e-3, max_iters <= 0 -> 100
- * (DESC.m:272).  MATLAB's sparse-QR least squares is replaced by f64 PCG on the normal equations. */
+ * (DESC.m:272).  MATLAB's sparse-QR least squares is replaced by f64 PCG on the normal equations; the
+ * weights span 1e-4..1e4 (DESC.m:279-282), squared in the normal equations, so a solve may stop at its
+ * iteration cap: info->cg_unconverged / cg_residual say so, and a warning is printed to stderr. */
 typedef struct desc_refine_info {
     int32_t iters;            /* refinement steps executed                                     */
     int32_t cg_iters;         /* conjugate-gradient steps in total                             */
     int32_t verbose;          /* in: print the reference's "Iter %d: ||dR||= %f" lines          */
-    int32_t reserved;
+    int32_t cg_unconverged;   /* refinement steps whose PCG solve stopped at its iteration cap
+                                 before reaching |r| <= 1e-13 |b| (0 = every solve converged)   */
     double  score;            /* last mean rotation update (Weighted_LAA.m:40)                 */
     double  ms_total;
+    double  cg_residual;      /* largest relative residual |r|/|b| left by any of the solves   */
 } desc_refine_info;
 int desc_refine_run(const desc_problem* prob, const double* s_vec, const double* R_init, double stop_threshold,
                     int32_t max_iters, int32_t device, double* R_out, desc_refine_info* info);

@@ -60,11 +60,17 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
 
     /* sizes of the per-cycle vectors are only known after the structure is built */
     desc_structure* st = NULL;
-    if (desc_structure_build(&prob, p.n_sample_min, p.seed, p.build_where, p.device, &st) != DESC_OK)
+    int rc = desc_structure_build(&prob, p.n_sample_min, p.seed, p.build_where, p.device, &st);
+    if (rc == DESC_ERR_TOO_LARGE && p.build_where == DESC_BUILD_DEVICE)   /* beyond the device builder's staging budget */
+        rc = desc_structure_build(&prob, p.n_sample_min, p.seed, DESC_BUILD_HOST, p.device, &st);
+    if (rc != DESC_OK) mexErrMsgIdAndTxt("desc_amd:structure", "%s", desc_last_error());
+    desc_structure_info v;                     /* O(1): the structure stays in HBM */
+    if (desc_structure_sizes(st, &v) != DESC_OK) {
+        desc_structure_free(st);
         mexErrMsgIdAndTxt("desc_amd:structure", "%s", desc_last_error());
-    desc_structure_view v;
-    desc_structure_get(st, &v);
+    }
     const mwSize mc = (mwSize)v.m_cycle;
+    const double ms_structure = v.ms_build;
 
     plhs[0] = mxCreateDoubleMatrix(1, m, mxREAL);
     mxArray* obj = mxCreateDoubleMatrix(1, p.iters > 0 ? p.iters : 1, mxREAL);
@@ -87,8 +93,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (p.step_kind == DESC_STEP_HYBRID && p.hybrid_strategy == 0) { r.adam_m = mxGetPr(am); r.adam_v = mxGetPr(av); }
 
     desc_pgd* h = NULL;
-    int rc = desc_pgd_create(&prob, st, p.device, &h);
-    const double ms_structure = 0.0;
+    rc = desc_pgd_create(&prob, st, p.device, &h);
     desc_structure_free(st);
     if (rc == DESC_OK) rc = desc_pgd_run(h, &p, &r);
     if (h) desc_pgd_destroy(h);

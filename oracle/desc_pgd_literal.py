@@ -155,7 +155,7 @@ def default_sampler(rng):
 
 
 def desc_pgd_literal(Ind, RijMat, iters, Gradient, sampler=None, verbose=False,
-                     patience=30, return_state=False):
+                     patience=30, return_state=False, forced_lists=None):
     """Literal restatement of DESC_PGD.m:19-261.
 
     Ind      (m,2) integer array, 1-based node ids, i<j, sorted as the reference
@@ -167,6 +167,10 @@ def desc_pgd_literal(Ind, RijMat, iters, Gradient, sampler=None, verbose=False,
              entries of CoInd_ij (1-based node ids) standing in for ``datasample``.
              ``l`` is the 1-based index among edges with cycles, ``IJ`` the 1-based
              edge index.
+    forced_lists  test hook, not in the reference: {IJ: kept third vertices (1-based)} replaces
+             the outcome of :83-85 for the listed edges (any non-empty subset of the common
+             neighbours), so that hand-sized graphs can have absent mirror cycles.  The reference
+             itself only samples edges with >= 30 common neighbours.
 
     Returns S_vec (m,) and, if return_state, a dict with the structure arrays and
     per-iteration traces.
@@ -196,6 +200,10 @@ def desc_pgd_literal(Ind, RijMat, iters, Gradient, sampler=None, verbose=False,
     n_sample = int(n_sample)
 
     CoDeg_vec_pos_sampled = np.minimum(CoDeg_vec_pos, n_sample).astype(np.int64)   # :45
+    if forced_lists:
+        for t, IJ in enumerate(CoDeg_pos_ind):
+            if int(IJ) in forced_lists:
+                CoDeg_vec_pos_sampled[t] = len(forced_lists[int(IJ)])
     cum_ind = np.concatenate([[0], np.cumsum(CoDeg_vec_pos_sampled)]).astype(np.int64)  # :49
     m_pos = CoDeg_pos_ind.shape[0]                               # :50
     m_cycle = int(cum_ind[-1])                                   # :51
@@ -231,7 +239,11 @@ def desc_pgd_literal(Ind, RijMat, iters, Gradient, sampler=None, verbose=False,
         IJ = CoDeg_pos_ind[l - 1]
         i = Ind_i[IJ - 1]; j = Ind_j[IJ - 1]
         CoInd_ij = np.flatnonzero(AdjMat[:, i - 1] * AdjMat[:, j - 1]) + 1     # :82
-        if CoInd_ij.shape[0] >= n_sample:                        # :83
+        if forced_lists and int(IJ) in forced_lists:
+            kept = np.asarray(forced_lists[int(IJ)], dtype=np.int64)
+            assert kept.size and np.all(np.isin(kept, CoInd_ij))
+            CoInd_ij = kept
+        elif CoInd_ij.shape[0] >= n_sample:                      # :83
             CoInd_ij = np.asarray(sampler(l, IJ, CoInd_ij, n_sample), dtype=np.int64)   # :84
             assert CoInd_ij.shape[0] == n_sample
         lo, hi = cum_ind[l - 1], cum_ind[l]                      # range (lo+1):hi

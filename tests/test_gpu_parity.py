@@ -341,3 +341,83 @@ def test_c_client(lib, tmp_path):
     r = _build_c_example(tmp_path)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "iterations" in r.stdout and "s(corrupted edge" in r.stdout
+
+
+@pytest.mark.parametrize("variant", ["node", "gather"])
+def test_sampling_regime_known_answer_by_hand(lib, variant):
+    """The hand-tabulated two iterations of tests/kat_sampling.py (mirror cycles absent: the per-edge
+    scalar sums of DESC_PGD.m:189-190 reach only the masked positions) through the C ABI, both layouts."""
+    from tests import kat_sampling as K
+    Ind = np.array(K.EDGES)
+    ii = Ind[:, 0].astype(np.int32) - 1; jj = Ind[:, 1].astype(np.int32) - 1
+    rij = np.ascontiguousarray(np.transpose(K.rotations(), (2, 1, 0))).reshape(-1)
+    for iters, W, S, objs, avgs in ((1, K.W1, K.S1, [K.OBJ1], [K.AVG1]), (2, K.W2, K.S2, [K.OBJ1, K.OBJ2], [K.AVG1, K.AVG2])):
+        imp = lib.Structure.from_arrays(4, 6, 30, K.POS_EDGE, K.CUM_IND, K.K, K.E_JK, K.E_KI, K.IKJ, K.JKI)
+        _, s0, out = run_gpu(lib, 4, ii, jj, rij, c_params(iters, lr=K.LR), structure=imp, variant=variant)
+        assert np.abs(s0 - K.D).max() < K.TOL
+        assert np.abs(out["w"] - W).max() < K.TOL and np.abs(out["S_vec"] - S).max() < K.TOL
+        assert np.abs(out["obj"] - objs).max() < K.TOL and np.abs(out["avg"] - avgs).max() < K.TOL
+
+
+def test_wrapper_keeps_device_structure_on_the_device(lib):
+    """DESC_PGD() / DESC() on a device-built structure must not export it to the host (k_cycle_edges +
+    k_mirror + 5 x m_cycle int32 of D2H): sizes come from desc_structure_sizes."""
+    from desc_amd import ConstantStepSize, DESC, DESC_PGD
+    mo, nn, ii, jj, rij = make_problem("uniform", n=120, p=0.5, seed=31)
+    before = lib.host_exports()
+    S, info = DESC_PGD(mo.Ind, mo.RijMat, dict(iters=5, Gradient=ConstantStepSize(0.01), verbose=False), return_info=True)
+    DESC(mo.Ind, mo.RijMat, dict(iters=5, Gradient=ConstantStepSize(0.01), verbose=False))
+    assert lib.host_exports() == before
+    assert info["m_cycle"] > 0 and info["n_sample"] == 30 and info["ms_structure"] > 0 and info["built_where"] == lib.BUILD_DEVICE
+    # asking for the arrays still works and is what bumps the counter
+    st = lib.Structure.build(lib.ProblemArrays(nn, ii, jj), 30, 0, lib.BUILD_DEVICE, 0)
+    assert st.sizes()["m_cycle"] == info["m_cycle"] and not st.sizes()["host_resident"]
+    assert lib.host_exports() == before
+    st.arrays()
+    assert lib.host_exports() == before + 1 and st.sizes()["host_resident"]
+    st.free()
+
+
+@pytest.mark.parametrize("variant", ["node", "gather"])
+def test_adam_state_after_early_stop(lib, oracle, variant):
+    """HybridGradient (Adam) with the patience rule firing before iters is exhausted: the stop of iteration
+    `it` is only known during sweep it+1, whose Adam update must not leak into the returned m_t / v_t
+    (HybridGradient.m:28-31 is applied exactly iters_run times)."""
+    mo, nn, ii, jj, rij = make_problem("uniform", n=40, p=0.5, q=0.1, sigma=0.0, seed=10)
+    kw = dict(step_kind=2, lr=0.05, beta1=0.9, beta2=0.999, decay_interval=10, patience=3, stop_tol=1e-2)
+    st = oracle.build_structure(nn, ii, jj, seed=1)
+    S0 = oracle.cycle_d(ii, jj, rij.reshape(-1, 9), st)
+    am = np.zeros(st["m_cycle"]); av = np.zeros(st["m_cycle"])
+    ref = oracle.pgd_run(st, S0, 300, adam_m=am, adam_v=av, **kw)
+    assert 3 < ref["iters_run"] < 300
+    for chk in (0, 2):
+        gm = np.zeros(st["m_cycle"]); gv = np.zeros(st["m_cycle"])
+        _, s0, out = run_gpu(lib, nn, ii, jj, rij, c_params(300, seed=1, check_every=chk, **kw), variant=variant, adam=(gm, gv))
+        check(out, ref, s0, S0, tol=1e-9)
+        assert out["t_end"] == ref["iters_run"]
+        assert np.abs(out["adam_m"] - am).max() < 1e-9 and np.abs(out["adam_v"] - av).max() < 1e-9
+
+
+def test_download_between_iterations_does_not_double_count(lib, oracle):
+    """Piecewise API iterate -> download -> iterate: the objective/stop bookkeeping of an iteration is
+    done once, however often its state is downloaded (DESC_PGD.m:243-256 misses counter)."""
+    mo, nn, ii, jj, rij = make_problem("uniform", n=40, p=0.5, q=0.1, sigma=0.0, seed=10)
+    st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=1, iters=400, lr=1.0, patience=5, stop_tol=1e-3)
+    assert 8 < ref["iters_run"] < 400
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    hst = lib.Structure.build(prob, 30, 1, lib.BUILD_HOST, 0)
+    solver = lib.Solver(prob, hst, 0)
+    p = c_params(400, lr=1.0, seed=1, patience=5, stop_tol=1e-3)
+    solver.reset(p)
+    done = 0
+    while done < 400:
+        solver.iterate(1); done += 1
+        mid = solver.download(); mid2 = solver.download()          # twice: still counted once
+        assert np.array_equal(mid["S_vec"], mid2["S_vec"])
+        if mid["iters_run"] < done:
+            break
+    out = solver.download(want_w=True)
+    solver.destroy(); hst.free()
+    assert out["iters_run"] == ref["iters_run"]
+    assert np.abs(out["S_vec"] - ref["S_vec"]).max() <= TOL and np.abs(out["w"] - ref["w"]).max() <= TOL
+    assert np.allclose(out["obj"], ref["obj"], rtol=1e-12, atol=1e-9)

@@ -36,6 +36,8 @@ def test_struct_layouts_match_header(lib):
     assert C.sizeof(lib.Params) == 96
     assert C.sizeof(lib.Result) == 96
     assert C.sizeof(lib.StructureView) == 104
+    assert C.sizeof(lib.StructureInfo) == 56
+    assert C.sizeof(lib.RefineInfo) == 40
     p = lib.default_params()
     assert (p.iters, p.step_kind, p.patience, p.n_sample_min, p.build_where) == (100, 0, 30, 30, lib.BUILD_DEVICE)
     assert p.lr == 0.01 and p.stop_tol == 1e-5
@@ -110,6 +112,20 @@ def test_structure_edge_cases(lib):
     pos = a["codeg"][a["codeg"] > 0]
     assert a["n_sample"] == max(5, int(np.ceil(np.median(pos) / 4)))
     assert (np.diff(a["cum_ind"]) <= a["n_sample"]).all()
+
+
+def test_structure_sizes_is_cheap_and_matches_view(lib):
+    """desc_structure_sizes: the O(1) query bindings use to size per-cycle vectors (MEX shim, DESC_PGD())."""
+    mo, nn, ii, jj, _ = make_problem("uniform", n=60, p=0.6, seed=3)
+    st = lib.Structure.build(lib.ProblemArrays(nn, ii, jj), 30, 7)
+    sz, a = st.sizes(), st.arrays()
+    for key in ("n", "m", "m_pos", "m_cycle", "n_sample", "max_cnt"):
+        assert sz[key] == a[key], key
+    assert sz["built_where"] == lib.BUILD_HOST and sz["host_resident"] and sz["ms_build"] > 0
+    assert lib.host_exports() == 0                  # nothing device-built in a CPU-only process
+    with pytest.raises(lib.DescError) as ei:
+        lib.check(lib.load().desc_structure_sizes(None, None))
+    assert ei.value.code == lib.ERR_INVALID
 
 
 def test_marshal_edges_sorts_and_unpermutes():

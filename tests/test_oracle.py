@@ -129,6 +129,33 @@ def test_k4_one_corrupted_edge_first_iterations_by_hand():
     assert np.argmax(S50) == 0
 
 
+def test_sampling_regime_known_answer_by_hand(oracle):
+    """Mirror cycles absent (DESC_PGD.m:113,124 false): the per-edge scalar mirror sums of :189-190 reach
+    only the positions whose mirror was sampled.  Two iterations tabulated by hand in tests/kat_sampling.py;
+    both restatements must reproduce them, and the literal one must derive the same index structure."""
+    from tests import kat_sampling as K
+    Ind = np.array(K.EDGES)
+    for iters, W, S, objs, avgs in ((1, K.W1, K.S1, [K.OBJ1], [K.AVG1]), (2, K.W2, K.S2, [K.OBJ1, K.OBJ2], [K.AVG1, K.AVG2])):
+        Sv, st = desc_pgd_literal(Ind, K.rotations(), iters, ConstantStepSize(K.LR), return_state=True, forced_lists=K.FORCED)
+        assert np.abs(st["S0_long"] - K.D).max() < K.TOL
+        assert np.array_equal(st["cum_ind"], K.CUM_IND) and np.array_equal(st["IJK"] - 1, K.K)
+        assert np.array_equal(st["Ind_jk"] - 1, K.E_JK) and np.array_equal(st["Ind_ki"] - 1, K.E_KI)
+        assert np.array_equal(st["IKJ"] - 1, K.IKJ) and np.array_equal(st["JKI"] - 1, K.JKI)
+        assert np.abs(st["wijk"] - W).max() < K.TOL and np.abs(Sv - S).max() < K.TOL
+        assert np.abs(np.array(st["obj_vals"]) - objs).max() < K.TOL and np.abs(np.array(st["avg_changes"]) - avgs).max() < K.TOL
+        sd = K.structure_dict()
+        ii = Ind[:, 0].astype(np.int32) - 1; jj = Ind[:, 1].astype(np.int32) - 1
+        rij = np.ascontiguousarray(np.transpose(K.rotations(), (2, 1, 0))).reshape(-1, 9)
+        d = oracle.cycle_d(ii, jj, rij, sd)
+        assert np.abs(d - K.D).max() < K.TOL
+        res = oracle.pgd_run(sd, d, iters, lr=K.LR)
+        assert np.abs(res["w"] - W).max() < K.TOL and np.abs(res["S_vec"] - S).max() < K.TOL
+        assert np.abs(res["obj"] - objs).max() < K.TOL and np.abs(res["avg"] - avgs).max() < K.TOL
+    # initial state (:148-157)
+    Sv, st = desc_pgd_literal(Ind, K.rotations(), 0, ConstantStepSize(K.LR), return_state=True, forced_lists=K.FORCED)
+    assert np.abs(st["wijk"] - K.W0).max() < K.TOL and np.abs(Sv - K.S_INIT).max() < K.TOL
+
+
 # ------------------------------------------------------------------ invariants / cross-checks
 @pytest.mark.parametrize("n,p,seed", [(30, 0.5, 1), (110, 0.6, 2)])
 def test_literal_vs_sparse_c_oracle(oracle, n, p, seed):
