@@ -10,9 +10,10 @@ inconsistencies are already resident in HBM when the timed region starts.
 
 Every N runs BASELINE.json configs[1] (C2: Uniform n=1000 p=0.5 q=0.3, sigma=0.1) -- strong
 scaling: the total work is fixed, at N > 1 the edges-with-cycles are sharded over the ranks with
-a reduce-scatter and an all-gather per iteration (desc_amd/sharded.py).  C2 is small enough that a
-single GPU is about as fast as any sharding, so the N > 1 line additionally carries
-`north_star_config`: the same measurement on C4 (configs[3], n=5000 p=0.2).
+a reduce-scatter and an all-gather per iteration (desc_amd/sharded.py).  `value` is always C2; the
+line additionally carries `north_star_config`: the same measurement (iterations/s, roofline of the
+kernel pair, really timed end-to-end call) on C4 (configs[3], n=5000 p=0.2 -- the workload the
+north star's target is quoted on; it fits one GPU).
 Prints ONE JSON line (rank 0) with the contract's fields plus `roofline` (dominant
 kernel: the sweep, HBM-bound, algorithmic bytes 72*m_cycle + 12*m_pos per launch,
 SURVEY.md 8d) and `cpu_baseline` (the oracle's OpenMP C restatement timed on this
@@ -68,28 +69,153 @@ def generate(name):
     return mo, nn, ii, jj, rij
 
 
-def cpu_baseline(nn, ii, jj, rij, arrays, budget_s=20.0, max_iters=50):
-    """Time the oracle's C/OpenMP restatement of the same sweep on this host."""
+def cpu_baseline(nn, ii, jj, rij, arrays, budget_s=20.0, max_iters=50, threads=None):
+    """Time the oracle's C/OpenMP restatement of the same sweep on this host (threads=None: min(16, granted CPUs))."""
     from oracle import oracle as O
     O.build()
-    st = {k: arrays[k] for k in ("m", "m_pos", "m_cycle", "pos_edge", "cum_ind", "k", "e_jk", "e_ki", "ikj", "jki")}
-    S0 = O.cycle_d(ii, jj, rij.reshape(-1, 9), st)
-    t = time.perf_counter()
-    O.pgd_run(st, S0, 2, lr=0.01, patience=1 << 30)
-    per_iter = (time.perf_counter() - t) / 2
-    iters = int(max(2, min(max_iters, budget_s / max(per_iter, 1e-6))))
-    t = time.perf_counter()
-    ref = O.pgd_run(st, S0, iters, lr=0.01, patience=1 << 30)
-    dt = time.perf_counter() - t
+    L = O.lib()
+    default_threads = O.num_threads()
+    if threads:
+        L.oracle_set_threads(int(threads))
+    try:
+        st = {k: arrays[k] for k in ("m", "m_pos", "m_cycle", "pos_edge", "cum_ind", "k", "e_jk", "e_ki", "ikj", "jki")}
+        S0 = O.cycle_d(ii, jj, rij.reshape(-1, 9), st)
+        t = time.perf_counter()
+        O.pgd_run(st, S0, 2, lr=0.01, patience=1 << 30)
+        per_iter = (time.perf_counter() - t) / 2
+        iters = int(max(2, min(max_iters, budget_s / max(per_iter, 1e-6))))
+        t = time.perf_counter()
+        ref = O.pgd_run(st, S0, iters, lr=0.01, patience=1 << 30)
+        dt = time.perf_counter() - t
+        cores = O.num_threads()
+    finally:
+        L.oracle_set_threads(default_threads)
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
             model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
     except OSError:
         pass
-    return dict(value=iters / dt, unit="iters/s", cores=O.num_threads(), kind="port",
+    return dict(value=iters / dt, unit="iters/s", cores=cores, kind="port",
                 sample=f"{iters} PGD iterations of the same workload (oracle/desc_oracle.c, OpenMP)",
                 host_cpus=os.cpu_count(), cpu_model=model), ref, iters
+
+
+def literal_baseline(budget_iters=4):
+    """SURVEY.md 8d "reference-style interpreted" data point: the line-by-line NumPy restatement of DESC_PGD.m
+    (dense n x n / n x m_pos arrays, interpreted per-edge loops, like the MATLAB original) on C1, the only
+    BASELINE configuration the reference's own data structures fit comfortably."""
+    from oracle.desc_pgd_literal import ConstantStepSize as LConst, desc_pgd_literal
+    from oracle.oracle import keyed_sampler
+    mo, nn, ii, jj, rij = generate("C1")
+    t = time.perf_counter()
+    desc_pgd_literal(mo.Ind, mo.RijMat, 0, LConst(0.01), sampler=keyed_sampler(0))
+    t_setup = time.perf_counter() - t
+    t = time.perf_counter()
+    desc_pgd_literal(mo.Ind, mo.RijMat, budget_iters, LConst(0.01), sampler=keyed_sampler(0))
+    t_run = time.perf_counter() - t
+    per_iter = max(t_run - t_setup, 1e-9) / budget_iters
+    return dict(value=1.0 / per_iter, unit="iters/s", cores=1, kind="port",
+                sample=f"{budget_iters} iterations of oracle/desc_pgd_literal.py (interpreted NumPy, dense arrays) on {describe('C1')}",
+                setup_s=t_setup)
+
+
+def warm_up(lib):
+    """One call on a 200-node complete graph, outside every timer: HIP context, code-object load, the runtime's
+    pinned staging buffers and first-use kernel attributes are per-process one-time costs."""
+    wi, wj = np.triu_indices(200, 1)
+    wprob = lib.ProblemArrays(200, wi.astype(np.int32), wj.astype(np.int32), np.tile(np.eye(3).reshape(-1), wi.shape[0]))
+    wp = lib.default_params(); wp.iters = 2
+    lib.solve(wprob, wp)
+
+
+def load_traffic(name):
+    """HBM bytes per iteration from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the
+    bench): FETCH_SIZE and WRITE_SIZE collected in separate runs, corrected as MI355X_MICROARCH.md prescribes
+    (tools/pmc_traffic.py); null for workloads that have not been profiled."""
+    for fn in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as f:
+                t = json.load(f).get(name, {}).get("per_iteration_bytes")
+            if t:
+                return t, fn
+        except OSError:
+            pass
+    return None, None
+
+
+def measure(lib, name, K, W, seed, convergence, keep_arrays):
+    """One workload on one GPU: K timed iterations (inputs resident in HBM), the per-kernel roofline leg, one really
+    timed desc_pgd_solve call (host arrays in -> S_vec out, 100 iterations), optionally the run to the patience exit."""
+    t0 = time.perf_counter()
+    mo, nn, ii, jj, rij = generate(name)
+    t_gen = time.perf_counter() - t0
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    t0 = time.perf_counter()
+    st = lib.Structure.build(prob, 30, seed, lib.BUILD_DEVICE, 0)
+    t_struct = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    solver = lib.Solver(prob, st, 0)
+    t_create = time.perf_counter() - t0
+    sizes = st.sizes()
+    arrays = st.arrays() if keep_arrays else None     # host copy for the CPU baseline only (untimed; the GPU path never needs it)
+    st.free()
+
+    p = lib.default_params()
+    p.iters = W + 2 * K + 8
+    p.lr = 0.01
+    p.patience = (1 << 31) - 1          # the bench times exactly K sweeps: never stop early
+    p.seed = seed
+    solver.reset(p)
+    solver.iterate(W)
+    solver.sync()
+    # ---- timed region: exactly K steps, inputs resident in HBM ----
+    t0 = time.perf_counter()
+    solver.iterate(K)
+    solver.sync()
+    dt = time.perf_counter() - t0
+    # ---- roofline leg: the same K sweeps again, each iteration's kernels bracketed by HIP events
+    #      on the launch stream (not part of `value`) ----
+    _, ms_kernel = solver.iterate_timed(K, per_kernel=True)
+    out = solver.download()
+    m_cycle, m_pos, m = solver.m_cycle, solver.m_pos, solver.m
+    kname = solver.kernel_name()
+    conv = None
+    if convergence:
+        # wall-clock to the reference's own stopping rule (DESC_PGD.m:243-256: objective decrease < 1e-5 for 30
+        # consecutive iterations), reached with ConstantStepSize(1) (SURVEY.md 6); not part of `value`
+        pc = lib.default_params()
+        pc.iters = 5000; pc.lr = 1.0; pc.seed = seed
+        t0 = time.perf_counter()
+        conv = solver.run(pc)
+        conv["t"] = time.perf_counter() - t0
+    solver.destroy()
+    # ---- end to end, really timed: one desc_pgd_solve call = structure build + upload + layout + S0_long +
+    #      100 iterations + download (what DESC_PGD() / the MEX shim pay per call in a warm process)
+    pe = lib.default_params(); pe.iters = 100; pe.lr = 0.01; pe.seed = seed; pe.patience = (1 << 31) - 1
+    t0 = time.perf_counter()
+    e2e = lib.solve(prob, pe)
+    t_e2e = time.perf_counter() - t0
+
+    bytes_per_launch = 72.0 * m_cycle + 12.0 * m_pos
+    achieved = bytes_per_launch / (ms_kernel * 1e-3) / 1e9 if ms_kernel else 0.0
+    traffic, traffic_src = load_traffic(name)
+    res = dict(
+        name=name, mo=mo, nn=nn, ii=ii, jj=jj, rij=rij, arrays=arrays, dt=dt, out=out, m=m, m_pos=m_pos, m_cycle=m_cycle,
+        n_sample=int(sizes["n_sample"]),
+        roofline={"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                  "traffic": traffic, "traffic_source": traffic_src,
+                  "kernel": ("k_colsum_node + " + kname + "0> (one iteration = both launches)") if "node" in kname else kname,
+                  "bytes_per_launch": bytes_per_launch, "kernel_ms": ms_kernel},
+        setup_ms={"generate": t_gen * 1e3, "structure_device": t_struct * 1e3, "upload_layout_cycle_d": t_create * 1e3},
+        end_to_end={"ms": t_e2e * 1e3, "what": "one timed desc_pgd_solve call: host arrays in -> S_vec out, 100 iterations, warm process",
+                    "ms_structure": e2e["ms_structure"], "ms_upload": e2e["ms_upload"], "ms_layout_cycle_d": e2e["ms_cycle_d"],
+                    "ms_pgd": e2e["ms_pgd"], "ms_total_in_library": e2e["ms_total"]},
+        conv=None if conv is None else
+        {"iters_run": int(conv["iters_run"]), "ms_iterations": conv["t"] * 1e3,
+         "mean_abs_err_vs_truth": float(np.mean(np.abs(conv["S_vec"] - mo.ErrVec)))},
+        err=float(np.mean(np.abs(out["S_vec"] - mo.ErrVec))))
+    return res
 
 
 def main():
@@ -100,10 +226,10 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence", action="store_true", help="skip the run to the patience exit (profiling: keeps the kernel statistics to the timed sweeps)")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the extra C4 measurement of the default run")
     ap.add_argument("--seed", type=int, default=0, help="cycle-sampling seed")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or os.environ.get("DESC_FORCE_SHARDED") == "1":   # the env switch rehearses the N>1 code path on one GPU
         from desc_amd.sharded import bench_sharded
@@ -112,90 +238,44 @@ def main():
     from desc_amd import _lib
     name = args.workload or "C2"
     K, W = args.steps, args.warmup
-    t0 = time.perf_counter()
-    mo, nn, ii, jj, rij = generate(name)
-    t_gen = time.perf_counter() - t0
-    prob = _lib.ProblemArrays(nn, ii, jj, rij)
-    # one warm-up call on a 200-node complete graph, outside the timers: HIP context, code-object load, the
-    # runtime's pinned staging buffers and first-use kernel attributes are per-process one-time costs
-    wi, wj = np.triu_indices(200, 1)
-    wprob = _lib.ProblemArrays(200, wi.astype(np.int32), wj.astype(np.int32), np.tile(np.eye(3).reshape(-1), wi.shape[0]))
-    wst = _lib.Structure.build(wprob, 30, 0, _lib.BUILD_DEVICE, 0)
-    wsol = _lib.Solver(wprob, wst, 0)
-    wp = _lib.default_params(); wp.iters = 2
-    wsol.run(wp); wsol.destroy(); wst.free()
-    t0 = time.perf_counter()
-    st = _lib.Structure.build(prob, 30, args.seed, _lib.BUILD_DEVICE, 0)
-    t_struct = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    solver = _lib.Solver(prob, st, 0)
-    t_create = time.perf_counter() - t0
-    arrays = st.arrays()                 # host copy for the CPU baseline (not needed by the GPU path; untimed)
-    st.free()
-
-    p = _lib.default_params()
-    p.iters = W + 2 * K + 8
-    p.lr = 0.01
-    p.patience = (1 << 31) - 1          # the bench times exactly K sweeps: never stop early
-    p.seed = args.seed
-    solver.reset(p)
-    solver.iterate(W)
-    solver.sync()
-    # ---- timed region: exactly K steps, inputs resident in HBM ----
-    t0 = time.perf_counter()
-    solver.iterate(K)
-    solver.sync()
-    dt = time.perf_counter() - t0
-    # ---- roofline leg: the same K sweeps again, each sweep kernel bracketed by HIP events
-    #      on the launch stream (not part of `value`) ----
-    _, ms_kernel = solver.iterate_timed(K, per_kernel=True)
-    out = solver.download()
-    m_cycle, m_pos, m = solver.m_cycle, solver.m_pos, solver.m
-    kname = solver.kernel_name()
-    # ---- wall-clock to the reference's own stopping rule (DESC_PGD.m:243-256: objective decrease
-    #      < 1e-5 for 30 consecutive iterations), reached with ConstantStepSize(1);
-    #      not part of `value`
-    conv = None
-    if not args.no_convergence:
-        pc = _lib.default_params()
-        pc.iters = 5000; pc.lr = 1.0; pc.seed = args.seed
-        t0 = time.perf_counter()
-        conv = solver.run(pc)
-        t_conv = time.perf_counter() - t0
-    solver.destroy()
-
-    bytes_per_launch = 72.0 * m_cycle + 12.0 * m_pos
-    achieved = bytes_per_launch / (ms_kernel * 1e-3) / 1e9 if ms_kernel else 0.0
-    # HBM traffic per iteration from the PMC passes committed under profiles/ (rocprofv3 cannot
-    # be run from inside the bench); null for workloads that have not been profiled
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            traffic = json.load(f).get(name, {}).get("per_iteration_bytes")
-    except OSError:
-        pass
+    warm_up(_lib)
+    r = measure(_lib, name, K, W, args.seed, not args.no_convergence, not args.no_cpu_baseline)
+    dt = r["dt"]
     line = {
         "metric": "DESC_PGD iters/sec", "value": K / dt, "unit": "iters/s", "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": describe(name), "n": nn, "m": m, "m_pos": m_pos, "m_cycle": m_cycle,
-                   "n_sample": int(arrays["n_sample"]), "sampling_seed": args.seed, "parallelism": "1 GPU"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "k_colsum_node + " + kname + "0> (one iteration = both launches)" if "node" in kname else kname,
-                     "bytes_per_launch": bytes_per_launch, "kernel_ms": ms_kernel},
-        "cycle_updates_per_s": m_cycle * K / dt,
-        "setup_ms": {"generate": t_gen * 1e3, "structure_device": t_struct * 1e3, "upload_layout_cycle_d": t_create * 1e3},
-        "end_to_end_100_iters_ms": (t_struct + t_create) * 1e3 + 100 * dt / K * 1e3,
-        "to_patience_exit_lr1": None if conv is None else
-        {"iters_run": int(conv["iters_run"]), "ms_iterations": t_conv * 1e3, "ms_end_to_end": (t_struct + t_create + t_conv) * 1e3,
-         "mean_abs_err_vs_truth": float(np.mean(np.abs(conv["S_vec"] - mo.ErrVec)))},
-        "mean_abs_err_vs_truth": float(np.mean(np.abs(out["S_vec"] - mo.ErrVec))),
+        "config": {"workload": describe(name), "n": r["nn"], "m": r["m"], "m_pos": r["m_pos"], "m_cycle": r["m_cycle"],
+                   "n_sample": r["n_sample"], "sampling_seed": args.seed, "parallelism": "1 GPU"},
+        "roofline": r["roofline"],
+        "cycle_updates_per_s": r["m_cycle"] * K / dt,
+        "setup_ms": r["setup_ms"],
+        "end_to_end_100_iters_ms": r["end_to_end"]["ms"],
+        "end_to_end": r["end_to_end"],
+        "to_patience_exit_lr1": r["conv"],
+        "mean_abs_err_vs_truth": r["err"],
     }
+    if args.workload is None and not args.no_north_star:
+        # the workload the north star's target is quoted on (BASELINE configs[3], fits one GPU: 4 GB): same
+        # measurement, its own roofline; `value` stays C2 (the configuration the metric line is defined on)
+        x = measure(_lib, "C4", K, W, args.seed, False, False)
+        line["north_star_config"] = {
+            "workload": describe("C4"), "value": K / x["dt"], "unit": "iters/s", "steps": K, "warmup": W, "ms_per_step": x["dt"] / K * 1e3,
+            "m_cycle": x["m_cycle"], "m_pos": x["m_pos"], "n_sample": x["n_sample"], "roofline": x["roofline"],
+            "setup_ms": x["setup_ms"], "end_to_end": x["end_to_end"], "mean_abs_err_vs_truth": x["err"]}
     if not args.no_cpu_baseline:
-        cb, ref, it = cpu_baseline(nn, ii, jj, rij, arrays)
+        cb, ref, it = cpu_baseline(r["nn"], r["ii"], r["jj"], r["rij"], r["arrays"])
         line["cpu_baseline"] = cb
         line["gpu_over_cpu"] = line["value"] / cb["value"]
+        # SURVEY.md 8d's other two data points (reported, never the target): the same port on one thread, and
+        # the interpreted literal restatement on C1
+        one, _, _ = cpu_baseline(r["nn"], r["ii"], r["jj"], r["rij"], r["arrays"], budget_s=8.0, max_iters=10, threads=1)
+        variants = {"port_single_thread": one}
+        try:
+            variants["literal_numpy_C1"] = literal_baseline()
+        except Exception as e:            # the literal restatement is test infrastructure: never fail the bench on it
+            variants["literal_numpy_C1"] = {"error": repr(e)}
+        line["cpu_baseline_variants"] = variants
     else:
         line["cpu_baseline"] = None
     print(json.dumps(line))

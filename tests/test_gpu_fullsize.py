@@ -87,7 +87,6 @@ def test_full_size_properties_large(lib, name, iters):
     again = run(lib, prob, st, p, "node", want_w=False)
     solver = lib.Solver(prob, st, 0); d = solver.s0(); solver.destroy()
     a = st.arrays()                                               # lazily derived on the device, then copied
-    st.free()
     assert "node" in node["kernel"]
     w, S = node["w"], node["S_vec"]
     sums = np.add.reduceat(w, a["cum_ind"][:-1])
@@ -95,6 +94,16 @@ def test_full_size_properties_large(lib, name, iters):
     assert S.min() >= 0 and S.max() <= 1
     assert (np.diff(node["obj"]) < 0).all()
     assert np.array_equal(again["S_vec"], S) and np.array_equal(again["obj"], node["obj"])
+    # accuracy against the generator's ground truth at a budget where it means something: the reference's own
+    # stopping rule (DESC_PGD.m:243-256), reached with ConstantStepSize(1) as compare_algorithms.m:2-5 advises
+    # for large graphs.  (lr = 0.01 is still far from converged after `iters` sweeps: the error there is only
+    # required to be worse than at convergence.)
+    conv = run(lib, prob, st, c_params(600, lr=1.0, seed=0), "node", want_w=False)
+    err_short = float(np.mean(np.abs(S - mo.ErrVec))); err_conv = float(np.mean(np.abs(conv["S_vec"] - mo.ErrVec)))
+    print(f"{name}: mean|S-ErrVec| {err_short:.4f} after {iters} sweeps at lr 0.01, {err_conv:.4f} at the patience exit "
+          f"({conv['iters_run']} sweeps at lr 1)")
+    assert conv["iters_run"] < 600
+    assert err_conv < 0.03 and err_conv < err_short
     rng = np.random.default_rng(1)
     cum = a["cum_ind"]
     for l in rng.choice(a["m_pos"], 200, replace=False):
@@ -109,3 +118,4 @@ def test_full_size_properties_large(lib, name, iters):
         wn = np.maximum(v - css[rho] / (rho + 1), 0)
         assert np.abs(wn - w[lo:hi]).max() < 1e-13
         assert abs(wn @ d[lo:hi] - S[a["pos_edge"][l]]) < 1e-13
+    st.free()
