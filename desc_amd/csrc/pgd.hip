@@ -646,6 +646,242 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
     block_partials(obj_acc, chg_acc, a.partials, lb);
 }
 
+// ===========================================================================
+// BAND sweep: the same arithmetic with the i-rows of S in the LDS
+// ===========================================================================
+// k_sweep_node is bound by L1-miss sector traffic: every segment gathers ~cnt values out of row i of Sfull
+// (8 useful bytes per 64-byte sector, a different row for every segment of a chunk).  Here the nodes are cut
+// into bands whose CSR rows fit the LDS of one CU together (<= row_cap doubles: 36 rows at C2, 18 at C4 / C5);
+// the edges keep the (band(i), j, i) order, every workgroup owns ONE contiguous range of segments (equal cycle
+// counts; pure streaming measured no penalty for contiguous ranges -- tools/probes/stream_probe.hip), split into
+// "pieces" at band boundaries, loads the piece's band rows once (coalesced) and serves S({k,i}) and the segment's
+// old S from the LDS.  S({j,k}) stays a gather through L1: consecutive segments of a band share j.
+// 1024 threads = 16 waves per workgroup (one workgroup per CU); no barrier inside a piece.  A wave takes
+// SPW = 64/LPS consecutive segments per iteration; its software pipeline keeps, per lane group,
+//   records (cum, EdgeInfo: scalar loads, off vmcnt)  4 iterations ahead,
+//   the streamed pk / w / S0 of its cycles            3 iterations ahead (registers, 4 rotating sets),
+//   the gathers of S({j,k}), T1, T2 (+ LDS reads)     1 iteration ahead (2 sets),
+// issued in the order gathers -> stream -> arithmetic -> stores: loads and stores retire through one in-order
+// counter on gfx950, so everything an iteration waits for was issued before the previous iteration's stores.
+#ifndef DESC_BAND_ABLATE            // diagnostic builds only (tools/build_ablate.sh): 1 S({j,k}) from the LDS too, 2 no arithmetic,
+#define DESC_BAND_ABLATE 0          // 4 one threshold pass, 8 no stores, 16 no LDS gathers, 32 no T1/T2 loads, 64 S({j,k}) rows confined to 1 MiB
+#endif
+constexpr int BAND_THREADS = 1024;
+constexpr int BAND_ROW_CAP = 19200;          // doubles of LDS for the band rows (150 KiB of the CU's 160 KiB)
+struct alignas(16) PieceDesc { int32_t row_lo, row_len, seg_lo, seg_hi; };   // CSR slots of the band, device-order segments
+
+struct BandSweepArgs {
+    NodeSweepArgs n;
+    const PieceDesc* pieces;
+    const int32_t* piece_ptr;      // grid + 1
+    int32_t row_cap;
+};
+
+__device__ __forceinline__ PieceDesc uniform_load_piece(const PieceDesc* p, int i) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef const v4i __attribute__((address_space(4)))* cptr_t;
+    const v4i v = ((cptr_t)(unsigned long long)p)[i];
+    return PieceDesc{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ EdgeInfo uniform_load_einfo(const EdgeInfo* p, int i) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef const v4i __attribute__((address_space(4)))* cptr_t;
+    const v4i v = ((cptr_t)(unsigned long long)p)[i];
+    return EdgeInfo{v.x, v.y, v.z, v.w};
+}
+
+template <int LPS, int E, int STEP>
+__global__ __launch_bounds__(BAND_THREADS, 1) void k_sweep_band(BandSweepArgs b) {
+    extern __shared__ double s_dyn[];                  // [row_cap] band rows of S_old, then the nv table
+    const NodeSweepArgs& a = b.n;
+    double* s_rows = s_dyn;
+    double* s_nv = s_dyn + b.row_cap;
+    __shared__ double s_part[2][BAND_THREADS / 64];
+    static_assert((LPS == 16 || LPS == 32) && LPS * E <= 64 && STEP != DESC_STEP_HYBRID, "segments of up to 64 cycles; Adam runs on k_sweep_node");
+    if (a.state->stop) return;
+    constexpr int NW = BAND_THREADS / 64, SPW = 64 / LPS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = lane / LPS, rr = lane % LPS;
+    if (tid <= MAX_SEG_CYCLES) s_nv[tid] = tid <= a.max_cnt ? a.nv_tab[tid] : 0.0;
+    double obj_acc = 0.0, chg_acc = 0.0;
+
+    struct RecRaw { int c0[SPW], c1[SPW]; EdgeInfo ei[SPW]; int t0; };      // wave-uniform (SGPRs)
+    struct Rec { int c0, cnt, rbi, rbj, sa, sb, seg; };                   // this lane group's segment
+    struct Str { uint32_t pk[E]; double w[E], d[E]; };
+    struct Gat { double sj[E], si[E], T1, T2, So; };
+
+    const int p0 = uniform_load(b.piece_ptr, blockIdx.x), p1 = uniform_load(b.piece_ptr, blockIdx.x + 1);
+    for (int pc = p0; pc < p1; ++pc) {
+        const PieceDesc pd = uniform_load_piece(b.pieces, pc);
+        __syncthreads();                                   // every wave is done with the previous band's rows
+        for (int base = 0; base < pd.row_len; base += 8 * BAND_THREADS) {     // 8 independent loads in flight per thread
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = a.S_old[pd.row_lo + min(base + u * BAND_THREADS + tid, pd.row_len - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (base + u * BAND_THREADS + tid < pd.row_len) s_rows[base + u * BAND_THREADS + tid] = v[u];
+        }
+        __syncthreads();
+        const int nit = (pd.seg_hi - pd.seg_lo + NW * SPW - 1) / (NW * SPW);
+
+        auto load_raw = [&](int it) -> RecRaw {            // past the end: the piece's last segment, cnt = 0
+            RecRaw q;
+            q.t0 = pd.seg_lo + (it * NW + wv) * SPW;
+#pragma unroll
+            for (int s2 = 0; s2 < SPW; ++s2) {
+                const int t = min(q.t0 + s2, pd.seg_hi - 1);
+                q.c0[s2] = uniform_load(a.cum, t); q.c1[s2] = uniform_load(a.cum, t + 1);
+                q.ei[s2] = uniform_load_einfo(a.einfo, t);
+            }
+            return q;
+        };
+        auto land = [&](const RecRaw& q) -> Rec {
+            Rec r{};
+#pragma unroll
+            for (int s2 = 0; s2 < SPW; ++s2)
+                if (grp == s2) {
+                    r.c0 = q.c0[s2]; r.cnt = q.t0 + s2 < pd.seg_hi ? q.c1[s2] - q.c0[s2] : 0;
+                    r.rbi = q.ei[s2].rb_i - pd.row_lo; r.rbj = q.ei[s2].rb_j; r.sa = q.ei[s2].slot_a; r.sb = q.ei[s2].slot_b;
+                    r.seg = min(q.t0 + s2, pd.seg_hi - 1);
+                }
+            return r;
+        };
+        auto load_stream = [&](const Rec& r) -> Str {      // unconditional: idle lanes repeat a valid cycle of the segment
+            Str x;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int64_t c = (int64_t)r.c0 + min(rr + LPS * e, max(r.cnt, 1) - 1);
+                x.pk[e] = a.pk[c]; x.w[e] = a.w_old[c]; x.d[e] = a.S0[c];
+            }
+            return x;
+        };
+        auto issue_gathers = [&](const Rec& r, const Str& x) -> Gat {
+            Gat g;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t p = x.pk[e];
+                g.sj[e] = (DESC_BAND_ABLATE & 1) ? s_rows[((p >> 16) & 0x7FFFu) + (lane & 7)]
+                        : a.S_old[((DESC_BAND_ABLATE & 64) ? (r.rbj & 0x1FFFF) : r.rbj) + (int)((p >> 16) & 0x7FFFu)];   // 64: rows confined to 1 MiB (L2 hits)
+                g.si[e] = (DESC_BAND_ABLATE & 16) ? 0.5 : s_rows[r.rbi + (int)(p & 0x7FFFu)];
+            }
+            const int ta = a.t_seg_lo >= 0 ? 2 * (r.seg - a.t_seg_lo) : r.sa, tb = a.t_seg_lo >= 0 ? ta + 1 : r.sb;
+            g.T1 = (DESC_BAND_ABLATE & 32) ? 0.25 : a.Tfull[ta];                      // column j of node i = sum(wijk(IKJ(mask)))  (:189)
+            g.T2 = (DESC_BAND_ABLATE & 32) ? 0.25 : a.Tfull[tb];                      // column i of node j = sum(wijk(JKI(mask)))  (:190)
+            g.So = (DESC_BAND_ABLATE & 16) ? 0.5 : s_rows[r.sa - pd.row_lo];
+            return g;
+        };
+        // arithmetic + stores of one segment group (DESC_PGD.m:193-233), everything in registers
+        auto compute = [&](const Rec& r, const Str& x, const Gat& g) {
+            const int cnt = r.cnt;
+            double ws[E];
+            uint32_t okm = 0;
+            double part = 0.0;
+            if (DESC_BAND_ABLATE & 2) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) { const bool ok = rr + LPS * e < cnt; if (ok) okm |= 1u << e; ws[e] = x.w[e] + g.sj[e] + g.si[e] + x.d[e] + (double)(x.pk[e] & 1u) + g.T1 + g.T2; }
+                part = ws[0];
+            } else
+            if (__ballot(cnt > 0) != 0ull) {               // wave-uniform; no memory operation inside
+                const double nv = cnt > 0 ? s_nv[cnt] : 0.0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const bool ok = rr + LPS * e < cnt;
+                    const uint32_t p = ok ? x.pk[e] : 0u;
+                    const double w = ok ? x.w[e] : 0.0, d = ok ? x.d[e] : 0.0;
+                    if (ok) okm |= 1u << e;
+                    const double ss = g.sj[e] + g.si[e];                                                 // S(jk)+S(ki)
+                    obj_acc += w * ss;                                                                   // :233, one sweep late
+                    const double gr = ss + (((p & 0x8000u) ? g.T1 : 0.0) + ((p & 0x80000000u) ? g.T2 : 0.0)) * d;   // :193
+                    ws[e] = gr;
+                    part += ok ? gr * nv : 0.0;
+                }
+                const double dot = group_sum<LPS>(part);                                                 // :199-201
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const double gr = ws[e] - dot * nv;
+                    ws[e] = ((okm >> e) & 1u) ? apply_step<STEP>(a.st, x.w[e], gr, 0) : 0.0;             // :207
+                }
+                uint32_t act = okm;                        // simplex threshold (:215-223), Michelot fixed point
+                double s1v = 0.0; int na = 1;
+                for (;;) {
+                    double sp = 0.0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) sp += ((act >> e) & 1u) ? ws[e] : 0.0;
+                    s1v = group_sum<LPS>(sp) - 1.0;
+                    if (LPS == 16) na = max(group16_sum((int)__popc(act)), 1);
+                    else {
+                        na = 0;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) na += group_count<LPS>((act >> e) & 1u, lane);
+                        na = max(na, 1);
+                    }
+                    const double nad = (double)na;
+                    uint32_t keep = 0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) keep |= (((act >> e) & 1u) && ws[e] * nad > s1v) ? 1u << e : 0u;
+                    const bool changed = keep != act;
+                    act = keep;
+                    if (!__any(changed) || (DESC_BAND_ABLATE & 4)) break;
+                }
+                const double T = s1v / (double)na;
+                double sn = 0.0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const double wn = fmax(ws[e] - T, 0.0);                                              // :224
+                    ws[e] = wn;
+                    if ((okm >> e) & 1u) sn += wn * x.d[e];
+                }
+                part = group_sum<LPS>(sn);                                                               // :229
+            }
+            if (DESC_BAND_ABLATE & 8) { obj_acc += ws[0] + ws[E - 1] + part; return; }
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if ((okm >> e) & 1u) a.w_new[(int64_t)r.c0 + rr + LPS * e] = ws[e];
+            if (cnt > 0 && rr == 0) {
+                chg_acc += fabs(part - g.So);                                                            // :232
+                a.S_new[r.sa] = part; a.S_new[r.sb] = part;
+            }
+        };
+
+        // ---- prologue: records 0..3, streams 0..2, gathers 0
+        Rec R0, R1, R2, R3; Str S0, S1, S2, S3; Gat G0, G1;
+        RecRaw Q;
+        { const RecRaw q = load_raw(0); R0 = land(q); S0 = load_stream(R0); }
+        { const RecRaw q = load_raw(1); R1 = land(q); S1 = load_stream(R1); }
+        { const RecRaw q = load_raw(2); R2 = land(q); S2 = load_stream(R2); }
+        Q = load_raw(3);
+        G0 = issue_gathers(R0, S0);
+        // one iteration: Ra/Sa/Ga = group g (computed), Rb/Sb = g+1 (gathers issued into Gb), Rd/Sd <- g+3
+        auto step = [&](int g, const Rec& Ra, const Str& Sa, const Gat& Ga, const Rec& Rb, const Str& Sb, Gat& Gb, Rec& Rd, Str& Sd) {
+            const RecRaw qn = load_raw(g + 4);
+            Gb = issue_gathers(Rb, Sb);
+            Rd = land(Q);
+            Sd = load_stream(Rd);
+            compute(Ra, Sa, Ga);
+            Q = qn;
+        };
+        for (int g = 0; g < nit; g += 4) {                 // the tail iterations past nit compute nothing (cnt = 0)
+            step(g,     R0, S0, G0, R1, S1, G1, R3, S3);
+            step(g + 1, R1, S1, G1, R2, S2, G0, R0, S0);
+            step(g + 2, R2, S2, G0, R3, S3, G1, R1, S1);
+            step(g + 3, R3, S3, G1, R0, S0, G0, R2, S2);
+        }
+    }
+    // deterministic workgroup partials
+    obj_acc = group_sum<64>(obj_acc);
+    chg_acc = group_sum<64>(chg_acc);
+    __syncthreads();
+    if (lane == 0) { s_part[0][wv] = obj_acc; s_part[1][wv] = chg_acc; }
+    __syncthreads();
+    if (tid == 0) {
+        double o = 0.0, c = 0.0;
+        for (int k = 0; k < NW; ++k) { o += s_part[0][k]; c += s_part[1][k]; }
+        a.partials[2 * blockIdx.x] = o;
+        a.partials[2 * blockIdx.x + 1] = c;
+    }
+}
+
 // Mirror-weight column sums (DESC_PGD.m:185-191 in node form).  One workgroup per node
 // v: for every incident edge {v,u} (CSR order) stream its segment; a cycle with third
 // vertex t adds its weight to column idx_v(t) if the reverse cycle ({v,t};u) was sampled.
@@ -1046,6 +1282,11 @@ struct desc_pgd {
     int obj_grid = 0;
     int colsum_grid = 0, colsum_stride = 0;
     int band = 0;
+    bool band_ok = false;       // k_sweep_band applies (segments <= 64 cycles, rows fit the LDS)
+    int band_grid = 0, band_rows = 0;
+    size_t band_lds = 0;
+    PieceDesc* d_pieces = nullptr;
+    int32_t* d_piece_ptr = nullptr;
     std::vector<void*> allocs;
     // common
     int32_t* d_cum = nullptr;
@@ -1185,6 +1426,18 @@ void launch_node(desc_pgd* h, const NodeSweepArgs& a) {
     }
 }
 
+void launch_band(desc_pgd* h, const NodeSweepArgs& a) {
+    BandSweepArgs b{a, h->d_pieces, h->d_piece_ptr, h->band_rows};
+    dim3 grid(h->band_grid), block(BAND_THREADS);
+    switch (h->lps * 8 + h->G) {
+        case 16 * 8 + 1: hipLaunchKernelGGL((k_sweep_band<16, 1, DESC_STEP_CONSTANT>), grid, block, h->band_lds, h->stream, b); break;
+        case 16 * 8 + 2: hipLaunchKernelGGL((k_sweep_band<16, 2, DESC_STEP_CONSTANT>), grid, block, h->band_lds, h->stream, b); break;
+        default: hipLaunchKernelGGL((k_sweep_band<32, 2, DESC_STEP_CONSTANT>), grid, block, h->band_lds, h->stream, b); break;
+    }
+}
+// workgroups (= partial pairs) of the sweep kernel that serves this step kind
+int sweep_parts(const desc_pgd* h, bool adam) { return h->variant == VARIANT_NODE && h->band_ok && !adam ? h->band_grid : h->grid; }
+
 // enqueue sweep number t (1-based) and its finalize; ev0/ev1 bracket the kernels of the sweep proper
 int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     const desc_params& p = h->p;
@@ -1200,7 +1453,7 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
         a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
         a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->d_T; a.t_seg_lo = -1; a.nv_tab = h->d_nv; a.partials = h->d_partials;
         a.state = h->d_state; a.st = st; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks; a.max_cnt = h->max_cnt; a.ablate = h->ablate;
-        if (adam) launch_node<DESC_STEP_HYBRID>(h, a); else launch_node<DESC_STEP_CONSTANT>(h, a);
+        if (adam) launch_node<DESC_STEP_HYBRID>(h, a); else if (h->band_ok) launch_band(h, a); else launch_node<DESC_STEP_CONSTANT>(h, a);
     } else {
         SweepArgs a{};
         a.cum = h->d_cum; a.pos_edge = h->d_pos_edge; a.e_jk = h->d_ejk; a.e_ki = h->d_eki; a.ikj = h->d_ikj; a.jki = h->d_jki;
@@ -1210,7 +1463,7 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
         if (adam) launch_gather<DESC_STEP_HYBRID>(h, a); else launch_gather<DESC_STEP_CONSTANT>(h, a);
     }
     if (ev1) (void)hipEventRecord(ev1, h->stream);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, h->d_partials, h->grid, h->d_state, h->d_obj,
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, h->d_partials, sweep_parts(h, adam), h->d_state, h->d_obj,
                        h->d_avg, t, h->m, p.patience, p.stop_tol, 0);
     DESC_HIP(hipGetLastError());
     return DESC_OK;
@@ -1288,46 +1541,65 @@ int setup_gather(desc_pgd* h, const desc_problem* prob, const desc_structure* s)
 // Host-side plan of the node layout: band-major order of the edges with cycles, chunking,
 // and the chunk ranges of the `world` ranks (contiguous, equal numbers of chunks).
 struct NodePlan {
-    int band = 0;
+    int band = 0;                     // nodes per band (fixed-size bands), 0: LDS-sized bands
+    std::vector<int32_t> band_lo;     // nbands+1: first node of every band
+    std::vector<int64_t> bstart;      // nbands+1: first device position (= position in pos_edge) of every band
+    std::vector<int32_t> rowptr;      // n+1: CSR row starts (degrees prefix-summed)
     std::vector<int32_t> order;       // device position -> index into s->pos_edge
     std::vector<int32_t> cum2;        // m_pos+1, device order, global cycle numbering
     std::vector<int32_t> chunk_seg;   // nchunks+1
     std::vector<int64_t> rank_chunk;  // world+1
 };
 
-int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_deg, int world, int max_seg, NodePlan& P) {
-    const int64_t mp = s->m_pos;
-    int band = env_int("DESC_DEBUG_BAND", 0);
-    if (band <= 0)   // rows of one band should stay in an XCD's 4 MiB L2 next to the streamed arrays: ~1 MiB
-        band = (int)std::max<int64_t>(8, std::min<int64_t>(512, (1 << 20) / (8 * (int64_t)std::max(1, max_deg))));
-    P.band = band;
+// row_cap > 0: bands = maximal runs of consecutive nodes whose CSR rows hold <= row_cap entries together (the band
+// sweep keeps them in the LDS); row_cap == 0: bands of a fixed number of nodes sized for the L2 (k_sweep_node).
+int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_deg, int world, int max_seg, int row_cap, NodePlan& P) {
+    const int64_t mp = s->m_pos, n = prob->n, m = prob->m;
+    const int32_t* ii = prob->ind_i; const int32_t* jj = prob->ind_j; const int32_t* pe = s->pos_edge.data();
+    P.rowptr.assign((size_t)n + 1, 0);
+    for (int64_t e = 0; e < m; ++e) { P.rowptr[ii[e] + 1]++; P.rowptr[jj[e] + 1]++; }
+    for (int64_t v = 0; v < n; ++v) P.rowptr[v + 1] += P.rowptr[v];
+    P.band_lo.clear();
+    if (row_cap > 0) {
+        P.band = 0;
+        for (int64_t v = 0; v < n;) {
+            P.band_lo.push_back((int32_t)v);
+            int64_t e = v + 1;                               // a band holds at least one node (max_deg <= row_cap is the caller's check)
+            while (e < n && P.rowptr[e + 1] - P.rowptr[v] <= row_cap) ++e;
+            v = e;
+        }
+    } else {
+        int band = env_int("DESC_DEBUG_BAND", 0);
+        if (band <= 0)   // rows of one band should stay in an XCD's 4 MiB L2 next to the streamed arrays: ~1 MiB
+            band = (int)std::max<int64_t>(8, std::min<int64_t>(512, (1 << 20) / (8 * (int64_t)std::max(1, max_deg))));
+        P.band = band;
+        for (int64_t v = 0; v < n; v += band) P.band_lo.push_back((int32_t)v);
+    }
+    P.band_lo.push_back((int32_t)n);
+    const int64_t nb = (int64_t)P.band_lo.size() - 1;
     // order by (band(i), j, i): Ind -- and with it pos_edge -- is sorted by (i, j), so a band is a
     // contiguous range of pos_edge and one stable counting sort by j per band (bands in parallel)
     // gives the order in O(m_pos + bands * n)
     P.order.resize((size_t)mp);
+    P.bstart.assign((size_t)nb + 1, mp);       // first position of every band in pos_edge
     {
-        const int32_t* ii = prob->ind_i; const int32_t* jj = prob->ind_j; const int32_t* pe = s->pos_edge.data();
-        const int64_t n = prob->n, nb = n / band + 1;
-        std::vector<int64_t> bstart((size_t)nb + 1, mp);       // first position of every band in pos_edge
-        {
-            int64_t l = 0;
-            for (int64_t b = 0; b <= nb; ++b) {
-                while (l < mp && ii[pe[l]] / band < b) ++l;
-                bstart[b] = l;
-            }
+        int64_t l = 0;
+        for (int64_t b = 0; b <= nb; ++b) {
+            while (l < mp && ii[pe[l]] < P.band_lo[b]) ++l;
+            P.bstart[b] = l;
         }
-        host_parallel(nb, [&](int64_t b0, int64_t b1) {
-            std::vector<int32_t> cnt((size_t)n + 1);
-            for (int64_t b = b0; b < b1; ++b) {
-                const int64_t lo = bstart[b], hi = bstart[b + 1];
-                if (lo == hi) continue;
-                std::fill(cnt.begin(), cnt.end(), 0);
-                for (int64_t l = lo; l < hi; ++l) cnt[jj[pe[l]] + 1]++;
-                for (int64_t v = 0; v < n; ++v) cnt[v + 1] += cnt[v];
-                for (int64_t l = lo; l < hi; ++l) P.order[lo + cnt[jj[pe[l]]]++] = (int32_t)l;
-            }
-        }, mp >= (1 << 18) ? 1 : nb + 1);          // small problems: one thread
     }
+    host_parallel(nb, [&](int64_t b0, int64_t b1) {
+        std::vector<int32_t> cnt((size_t)n + 1);
+        for (int64_t b = b0; b < b1; ++b) {
+            const int64_t lo = P.bstart[b], hi = P.bstart[b + 1];
+            if (lo == hi) continue;
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (int64_t l = lo; l < hi; ++l) cnt[jj[pe[l]] + 1]++;
+            for (int64_t v = 0; v < n; ++v) cnt[v + 1] += cnt[v];
+            for (int64_t l = lo; l < hi; ++l) P.order[lo + cnt[jj[pe[l]]]++] = (int32_t)l;
+        }
+    }, mp >= (1 << 18) ? 1 : nb + 1);          // small problems: one thread
     P.cum2.assign((size_t)mp + 1, 0);
     for (int64_t q = 0; q < mp; ++q) {
         const int32_t l = P.order[q];
@@ -1360,7 +1632,17 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     };
     int rc;
     NodePlan P;
-    if ((rc = make_node_plan(prob, s, h->max_deg, h->world, h->max_cnt <= 32 ? 32 : h->max_cnt <= 128 ? 16 : 8, P))) return rc;   // 8 waves x 64/lps segments
+    // band sweep (i-rows of S in the LDS): segments of up to 64 cycles, every CSR row fits the LDS; DESC_DEBUG_VARIANT=2 keeps
+    // the L2-sized bands of k_sweep_node for comparison
+    int ncu = 256;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    }
+    // (tiny problems stay on k_sweep_node: with < 2 M cycles a 1024-thread workgroup per CU is mostly pipeline fill -- C1: 31 vs 20 us)
+    const int force_band = env_int("DESC_DEBUG_VARIANT", 0);
+    h->band_ok = force_band != VARIANT_NODE && h->max_cnt <= 64 && h->max_deg <= BAND_ROW_CAP && (h->m_cycle >= (2 << 20) || force_band == 3);
+    if ((rc = make_node_plan(prob, s, h->max_deg, h->world, h->max_cnt <= 32 ? 32 : h->max_cnt <= 128 ? 16 : 8, h->band_ok ? BAND_ROW_CAP : 0, P))) return rc;   // 8 waves x 64/lps segments
     h->band = P.band;
     lap("plan");
     const std::vector<int32_t>& cum2 = P.cum2;
@@ -1377,6 +1659,91 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     h->t_part = 2 * std::max<int64_t>(max_local, 1);
     const int64_t mcl = h->cyc_hi - h->cyc_lo;            // local cycles
     const int64_t nsl = h->seg_hi - h->seg_lo;            // local segments
+    // band sweep: the work of every workgroup as a list of pieces (band rows + a range of that band's segments).
+    //  * Sfull fits the L2s (small graphs): one contiguous range of segments per workgroup (equal cycle counts), split at band
+    //    boundaries -- each workgroup loads one or two bands.
+    //  * otherwise S({j,k}) rows would be fetched from the Infinity Cache once per (band, j) (measured: 8 % of the iteration at C4,
+    //    17 % at C5): the (band, j) plane is cut into units (band b, block of JB consecutive j) whose j-rows (~1.5 MiB) fit an
+    //    XCD's L2, and the units are dealt in j-block-major order to the least-loaded workgroup (deterministic list scheduling), so
+    //    that at any moment all workgroups gather from the same block of rows.
+    std::vector<PieceDesc> pieces; std::vector<int32_t> piece_ptr;
+    if (h->band_ok) {
+        h->band_grid = ncu;
+        h->band_rows = 0;
+        const int G = h->band_grid;
+        const int64_t nbands = (int64_t)P.band_lo.size() - 1;
+        std::vector<std::vector<PieceDesc>> per_wg((size_t)G);
+        auto piece_of = [&](int64_t bd, int64_t q0, int64_t q1) {
+            const int32_t row_lo = P.rowptr[P.band_lo[bd]], row_len = P.rowptr[P.band_lo[bd + 1]] - row_lo;
+            h->band_rows = std::max(h->band_rows, (int)row_len);
+            return PieceDesc{row_lo, row_len, (int32_t)q0, (int32_t)q1};
+        };
+        const int jmajor_env = env_int("DESC_DEBUG_JMAJOR", -1);
+        const bool jmajor = jmajor_env >= 0 ? jmajor_env != 0 : (int64_t)2 * m * 8 > (12ll << 20);      // C3 (6.4 MB): contiguous 0.167 ms, units 0.184
+        if (!jmajor) {
+            int64_t q = h->seg_lo, bd = 0;
+            for (int b = 0; b < G; ++b) {
+                const int64_t target = h->cyc_lo + (b + 1 == G ? mcl : mcl * (b + 1) / G);
+                int64_t qe = q;
+                while (qe < h->seg_hi && (cum2[qe + 1] <= target || b + 1 == G)) ++qe;
+                while (q < qe) {
+                    while (bd + 1 < nbands && P.bstart[bd + 1] <= q) ++bd;
+                    const int64_t e = std::min<int64_t>(qe, P.bstart[bd + 1]);
+                    per_wg[b].push_back(piece_of(bd, q, e));
+                    q = e;
+                }
+            }
+        } else {
+            const int64_t avg_deg = std::max<int64_t>(1, 2 * m / std::max<int64_t>(1, n));
+            int64_t JB = env_int("DESC_DEBUG_JBLOCK", 0);
+            if (JB <= 0) JB = std::max<int64_t>(32, (3ll << 19) / (8 * avg_deg));
+            const int64_t cap = std::max<int64_t>(16384, mcl / (4 * (int64_t)G));        // cycles per unit at most
+            const int64_t nJ = (n + JB - 1) / JB;
+            auto j_of = [&](int64_t q) { return (int64_t)prob->ind_j[s->pos_edge[P.order[q]]]; };
+            // position of the first segment of band bd with j >= jlim, inside the rank's range
+            std::vector<int64_t> cur((size_t)nbands), bend((size_t)nbands);
+            for (int64_t bd = 0; bd < nbands; ++bd) {
+                cur[bd] = std::min(std::max(P.bstart[bd], h->seg_lo), h->seg_hi);
+                bend[bd] = std::min(std::max(P.bstart[bd + 1], h->seg_lo), h->seg_hi);
+            }
+            std::vector<int64_t> load((size_t)G, 0);
+            // min-heap over (load, wg): the next unit goes to the workgroup that would be free first
+            std::vector<std::pair<int64_t, int>> heap; heap.reserve((size_t)G);
+            for (int b = 0; b < G; ++b) heap.push_back({0, b});
+            auto cmp = [](const std::pair<int64_t, int>& x, const std::pair<int64_t, int>& y) { return x > y; };
+            std::make_heap(heap.begin(), heap.end(), cmp);
+            for (int64_t J = 0; J < nJ; ++J) {
+                const int64_t jlim = (J + 1) * JB;
+                for (int64_t bd = 0; bd < nbands; ++bd) {
+                    int64_t lo = cur[bd], hi = bend[bd];
+                    if (lo >= hi) continue;
+                    int64_t a0 = lo, a1 = hi;                   // first q in [lo, hi) with j(q) >= jlim
+                    while (a0 < a1) { const int64_t mid = (a0 + a1) >> 1; if (j_of(mid) < jlim) a0 = mid + 1; else a1 = mid; }
+                    const int64_t e = a0;
+                    cur[bd] = e;
+                    while (lo < e) {                             // split units above the cap
+                        int64_t x = lo;
+                        while (x < e && cum2[x + 1] - cum2[lo] <= cap) ++x;
+                        if (x == lo) x = lo + 1;
+                        std::pop_heap(heap.begin(), heap.end(), cmp);
+                        auto& top = heap.back();
+                        per_wg[top.second].push_back(piece_of(bd, lo, x));
+                        top.first += cum2[x] - cum2[lo] + 4096;  // + the row load and pipeline fill of a piece, in cycle units
+                        std::push_heap(heap.begin(), heap.end(), cmp);
+                        lo = x;
+                    }
+                }
+            }
+        }
+        piece_ptr.assign((size_t)G + 1, 0);
+        for (int b = 0; b < G; ++b) {
+            pieces.insert(pieces.end(), per_wg[b].begin(), per_wg[b].end());
+            piece_ptr[b + 1] = (int32_t)pieces.size();
+        }
+        if (pieces.empty()) pieces.push_back(PieceDesc{0, 0, 0, 0});
+        if (timing) fprintf(stderr, "[desc_amd] band sweep: %lld bands, %zu pieces over %d workgroups, %s, rows <= %d\n", (long long)nbands, pieces.size(), G,
+                            jmajor ? "j-block-major units" : "contiguous ranges", h->band_rows);
+    }
 
     // A structure built on this device brings its CSR, edge tables and sampled k along in HBM: the
     // per-edge tables and the cycle layout are then made by kernels and the host only plans.
@@ -1497,6 +1864,10 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     if ((rc = dalloc(h, &h->d_pairs, 2 * (size_t)h->world))) return rc;
     if ((rc = dalloc(h, &h->d_rank_seg, (size_t)h->world + 1))) return rc;
     if ((rc = dalloc(h, &h->d_xpos, 2 * m))) return rc;
+    if (h->band_ok) {
+        if ((rc = dalloc(h, &h->d_pieces, pieces.size()))) return rc;
+        if ((rc = dalloc(h, &h->d_piece_ptr, piece_ptr.size()))) return rc;
+    }
     lap("alloc");
     int32_t *d_ii = nullptr, *d_jj = nullptr, *d_adj = nullptr, *d_adj_eid = nullptr, *d_pos_edge2 = nullptr;
     uint32_t* d_kf = nullptr; double* d_rij = nullptr;
@@ -1518,6 +1889,10 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     if ((rc = upload(h, h->d_rank_seg, rank_seg32.data(), rank_seg32.size()))) return rc;
     if ((rc = upload(h, d_pos_edge2, pos_edge2.data(), (size_t)mp))) return rc;
     if ((rc = upload(h, d_rij, prob->rij, 9 * (size_t)m))) return rc;
+    if (h->band_ok) {
+        if ((rc = upload(h, h->d_pieces, pieces.data(), pieces.size()))) return rc;
+        if ((rc = upload(h, h->d_piece_ptr, piece_ptr.data(), piece_ptr.size()))) return rc;
+    }
     if (dev_cycles) {
         DESC_HIP(hipMemcpyAsync(h->d_rowptr, s->d_rowptr, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToDevice, h->stream));
         hipLaunchKernelGGL(k_edge_slots, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (m + 255) / 256))), dim3(256), 0, h->stream,
@@ -1545,11 +1920,9 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     h->lps = h->max_cnt <= 32 ? 16 : h->max_cnt <= 128 ? 32 : 64;
     h->G = h->max_cnt <= 16 ? 1 : h->max_cnt <= 64 ? 2 : 4;
     {   // persistent grid: exactly the workgroups that are co-resident (registers / LDS decide)
-        int per_cu = 0, ncu = 256;
+        int per_cu = 0;
         const void* kfn = (const void*)k_sweep_node<32, 4, DESC_STEP_CONSTANT>;    // the largest-register instance
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, SWEEP_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
         int64_t want = std::min<int64_t>(std::max(h->nchunks, 1), (int64_t)ncu * per_cu);
         h->grid = (int)(std::max<int64_t>(want, 8) + 7) / 8 * 8;
     }
@@ -1561,8 +1934,15 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
         if (lds > 64 * 1024)
             DESC_HIP(hipFuncSetAttribute((const void*)k_colsum_node, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
+    if (h->band_ok) {      // the band rows + the nv table in dynamic LDS: more than the 64 KiB default
+        h->band_lds = ((size_t)h->band_rows + MAX_SEG_CYCLES + 1) * sizeof(double);
+        const void* kb = h->lps == 16 ? (h->G == 1 ? (const void*)k_sweep_band<16, 1, DESC_STEP_CONSTANT> : (const void*)k_sweep_band<16, 2, DESC_STEP_CONSTANT>)
+                                      : (const void*)k_sweep_band<32, 2, DESC_STEP_CONSTANT>;
+        if (hipFuncSetAttribute(kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->band_lds) != hipSuccess) { (void)hipGetLastError(); h->band_ok = false; }
+    }
     char nm[64];
-    snprintf(nm, sizeof nm, "k_sweep_node<%d,%d,", h->lps, h->G);
+    if (h->band_ok) snprintf(nm, sizeof nm, "k_sweep_band<%d,%d,", h->lps, h->G);
+    else snprintf(nm, sizeof nm, "k_sweep_node<%d,%d,", h->lps, h->G);
     h->kname = nm;
 
     lap("occupancy/attrs");
@@ -1701,7 +2081,7 @@ int desc_pgd_create_shard(const desc_problem* prob, const desc_structure* s, int
         if (!rc) { hipError_t e = hipStreamSynchronize(h->stream); if (e != hipSuccess) rc = fail(DESC_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
     }
     if (!rc) rc = (h->variant == VARIANT_NODE) ? setup_node(h, prob, s) : setup_gather(h, prob, s);
-    if (!rc) rc = dalloc(h, &h->d_partials, 2 * (size_t)std::max(h->grid, h->obj_grid));
+    if (!rc) rc = dalloc(h, &h->d_partials, 2 * (size_t)std::max(std::max(h->grid, h->obj_grid), h->band_grid));
     if (rc) { free_all(h); return rc; }
     *out = h;
     return DESC_OK;
@@ -1742,7 +2122,7 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
         if (gr >= 8 && gr / 8 * 8 != h->grid) {
             dfree(h, h->d_partials); h->d_partials = nullptr;
             h->grid = gr / 8 * 8;
-            rc = dalloc(h, &h->d_partials, 2 * (size_t)std::max(h->grid, h->obj_grid)); if (rc) return rc;
+            rc = dalloc(h, &h->d_partials, 2 * (size_t)std::max(std::max(h->grid, h->obj_grid), h->band_grid)); if (rc) return rc;
         }
     }
     h->t_done = 0; h->t_plugin = p->t0; h->ms_pgd = 0; h->objective_done = false; h->final_obj_T = -1;
@@ -1981,10 +2361,10 @@ int desc_pgd_shard_sweep(desc_pgd* h) {
     a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_Trecv; a.t_seg_lo = (int32_t)h->seg_lo; a.nv_tab = h->d_nv; a.partials = h->d_partials;
     a.state = h->d_state; a.st = st; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks;
     a.max_cnt = h->max_cnt; a.ablate = 0;
-    if (adam) launch_node<DESC_STEP_HYBRID>(h, a); else launch_node<DESC_STEP_CONSTANT>(h, a);
+    if (adam) launch_node<DESC_STEP_HYBRID>(h, a); else if (h->band_ok) launch_band(h, a); else launch_node<DESC_STEP_CONSTANT>(h, a);
     const int nloc = (int)(h->seg_hi - h->seg_lo);
     hipLaunchKernelGGL(k_pack_S, dim3(std::max(1, std::min(1024, (nloc + 255) / 256))), dim3(256), 0, h->stream, h->d_einfo, h->d_S[wr],
-                       h->d_partials, h->grid, h->x_sall + (int64_t)h->rank * h->slice_len, (int)h->seg_lo, (int)h->seg_hi, h->slice_len);
+                       h->d_partials, sweep_parts(h, adam), h->x_sall + (int64_t)h->rank * h->slice_len, (int)h->seg_lo, (int)h->seg_hi, h->slice_len);
     DESC_HIP(hipGetLastError());
     return DESC_OK;
 }

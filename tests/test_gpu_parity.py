@@ -12,10 +12,10 @@ from tests.helpers import (assert_structure_equal, c_params, make_problem, oracl
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
-VARIANTS = {"node": "0", "gather": "1"}
+VARIANTS = {"band": "3", "node": "2", "gather": "1"}     # DESC_DEBUG_VARIANT: band sweep (forced also on tiny graphs) / k_sweep_node / gather layout
 
 
-def run_gpu(lib, nn, ii, jj, rij, p, want_w=True, structure=None, variant="node", adam=None):
+def run_gpu(lib, nn, ii, jj, rij, p, want_w=True, structure=None, variant="band", adam=None):
     os.environ["DESC_DEBUG_VARIANT"] = VARIANTS[variant]
     try:
         prob = lib.ProblemArrays(nn, ii, jj, rij)
@@ -55,7 +55,7 @@ def test_group_sum_primitives(lib):
         assert np.all(out.reshape(-1, G) == out.reshape(-1, G)[:, :1])   # identical bits in every lane
 
 
-@pytest.mark.parametrize("variant", ["node", "gather"])
+@pytest.mark.parametrize("variant", ["band", "node", "gather"])
 @pytest.mark.parametrize("n,p,seed", [(12, 0.6, 9), (30, 0.5, 1), (60, 0.3, 2), (120, 0.6, 3), (200, 0.5, 4), (260, 0.5, 5)])
 def test_uniform_constant_step(lib, oracle, n, p, seed, variant):
     """G=16 (n=12), G=32 (n_sample=30) and G=64 (n=260: n_sample=33) kernels; sampling and no-sampling regimes."""
@@ -63,11 +63,11 @@ def test_uniform_constant_step(lib, oracle, n, p, seed, variant):
     st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=11, iters=100, lr=0.01)
     arrays, s0, out = run_gpu(lib, nn, ii, jj, rij, c_params(100, lr=0.01, seed=11), variant=variant)
     assert_structure_equal(arrays, st)
-    assert variant not in ("node",) or "node" in out["kernel"]
+    assert variant == "gather" or variant in out["kernel"]
     check(out, ref, s0, S0)
 
 
-@pytest.mark.parametrize("variant", ["node", "gather"])
+@pytest.mark.parametrize("variant", ["band", "node", "gather"])
 def test_nonuniform_self_consistent(lib, oracle, variant):
     mo, nn, ii, jj, rij = make_problem("nonuniform", n=150, p=0.4, seed=6, crpt_type="self-consistent")
     st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=2, iters=60, lr=0.01)
@@ -76,7 +76,7 @@ def test_nonuniform_self_consistent(lib, oracle, variant):
     check(out, ref, s0, S0)
 
 
-@pytest.mark.parametrize("variant", ["node", "gather"])
+@pytest.mark.parametrize("variant", ["band", "node", "gather"])
 def test_long_segments(lib, oracle, variant):
     """codegree ~ 280 -> n_sample = 70 > 64: 32 lanes per segment in the node layout, the multi-pass
     wave-per-edge kernel in the gather layout."""
@@ -84,7 +84,7 @@ def test_long_segments(lib, oracle, variant):
     st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=3, iters=25, lr=0.01)
     assert st["n_sample"] > 64
     arrays, s0, out = run_gpu(lib, nn, ii, jj, rij, c_params(25, lr=0.01, seed=3), variant=variant)
-    assert ("node<32,4" in out["kernel"]) if variant == "node" else ("big" in out["kernel"])
+    assert ("node<32,4" in out["kernel"]) if variant != "gather" else ("big" in out["kernel"])    # band sweep: segments <= 64 only
     check(out, ref, s0, S0)
 
 
@@ -134,7 +134,7 @@ def test_segments_longer_than_256_fall_back(lib, oracle):
     check(out, ref, s0, S0)
 
 
-@pytest.mark.parametrize("variant", ["node", "gather"])
+@pytest.mark.parametrize("variant", ["band", "node", "gather"])
 @pytest.mark.parametrize("kind", ["large_lr", "piecewise", "hybrid_adam", "hybrid_plain"])
 def test_step_plugins(lib, oracle, kind, variant):
     mo, nn, ii, jj, rij = make_problem("uniform", n=90, p=0.5, q=0.3, sigma=0.1, seed=8)
@@ -149,7 +149,7 @@ def test_step_plugins(lib, oracle, kind, variant):
     check(out, ref, s0, S0, tol=1e-9 if kind == "hybrid_adam" else TOL)
 
 
-@pytest.mark.parametrize("variant", ["node", "gather"])
+@pytest.mark.parametrize("variant", ["band", "node", "gather"])
 def test_early_stop_matches_oracle(lib, oracle, variant):
     """lr = 1 converges quickly: the patience rule (DESC_PGD.m:243-246) fires before
     iters is exhausted, on the device, at the same iteration as in the oracle."""
@@ -202,7 +202,7 @@ import glob as _glob
 _GOLDEN = sorted(_glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
 
 
-@pytest.mark.parametrize("variant", ["node", "gather"])
+@pytest.mark.parametrize("variant", ["band", "node", "gather"])
 @pytest.mark.parametrize("path", _GOLDEN, ids=[os.path.basename(p)[:-4] for p in _GOLDEN])
 def test_golden_fixtures(lib, path, variant):
     """HIP path against the committed golden vectors (tests/golden/make_golden.py)."""
@@ -287,7 +287,7 @@ def test_device_resident_structure_layout(lib, oracle, n, p, seed, kind):
     dev_st = lib.Structure.build(prob, 30, 21, lib.BUILD_DEVICE, 0)
     solver = lib.Solver(prob, dev_st, 0)          # before any .arrays(): the host copy does not exist yet
     try:
-        assert "node" in solver.kernel_name()
+        assert "node" in solver.kernel_name() or "band" in solver.kernel_name()
         s0 = solver.s0()
         out = solver.run(c_params(60, seed=21, **step), want_w=True)
     finally:
@@ -343,7 +343,7 @@ def test_c_client(lib, tmp_path):
     assert "iterations" in r.stdout and "s(corrupted edge" in r.stdout
 
 
-@pytest.mark.parametrize("variant", ["node", "gather"])
+@pytest.mark.parametrize("variant", ["band", "node", "gather"])
 def test_sampling_regime_known_answer_by_hand(lib, variant):
     """The hand-tabulated two iterations of tests/kat_sampling.py (mirror cycles absent: the per-edge
     scalar sums of DESC_PGD.m:189-190 reach only the masked positions) through the C ABI, both layouts."""
@@ -378,7 +378,7 @@ def test_wrapper_keeps_device_structure_on_the_device(lib):
     st.free()
 
 
-@pytest.mark.parametrize("variant", ["node", "gather"])
+@pytest.mark.parametrize("variant", ["band", "node", "gather"])
 def test_adam_state_after_early_stop(lib, oracle, variant):
     """HybridGradient (Adam) with the patience rule firing before iters is exhausted: the stop of iteration
     `it` is only known during sweep it+1, whose Adam update must not leak into the returned m_t / v_t
