@@ -882,6 +882,43 @@ __global__ __launch_bounds__(BAND_THREADS, 1) void k_sweep_band(BandSweepArgs b)
     }
 }
 
+// Sum the block partials in a fixed order, record the traces and run the early-stop
+// rule of DESC_PGD.m:243-256 for the iteration whose objective just became known.
+// t = 1-based index of the sweep that produced the partials.  Called by one full wave.
+struct FinArgs {
+    const double* partials; DevState* st; double* obj_trace; double* avg_trace;
+    int64_t m; double stop_tol; int32_t nparts, t, patience, last_only;      // t == 0: nothing to do
+};
+__device__ __forceinline__ void finalize_wave(const FinArgs f) {
+    DevState* st = f.st;
+    if (st->stop) return;
+    const int lane = threadIdx.x & 63;
+    // every lane adds its strided share in index order, then the fixed DPP butterfly
+    double o = 0.0, ch = 0.0;
+    for (int i = lane; i < f.nparts; i += 64) { o += f.partials[2 * i]; ch += f.partials[2 * i + 1]; }
+    o = group_sum<64>(o); ch = group_sum<64>(ch);
+    if (lane != 0) return;
+    // last_only: the partials come from the objective kernel after the final sweep t and
+    // hold obj(t).  Otherwise they come from sweep t: obj(t-1) and sum|dS| of sweep t.
+    const int t = f.t;
+    const int it = f.last_only ? t : t - 1;          // iteration whose objective is o
+    if (!f.last_only) f.avg_trace[t - 1] = ch / (double)f.m;                            // :232
+    if (it >= 1) {
+        f.obj_trace[it - 1] = o;                                                        // :233
+        if (it <= st->last_tested) return;          // already tested (objective evaluated early by a download)
+        st->last_tested = it;
+        if (it > 1 && f.obj_trace[it - 2] - f.obj_trace[it - 1] < f.stop_tol) {         // :243
+            st->misses += 1;
+            if (st->misses >= f.patience) {                                             // :245-246
+                st->stop = 1; st->iters_run = it; st->final_parity = it & 1;
+            }
+        } else {
+            st->misses = 0;                                                             // :255
+        }
+    }
+}
+__global__ __launch_bounds__(64) void k_finalize(FinArgs f) { finalize_wave(f); }
+
 // Mirror-weight column sums (DESC_PGD.m:185-191 in node form).  One workgroup per node
 // v: for every incident edge {v,u} (CSR order) stream its segment; a cycle with third
 // vertex t adds its weight to column idx_v(t) if the reverse cycle ({v,t};u) was sampled.
@@ -890,14 +927,21 @@ __global__ __launch_bounds__(BAND_THREADS, 1) void k_sweep_band(BandSweepArgs b)
 // fixed order at the end -> bitwise reproducible.  Loads of COLSUM_U segments are in
 // flight per wave at once.
 constexpr int COLSUM_U = 8;
+// The LAST workgroup of the launch does no column at all: it runs the bookkeeping of the previous sweep (traces,
+// stop rule) that used to be a separate one-wave launch per iteration.  If it sets the stop flag while the
+// node workgroups of this launch are running, they finish a T that nobody reads: the sweep that follows returns at once.
 __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, const int2* adj_seg, const uint32_t* pk, const double* w,
-                                                     double* Tfull, int n, int stride_cols, const DevState* st, const int32_t* xpos) {
+                                                     double* Tfull, int n, int stride_cols, const DevState* st, const int32_t* xpos, FinArgs fin) {
+    if (blockIdx.x == gridDim.x - 1) {
+        if (fin.t > 0 && threadIdx.x < 64) finalize_wave(fin);
+        return;
+    }
     if (st->stop) return;
     extern __shared__ double acc[];                   // [4][stride_cols] doubles, then 2 ints per incident edge
     int* seg_base = (int*)(acc + 4 * stride_cols);
     int* seg_cf = seg_base + stride_cols;             // n_both | n_i << 9 | n_jonly << 18 | (v is the smaller endpoint) << 31
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int v = blockIdx.x; v < n; v += gridDim.x) {
+    for (int v = blockIdx.x; v < n; v += gridDim.x - 1) {
         const int r0 = rowptr[v], deg = rowptr[v + 1] - r0;
         if (deg == 0) continue;
         for (int t = threadIdx.x; t < 4 * stride_cols; t += 256) acc[t] = 0.0;
@@ -1220,38 +1264,6 @@ __global__ void k_gather_pairs(const double* sall, int64_t slice_len, int world,
 // ===========================================================================
 // shared small kernels
 // ===========================================================================
-// Sum the block partials in a fixed order, record the traces and run the early-stop
-// rule of DESC_PGD.m:243-256 for the iteration whose objective just became known.
-// t = 1-based index of the sweep that produced the partials.
-__global__ __launch_bounds__(64) void k_finalize(const double* partials, int nparts, DevState* st,
-                                                 double* obj_trace, double* avg_trace, int t, int64_t m,
-                                                 int patience, double stop_tol, int last_only) {
-    if (st->stop) return;
-    // one wave: every lane adds its strided share in index order, then the fixed DPP butterfly
-    double o = 0.0, ch = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += 64) { o += partials[2 * i]; ch += partials[2 * i + 1]; }
-    o = group_sum<64>(o); ch = group_sum<64>(ch);
-    if (threadIdx.x != 0) return;
-    const double sh[2][1] = {{o}, {ch}};
-    // last_only: the partials come from the objective kernel after the final sweep t and
-    // hold obj(t).  Otherwise they come from sweep t: obj(t-1) and sum|dS| of sweep t.
-    const int it = last_only ? t : t - 1;          // iteration whose objective is sh[0][0]
-    if (!last_only) avg_trace[t - 1] = sh[1][0] / (double)m;                          // :232
-    if (it >= 1) {
-        obj_trace[it - 1] = sh[0][0];                                                 // :233
-        if (it <= st->last_tested) return;          // already tested (objective evaluated early by a download)
-        st->last_tested = it;
-        if (it > 1 && obj_trace[it - 2] - obj_trace[it - 1] < stop_tol) {             // :243
-            st->misses += 1;
-            if (st->misses >= patience) {                                             // :245-246
-                st->stop = 1; st->iters_run = it; st->final_parity = it & 1;
-            }
-        } else {
-            st->misses = 0;                                                           // :255
-        }
-    }
-}
-
 __global__ void k_fill(double* p, int64_t n, double v) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -1320,6 +1332,7 @@ struct desc_pgd {
     double* d_pairs = nullptr;          // 2*world gathered scalars
     bool borrowed_stream = false, objective_done = false;
     int final_obj_T = -1;               // sweep count for which download already evaluated the objective
+    int pending_fin = 0, pending_parts = 0;   // sweep whose bookkeeping (k_finalize) rides on the next column-sum launch
     int32_t* d_rank_seg = nullptr;
     int trace_cap = 0;
     // run state
@@ -1438,17 +1451,27 @@ void launch_band(desc_pgd* h, const NodeSweepArgs& a) {
 // workgroups (= partial pairs) of the sweep kernel that serves this step kind
 int sweep_parts(const desc_pgd* h, bool adam) { return h->variant == VARIANT_NODE && h->band_ok && !adam ? h->band_grid : h->grid; }
 
+FinArgs fin_args(const desc_pgd* h, const double* partials, int nparts, int t, int last_only) {
+    return FinArgs{partials, h->d_state, h->d_obj, h->d_avg, h->m, h->p.stop_tol, nparts, t, h->p.patience, last_only};
+}
+// the bookkeeping of the last enqueued sweep, if it is still waiting for a column-sum launch to ride on
+void flush_finalize(desc_pgd* h) {
+    if (!h->pending_fin) return;
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, fin_args(h, h->d_partials, h->pending_parts, h->pending_fin, 0));
+    h->pending_fin = 0;
+}
+
 // enqueue sweep number t (1-based) and its finalize; ev0/ev1 bracket the kernels of the sweep proper
 int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
-    const desc_params& p = h->p;
     const int rd = (t - 1) & 1, wr = t & 1;
     bool adam = false;
     const StepArgs st = make_step(h, &adam, rd, wr);
     if (ev0) (void)hipEventRecord(ev0, h->stream);
     if (h->variant == VARIANT_NODE) {
-        hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 2 * sizeof(int)), h->stream,
+        hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 2 * sizeof(int)), h->stream,
                            h->d_rowptr, h->d_adj_seg, h->d_pk, h->d_w[rd], h->d_T, (int)h->n,
-                           h->colsum_stride, h->d_state, (const int32_t*)nullptr);
+                           h->colsum_stride, h->d_state, (const int32_t*)nullptr, fin_args(h, h->d_partials, h->pending_parts, h->pending_fin, 0));
+        h->pending_fin = 0;
         NodeSweepArgs a{};
         a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
         a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->d_T; a.t_seg_lo = -1; a.nv_tab = h->d_nv; a.partials = h->d_partials;
@@ -1463,8 +1486,8 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
         if (adam) launch_gather<DESC_STEP_HYBRID>(h, a); else launch_gather<DESC_STEP_CONSTANT>(h, a);
     }
     if (ev1) (void)hipEventRecord(ev1, h->stream);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, h->d_partials, sweep_parts(h, adam), h->d_state, h->d_obj,
-                       h->d_avg, t, h->m, p.patience, p.stop_tol, 0);
+    h->pending_fin = t; h->pending_parts = sweep_parts(h, adam);
+    if (h->variant != VARIANT_NODE) flush_finalize(h);         // no column-sum launch to ride on
     DESC_HIP(hipGetLastError());
     return DESC_OK;
 }
@@ -2125,7 +2148,7 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
             rc = dalloc(h, &h->d_partials, 2 * (size_t)std::max(std::max(h->grid, h->obj_grid), h->band_grid)); if (rc) return rc;
         }
     }
-    h->t_done = 0; h->t_plugin = p->t0; h->ms_pgd = 0; h->objective_done = false; h->final_obj_T = -1;
+    h->t_done = 0; h->t_plugin = p->t0; h->ms_pgd = 0; h->objective_done = false; h->final_obj_T = -1; h->pending_fin = 0;
     const int cap = std::max(1, p->iters);
     if (cap > h->trace_cap) {
         dfree(h, h->d_obj); dfree(h, h->d_avg);
@@ -2221,6 +2244,7 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
     if (!r->s_vec && h->m > 0) return fail(DESC_ERR_INVALID, "result.s_vec is NULL");
     int rc = set_device(h); if (rc) return rc;
     const int T = h->t_done;
+    flush_finalize(h);
     // objective of the last sweep (DESC_PGD.m:233) and its stop test
     if (h->m_pos > 0 && T >= 1 && h->world == 1 && h->final_obj_T != T) {
         h->final_obj_T = T;
@@ -2230,8 +2254,7 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
         else
             hipLaunchKernelGGL(k_objective, dim3(h->obj_grid), dim3(256), 0, h->stream, h->d_w[T & 1], h->d_S[T & 1], h->d_ejk,
                                h->d_eki, h->m_cycle, h->d_partials, h->d_state);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, h->d_partials, h->obj_grid, h->d_state, h->d_obj,
-                           h->d_avg, T, h->m, h->p.patience, h->p.stop_tol, 1);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, fin_args(h, h->d_partials, h->obj_grid, T, 1));
     }
     DevState st{};
     DESC_HIP(hipMemcpyAsync(&st, h->d_state, sizeof st, hipMemcpyDeviceToHost, h->stream));
@@ -2298,6 +2321,8 @@ int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r) {
         left -= nq;
         if (left > 0 && h->m_pos > 0) {
             DevState st{};
+            flush_finalize(h);
+            DESC_HIP(hipStreamSynchronize(h->stream));
             DESC_HIP(hipMemcpy(&st, h->d_state, sizeof st, hipMemcpyDeviceToHost));
             if (st.stop) break;
         }
@@ -2341,8 +2366,8 @@ int desc_pgd_shard_colsum(desc_pgd* h) {
     if (!h || !h->armed || !h->x_T) return fail(DESC_ERR_STATE, "shard not armed / bound");
     int rc = set_device(h); if (rc) return rc;
     const int rd = h->t_done & 1;
-    hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 2 * sizeof(int)), h->stream,
-                       h->d_rowptr, h->d_adj_seg, h->d_pk, h->d_w[rd], h->x_T, (int)h->n, h->colsum_stride, h->d_state, h->d_xpos);
+    hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 2 * sizeof(int)), h->stream,
+                       h->d_rowptr, h->d_adj_seg, h->d_pk, h->d_w[rd], h->x_T, (int)h->n, h->colsum_stride, h->d_state, h->d_xpos, FinArgs{});
     DESC_HIP(hipGetLastError());
     return DESC_OK;
 }
@@ -2388,8 +2413,7 @@ int desc_pgd_shard_finish(desc_pgd* h, int32_t initial) {
     hipLaunchKernelGGL(k_unpack_S, dim3(g), dim3(256), 0, h->stream, h->d_einfo, h->d_rank_seg, h->world, h->x_sall, h->slice_len,
                        h->d_S[initial == 2 ? 0 : wr], initial == 2 ? h->d_S[1] : nullptr, h->d_pairs);
     if (initial != 2)
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, h->d_pairs, h->world, h->d_state, h->d_obj, h->d_avg, t, h->m,
-                           h->p.patience, h->p.stop_tol, 0);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, fin_args(h, h->d_pairs, h->world, t, 0));
     DESC_HIP(hipGetLastError());
     return DESC_OK;
 }
@@ -2407,8 +2431,7 @@ int desc_pgd_shard_objective(desc_pgd* h, int32_t phase) {
                            h->x_sall + (int64_t)h->rank * h->slice_len, (int)h->seg_lo, (int)h->seg_lo, h->slice_len);
     } else {
         hipLaunchKernelGGL(k_gather_pairs, dim3(1), dim3(64), 0, h->stream, h->x_sall, h->slice_len, h->world, h->d_pairs);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, h->d_pairs, h->world, h->d_state, h->d_obj, h->d_avg, T, h->m,
-                           h->p.patience, h->p.stop_tol, 1);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, fin_args(h, h->d_pairs, h->world, T, 1));
         h->objective_done = true;
     }
     DESC_HIP(hipGetLastError());
@@ -2420,6 +2443,7 @@ int desc_pgd_stopped(desc_pgd* h, int32_t* stopped) {
     if (!h || !stopped) return fail(DESC_ERR_INVALID, "NULL argument");
     int rc = set_device(h); if (rc) return rc;
     DevState st{};
+    flush_finalize(h);
     DESC_HIP(hipMemcpyAsync(&st, h->d_state, sizeof st, hipMemcpyDeviceToHost, h->stream));
     DESC_HIP(hipStreamSynchronize(h->stream));
     *stopped = st.stop;
