@@ -27,7 +27,8 @@ EXPORTS = [
     "desc_pgd_iterate_timed", "desc_pgd_sync", "desc_pgd_download", "desc_pgd_get_s0",
     "desc_pgd_sizes", "desc_pgd_kernel_name", "desc_pgd_solve", "desc_selftest_group_sum",
     "desc_pgd_create_shard", "desc_pgd_shard_info", "desc_pgd_shard_bind", "desc_pgd_shard_colsum", "desc_pgd_shard_sweep",
-    "desc_pgd_shard_finish", "desc_pgd_shard_objective", "desc_pgd_stopped", "desc_spectral_run", "desc_cemp_run", "desc_refine_run",
+    "desc_pgd_shard_finish", "desc_pgd_shard_objective", "desc_pgd_shard_set_collectives", "desc_pgd_shard_start",
+    "desc_pgd_shard_iterate", "desc_pgd_shard_run", "desc_pgd_stopped", "desc_device_synchronize", "desc_memcpy_d2h", "desc_memcpy_h2d", "desc_spectral_run", "desc_cemp_run", "desc_refine_run",
 ]
 
 I32P = C.POINTER(C.c_int32)
@@ -72,6 +73,14 @@ class ShardInfo(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("t_len", C.c_int64), ("t_part", C.c_int64), ("slice_len", C.c_int64),
                 ("seg_lo", C.c_int64), ("seg_hi", C.c_int64), ("cyc_lo", C.c_int64), ("cyc_hi", C.c_int64),
                 ("m_pos", C.c_int64), ("m_cycle", C.c_int64)]
+
+
+RS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)     # ncclReduceScatter
+AG_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p)              # ncclAllGather
+
+
+class Collectives(C.Structure):
+    _fields_ = [("comm", C.c_void_p), ("reduce_scatter", C.c_void_p), ("all_gather", C.c_void_p)]
 
 
 class SpectralInfo(C.Structure):
@@ -151,6 +160,13 @@ def load():
     L.desc_pgd_shard_finish.argtypes = [C.c_void_p, C.c_int32]
     L.desc_pgd_shard_objective.argtypes = [C.c_void_p, C.c_int32]
     L.desc_pgd_stopped.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    L.desc_pgd_shard_set_collectives.argtypes = [C.c_void_p, C.POINTER(Collectives)]
+    L.desc_pgd_shard_start.argtypes = [C.c_void_p, C.POINTER(Params)]
+    L.desc_pgd_shard_iterate.argtypes = [C.c_void_p, C.c_int32]
+    L.desc_pgd_shard_run.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Result)]
+    L.desc_device_synchronize.argtypes = [C.c_int32]
+    L.desc_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.desc_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.desc_spectral_run.argtypes = [C.POINTER(Problem), F64P, C.c_int32, C.c_double, C.c_int32, C.c_int32, F64P,
                                     C.POINTER(SpectralInfo)]
     _lib = L
@@ -335,6 +351,25 @@ class Solver:
 
     def shard_objective(self, phase):
         check(load().desc_pgd_shard_objective(self.handle, phase))
+
+    # fused protocol: whole iterations enqueued from C (collectives = function pointers, e.g. RCCL's)
+    def shard_set_collectives(self, comm=None, reduce_scatter=None, all_gather=None):
+        c = Collectives(comm, C.cast(reduce_scatter, C.c_void_p) if reduce_scatter is not None else None,
+                        C.cast(all_gather, C.c_void_p) if all_gather is not None else None)
+        self._coll_keepalive = (reduce_scatter, all_gather)
+        check(load().desc_pgd_shard_set_collectives(self.handle, C.byref(c)))
+
+    def shard_start(self, params: Params):
+        self._iters_cap = params.iters
+        check(load().desc_pgd_shard_start(self.handle, C.byref(params)))
+
+    def shard_iterate(self, n):
+        check(load().desc_pgd_shard_iterate(self.handle, n))
+
+    def shard_run(self, params: Params):
+        r, bufs = self._result(params.iters)
+        check(load().desc_pgd_shard_run(self.handle, C.byref(params), C.byref(r)))
+        return self._pack(r, bufs)
 
     def stopped(self):
         f = C.c_int32()

@@ -385,6 +385,7 @@ struct NodeSweepArgs {
     double* S_new;
     const double* Tfull;       // 2m: Tfull[rowptr[v]+t] = sum_k w(v,k; nbr_t), masked; sharded runs: T1, T2 per owned segment
     int32_t t_seg_lo;          // >= 0: Tfull holds {T1, T2} of segment l at 2*(l - t_seg_lo) (after the reduce-scatter)
+    double* s_slice;           // sharded runs: the new S of segment l also goes to s_slice[l - t_seg_lo] (this rank's all-gather slice)
     const double* nv_tab;
     double* partials;
     const DevState* state;
@@ -601,6 +602,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
             if (cnt > 0 && r16 == 0) {
                 chg_acc += fabs(part - c.g.So);                                                      // :232
                 a.S_new[r0.sa] = part; a.S_new[r0.sb] = part;
+                if (a.s_slice) a.s_slice[r0.seg - a.t_seg_lo] = part;
             }
         }
         return o;
@@ -841,6 +843,7 @@ __global__ __launch_bounds__(BAND_THREADS, 1) void k_sweep_band(BandSweepArgs b)
             if (cnt > 0 && rr == 0) {
                 chg_acc += fabs(part - g.So);                                                            // :232
                 a.S_new[r.sa] = part; a.S_new[r.sb] = part;
+                if (a.s_slice) a.s_slice[r.seg - a.t_seg_lo] = part;
             }
         };
 
@@ -888,6 +891,7 @@ __global__ __launch_bounds__(BAND_THREADS, 1) void k_sweep_band(BandSweepArgs b)
 struct FinArgs {
     const double* partials; DevState* st; double* obj_trace; double* avg_trace;
     int64_t m; double stop_tol; int32_t nparts, t, patience, last_only;      // t == 0: nothing to do
+    int64_t rank_stride; int32_t nranks;     // sharded runs: the partials of rank r start at partials + r * rank_stride (0 / 0: one rank)
 };
 __device__ __forceinline__ void finalize_wave(const FinArgs f) {
     DevState* st = f.st;
@@ -895,7 +899,10 @@ __device__ __forceinline__ void finalize_wave(const FinArgs f) {
     const int lane = threadIdx.x & 63;
     // every lane adds its strided share in index order, then the fixed DPP butterfly
     double o = 0.0, ch = 0.0;
-    for (int i = lane; i < f.nparts; i += 64) { o += f.partials[2 * i]; ch += f.partials[2 * i + 1]; }
+    for (int r = 0; r < max(f.nranks, 1); ++r) {      // rank order, then index order: the same sum on every rank
+        const double* q = f.partials + (int64_t)r * f.rank_stride;
+        for (int i = lane; i < f.nparts; i += 64) { o += q[2 * i]; ch += q[2 * i + 1]; }
+    }
     o = group_sum<64>(o); ch = group_sum<64>(ch);
     if (lane != 0) return;
     // last_only: the partials come from the objective kernel after the final sweep t and
@@ -1161,7 +1168,7 @@ __global__ __launch_bounds__(256) void k_xpos(const int32_t* rowptr, const int32
 }
 
 __global__ __launch_bounds__(256) void k_init_node(const int32_t* cum, const EdgeInfo* einfo, const double* S0,
-                                                   double* w, double* S_a, double* S_b, int m_pos) {
+                                                   double* w, double* S_a, double* S_b, int m_pos, double* s_slice) {
     const int lane = threadIdx.x & 63;
     const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * 256) >> 6;
@@ -1174,6 +1181,7 @@ __global__ __launch_bounds__(256) void k_init_node(const int32_t* cum, const Edg
         if (lane == 0) {
             const EdgeInfo ei = einfo[l];
             S_a[ei.slot_a] = s; S_a[ei.slot_b] = s; S_b[ei.slot_a] = s; S_b[ei.slot_b] = s;
+            if (s_slice) s_slice[l] = s;
         }
     }
 }
@@ -1219,45 +1227,28 @@ __global__ __launch_bounds__(256) void k_reorder_cycles(const int32_t* cum, cons
 }
 
 // ---- multi-GPU exchange helpers (node variant) --------------------------------
-// S of the local edges (+ this rank's two scalar partials) -> this rank's slice of the
-// exchange buffer
-__global__ __launch_bounds__(256) void k_pack_S(const EdgeInfo* einfo, const double* Sfull, const double* partials, int nparts,
-                                                double* slice, int seg_lo, int seg_hi, int64_t slice_len) {
-    const int nloc = seg_hi - seg_lo;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < nloc; t += gridDim.x * 256) slice[t] = Sfull[einfo[seg_lo + t].slot_a];
-    if (blockIdx.x == 0) {
-        __shared__ double sh[2][256];
-        double o = 0.0, ch = 0.0;
-        for (int i = threadIdx.x; i < nparts; i += 256) { o += partials[2 * i]; ch += partials[2 * i + 1]; }
-        sh[0][threadIdx.x] = o; sh[1][threadIdx.x] = ch;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) { sh[0][threadIdx.x] += sh[0][threadIdx.x + s]; sh[1][threadIdx.x] += sh[1][threadIdx.x + s]; }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) { slice[slice_len - 2] = sh[0][0]; slice[slice_len - 1] = sh[1][0]; }
-    }
-}
-// gathered slices -> both CSR slots of every edge with cycles; scalar pairs -> contiguous
+// A rank's all-gather slice = [S of the edges it owns, padded to the largest shard | SHARD_PARTS pairs of workgroup
+// partials (objective, sum |dS|)].  The sweep kernels write both straight into the slice; after the all-gather
+// k_unpack_S scatters S of every edge into both of its CSR slots, and its extra last workgroup adds all ranks'
+// partials in rank order (identical sums, hence identical stop decisions, on every rank) and runs the stop rule.
+constexpr int SHARD_PARTS = 512;
 __global__ __launch_bounds__(256) void k_unpack_S(const EdgeInfo* einfo, const int32_t* rank_seg, int world, const double* sall,
-                                                  int64_t slice_len, double* S_a, double* S_b, double* pairs) {
+                                                  int64_t slice_len, double* S_a, double* S_b, FinArgs fin) {
+    if (blockIdx.x == gridDim.x - 1) {
+        if (fin.t > 0 && threadIdx.x < 64) finalize_wave(fin);
+        return;
+    }
+    // once the stop rule has fired the slices hold the discarded sweep: the double buffers must keep the final iterate
+    if (fin.st->stop) return;
     for (int r = 0; r < world; ++r) {
         const int lo = rank_seg[r], hi = rank_seg[r + 1];
         const double* sl = sall + (int64_t)r * slice_len;
-        for (int t = blockIdx.x * 256 + threadIdx.x; t < hi - lo; t += gridDim.x * 256) {
+        for (int t = blockIdx.x * 256 + threadIdx.x; t < hi - lo; t += (gridDim.x - 1) * 256) {
             const EdgeInfo ei = einfo[lo + t];
             const double v = sl[t];
             S_a[ei.slot_a] = v; S_a[ei.slot_b] = v;
             if (S_b) { S_b[ei.slot_a] = v; S_b[ei.slot_b] = v; }
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) { pairs[2 * r] = sl[slice_len - 2]; pairs[2 * r + 1] = sl[slice_len - 1]; }
-    }
-}
-
-__global__ void k_gather_pairs(const double* sall, int64_t slice_len, int world, double* pairs) {
-    for (int r = threadIdx.x; r < world; r += blockDim.x) {
-        pairs[2 * r] = sall[(int64_t)r * slice_len + slice_len - 2];
-        pairs[2 * r + 1] = sall[(int64_t)r * slice_len + slice_len - 1];
     }
 }
 
@@ -1323,14 +1314,19 @@ struct desc_pgd {
     int64_t cyc_lo = 0, cyc_hi = 0;     // their cycles
     int ch_lo = 0;                      // first chunk owned
     int64_t slice_len = 0;              // doubles per rank in the S exchange buffer
+    int64_t slice_S = 0;                // ... of which S values (the rest: SHARD_PARTS pairs of partials)
+    desc_collectives coll{};            // fused protocol: the caller's collectives (RCCL entry points + communicator)
+    hipStream_t comm_stream = nullptr;  // second stream: exchange + unpack overlap the next column-sum pass
+    hipEvent_t ev_col = nullptr, ev_rs = nullptr, ev_sw = nullptr, ev_done = nullptr;
+    bool own_xbuf = false, force_coll = false;
     std::vector<int64_t> rank_seg;      // world+1 segment boundaries
     double* x_T = nullptr;              // caller-bound exchange buffers (device): owner-sorted partial mirror sums (send)
     double* x_Trecv = nullptr;          // reduce-scattered mirror sums of the owned segments
     int32_t* d_xpos = nullptr;          // 2m: CSR slot -> position in x_T
     int64_t t_part = 0;
     double* x_sall = nullptr;           //   world * slice_len
-    double* d_pairs = nullptr;          // 2*world gathered scalars
     bool borrowed_stream = false, objective_done = false;
+    int last_parts = 0;                 // workgroup partials the last sharded sweep wrote
     int final_obj_T = -1;               // sweep count for which download already evaluated the objective
     int pending_fin = 0, pending_parts = 0;   // sweep whose bookkeeping (k_finalize) rides on the next column-sum launch
     int32_t* d_rank_seg = nullptr;
@@ -1369,6 +1365,8 @@ void free_all(desc_pgd* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     for (void* q : h->allocs) if (q) (void)hipFree(q);
+    for (hipEvent_t e : {h->ev_col, h->ev_rs, h->ev_sw, h->ev_done}) if (e) (void)hipEventDestroy(e);
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     if (h->stream && !h->borrowed_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1452,7 +1450,7 @@ void launch_band(desc_pgd* h, const NodeSweepArgs& a) {
 int sweep_parts(const desc_pgd* h, bool adam) { return h->variant == VARIANT_NODE && h->band_ok && !adam ? h->band_grid : h->grid; }
 
 FinArgs fin_args(const desc_pgd* h, const double* partials, int nparts, int t, int last_only) {
-    return FinArgs{partials, h->d_state, h->d_obj, h->d_avg, h->m, h->p.stop_tol, nparts, t, h->p.patience, last_only};
+    return FinArgs{partials, h->d_state, h->d_obj, h->d_avg, h->m, h->p.stop_tol, nparts, t, h->p.patience, last_only, 0, 1};
 }
 // the bookkeeping of the last enqueued sweep, if it is still waiting for a column-sum launch to ride on
 void flush_finalize(desc_pgd* h) {
@@ -1678,7 +1676,8 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     int64_t max_local = 0;
     for (int r = 0; r <= h->world; ++r) h->rank_seg[r] = P.chunk_seg[P.rank_chunk[r]];
     for (int r = 0; r < h->world; ++r) max_local = std::max(max_local, h->rank_seg[r + 1] - h->rank_seg[r]);
-    h->slice_len = max_local + 2;
+    h->slice_len = max_local + 2 * SHARD_PARTS;     // S of the owned edges, then the workgroup partials (see k_unpack_S)
+    h->slice_S = max_local;
     h->t_part = 2 * std::max<int64_t>(max_local, 1);
     const int64_t mcl = h->cyc_hi - h->cyc_lo;            // local cycles
     const int64_t nsl = h->seg_hi - h->seg_lo;            // local segments
@@ -1884,7 +1883,6 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     if ((rc = dalloc(h, &h->d_T, 2 * m))) return rc;
     if ((rc = dalloc(h, &h->d_Svec, m))) return rc;
     if ((rc = dalloc(h, &h->d_chunk_desc, chunk_desc.size()))) return rc;
-    if ((rc = dalloc(h, &h->d_pairs, 2 * (size_t)h->world))) return rc;
     if ((rc = dalloc(h, &h->d_rank_seg, (size_t)h->world + 1))) return rc;
     if ((rc = dalloc(h, &h->d_xpos, 2 * m))) return rc;
     if (h->band_ok) {
@@ -1949,7 +1947,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
         int64_t want = std::min<int64_t>(std::max(h->nchunks, 1), (int64_t)ncu * per_cu);
         h->grid = (int)(std::max<int64_t>(want, 8) + 7) / 8 * 8;
     }
-    h->obj_grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (nsl + 3) / 4));
+    h->obj_grid = (int)std::min<int64_t>(SHARD_PARTS, std::max<int64_t>(1, (nsl + 3) / 4));     // sharded runs: its partials travel in the all-gather slice
     h->colsum_stride = (h->max_deg + 1) | 1;                 // odd stride: the 4 copies start on different banks
     h->colsum_grid = (int)std::max<int64_t>(1, n);            // one node per workgroup: the dispatcher balances
     {
@@ -2179,7 +2177,8 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
     if (h->m_pos > 0) {
         int g = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (h->m_pos + 3) / 4));
         if (h->variant == VARIANT_NODE)
-            hipLaunchKernelGGL(k_init_node, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_einfo + h->seg_lo, h->d_S0, h->d_w[0], h->d_S[0], h->d_S[1], (int)(h->seg_hi - h->seg_lo));
+            hipLaunchKernelGGL(k_init_node, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_einfo + h->seg_lo, h->d_S0, h->d_w[0], h->d_S[0], h->d_S[1], (int)(h->seg_hi - h->seg_lo),
+                               h->x_sall ? h->x_sall + (int64_t)h->rank * h->slice_len : (double*)nullptr);
         else
             hipLaunchKernelGGL(k_init, dim3(g), dim3(256), 0, h->stream, h->d_cum, h->d_pos_edge, h->d_S0, h->d_w[0], h->d_S[0], h->d_S[1], (int)h->m_pos);
     }
@@ -2234,6 +2233,7 @@ int desc_pgd_sync(desc_pgd* h) {
     if (!h) return fail(DESC_ERR_INVALID, "NULL handle");
     int rc = set_device(h); if (rc) return rc;
     DESC_HIP(hipStreamSynchronize(h->stream));
+    if (h->comm_stream) DESC_HIP(hipStreamSynchronize(h->comm_stream));
     DESC_HIP(hipGetLastError());
     return DESC_OK;
 }
@@ -2245,6 +2245,7 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
     int rc = set_device(h); if (rc) return rc;
     const int T = h->t_done;
     flush_finalize(h);
+    if (h->comm_stream) DESC_HIP(hipStreamSynchronize(h->comm_stream));
     // objective of the last sweep (DESC_PGD.m:233) and its stop test
     if (h->m_pos > 0 && T >= 1 && h->world == 1 && h->final_obj_T != T) {
         h->final_obj_T = T;
@@ -2348,9 +2349,20 @@ int desc_pgd_shard_info(const desc_pgd* h, desc_shard_info* info) {
 int desc_pgd_shard_bind(desc_pgd* h, double* T_send, double* T_recv, double* sall, void* hip_stream) {
     if (!h) return fail(DESC_ERR_INVALID, "NULL handle");
     if (h->variant != VARIANT_NODE) return fail(DESC_ERR_STATE, "sharding needs the node layout");
-    if (!T_send || !T_recv || !sall) return fail(DESC_ERR_INVALID, "NULL exchange buffer");
     int rc = set_device(h); if (rc) return rc;
     DESC_HIP(hipStreamSynchronize(h->stream));
+    if (sweep_parts(h, false) > SHARD_PARTS || h->grid > SHARD_PARTS) return fail(DESC_ERR_STATE, "sweep grid exceeds the partials area of the exchange slice");
+    if (!T_send && !T_recv && !sall) {       // library-owned exchange buffers (the fused protocol does not need torch tensors)
+        const int64_t t_len = (int64_t)h->world * h->t_part + 1;
+        if ((rc = dalloc(h, &T_send, (size_t)t_len))) return rc;
+        if (h->world > 1) { if ((rc = dalloc(h, &T_recv, (size_t)h->t_part))) return rc; }
+        else T_recv = T_send;                // one rank: the owner-sorted partial sums ARE the totals
+        if ((rc = dalloc(h, &sall, (size_t)(h->world * h->slice_len)))) return rc;
+        DESC_HIP(hipMemsetAsync(T_send, 0, sizeof(double) * t_len, h->stream));
+        DESC_HIP(hipMemsetAsync(sall, 0, sizeof(double) * h->world * h->slice_len, h->stream));
+        DESC_HIP(hipStreamSynchronize(h->stream));
+        h->own_xbuf = true;
+    } else if (!T_send || !T_recv || !sall) return fail(DESC_ERR_INVALID, "NULL exchange buffer");
     h->x_T = T_send; h->x_Trecv = T_recv; h->x_sall = sall;
     if (hip_stream) {          // run on the caller's stream so collectives and kernels are ordered
         if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -2360,81 +2372,194 @@ int desc_pgd_shard_bind(desc_pgd* h, double* T_send, double* T_recv, double* sal
     return DESC_OK;
 }
 
+namespace {
+// the pieces of one sharded iteration, each enqueued on the stream given
+int shard_enqueue_colsum(desc_pgd* h, hipStream_t st) {
+    const int rd = h->t_done & 1;
+    hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 2 * sizeof(int)), st,
+                       h->d_rowptr, h->d_adj_seg, h->d_pk, h->d_w[rd], h->x_T, (int)h->n, h->colsum_stride, h->d_state, h->d_xpos, FinArgs{});
+    DESC_HIP(hipGetLastError());
+    return DESC_OK;
+}
+double* my_slice(desc_pgd* h) { return h->x_sall + (int64_t)h->rank * h->slice_len; }
+int shard_enqueue_sweep(desc_pgd* h, hipStream_t st) {
+    if (h->t_done + 1 > h->trace_cap) return fail(DESC_ERR_INVALID, "iterating past params.iters = %d", h->p.iters);
+    const int t = ++h->t_done, rd = (t - 1) & 1, wr = t & 1;
+    bool adam = false;
+    const StepArgs sa = make_step(h, &adam, rd, wr);
+    NodeSweepArgs a{};
+    a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
+    a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_Trecv; a.t_seg_lo = (int32_t)h->seg_lo; a.nv_tab = h->d_nv;
+    a.s_slice = my_slice(h); a.partials = my_slice(h) + h->slice_S;       // S and the workgroup partials go straight into the slice
+    a.state = h->d_state; a.st = sa; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks;
+    a.max_cnt = h->max_cnt; a.ablate = 0;
+    const hipStream_t keep = h->stream; h->stream = st;
+    if (adam) launch_node<DESC_STEP_HYBRID>(h, a); else if (h->band_ok) launch_band(h, a); else launch_node<DESC_STEP_CONSTANT>(h, a);
+    h->stream = keep;
+    h->last_parts = sweep_parts(h, adam);
+    DESC_HIP(hipGetLastError());
+    return DESC_OK;
+}
+// after the all-gather: S of every edge into the CSR-aligned copy (+ traces and stop rule of sweep t when fin_t > 0)
+int shard_enqueue_unpack(desc_pgd* h, hipStream_t st, double* S_a, double* S_b, int fin_t, int last_only, int /*nparts*/) {
+    const int g = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (h->slice_S + 255) / 256));
+    // the whole partial area of every slice is added (sweep grids may differ between ranks on tiny problems; unused pairs are zero)
+    FinArgs f = fin_args(h, h->x_sall + h->slice_S, SHARD_PARTS, fin_t, last_only);
+    f.rank_stride = h->slice_len; f.nranks = h->world;
+    hipLaunchKernelGGL(k_unpack_S, dim3(g + 1), dim3(256), 0, st, h->d_einfo, h->d_rank_seg, S_a ? h->world : 0, h->x_sall, h->slice_len, S_a, S_b, f);
+    if (last_only)        // the objective pass filled more pairs than a sweep does: clear this rank's area for further iterations
+        DESC_HIP(hipMemsetAsync(my_slice(h) + h->slice_S, 0, sizeof(double) * 2 * SHARD_PARTS, st));
+    DESC_HIP(hipGetLastError());
+    return DESC_OK;
+}
+int shard_enqueue_objective(desc_pgd* h, hipStream_t st) {
+    const int T = h->t_done;
+    // exactly SHARD_PARTS workgroups on every rank (idle ones write zeros): the partial areas of all slices are summed in full
+    hipLaunchKernelGGL(k_objective_node, dim3(SHARD_PARTS), dim3(256), 0, st, h->d_cum + h->seg_lo, h->d_einfo + h->seg_lo, h->d_pk,
+                       h->d_w[T & 1], h->d_S[T & 1], (int)(h->seg_hi - h->seg_lo), my_slice(h) + h->slice_S, h->d_state);
+    DESC_HIP(hipGetLastError());
+    return DESC_OK;
+}
+}  // namespace
+
 // step 1 of an iteration: partial column sums of the segments this rank owns -> T_send, grouped by the
 // rank that owns each edge (then: reduce-scatter(sum) T_send -> T_recv)
 int desc_pgd_shard_colsum(desc_pgd* h) {
     if (!h || !h->armed || !h->x_T) return fail(DESC_ERR_STATE, "shard not armed / bound");
     int rc = set_device(h); if (rc) return rc;
-    const int rd = h->t_done & 1;
-    hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 2 * sizeof(int)), h->stream,
-                       h->d_rowptr, h->d_adj_seg, h->d_pk, h->d_w[rd], h->x_T, (int)h->n, h->colsum_stride, h->d_state, h->d_xpos, FinArgs{});
-    DESC_HIP(hipGetLastError());
-    return DESC_OK;
+    return shard_enqueue_colsum(h, h->stream);
 }
 
-// step 2: sweep the owned chunks (T now holds the global sums), then pack S of the owned
-// edges and this rank's scalar partials into its slice of sall (then: all-gather sall)
+// step 2: sweep the owned chunks (T_recv holds the global sums); S of the owned edges and the workgroup partials
+// are written straight into this rank's slice of sall (then: all-gather sall)
 int desc_pgd_shard_sweep(desc_pgd* h) {
     if (!h || !h->armed || !h->x_T) return fail(DESC_ERR_STATE, "shard not armed / bound");
-    if (h->t_done + 1 > h->trace_cap) return fail(DESC_ERR_INVALID, "iterating past params.iters = %d", h->p.iters);
     int rc = set_device(h); if (rc) return rc;
-    const int t = ++h->t_done, rd = (t - 1) & 1, wr = t & 1;
-    bool adam = false;
-    const StepArgs st = make_step(h, &adam, rd, wr);
-    NodeSweepArgs a{};
-    a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
-    a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_Trecv; a.t_seg_lo = (int32_t)h->seg_lo; a.nv_tab = h->d_nv; a.partials = h->d_partials;
-    a.state = h->d_state; a.st = st; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks;
-    a.max_cnt = h->max_cnt; a.ablate = 0;
-    if (adam) launch_node<DESC_STEP_HYBRID>(h, a); else if (h->band_ok) launch_band(h, a); else launch_node<DESC_STEP_CONSTANT>(h, a);
-    const int nloc = (int)(h->seg_hi - h->seg_lo);
-    hipLaunchKernelGGL(k_pack_S, dim3(std::max(1, std::min(1024, (nloc + 255) / 256))), dim3(256), 0, h->stream, h->d_einfo, h->d_S[wr],
-                       h->d_partials, sweep_parts(h, adam), h->x_sall + (int64_t)h->rank * h->slice_len, (int)h->seg_lo, (int)h->seg_hi, h->slice_len);
-    DESC_HIP(hipGetLastError());
-    return DESC_OK;
+    return shard_enqueue_sweep(h, h->stream);
 }
 
-// step 3: (sall gathered) scatter S of every edge into the CSR-aligned copy, add the
-// scalar partials in rank order, record traces, early-stop rule.
-// initial != 0: the exchange after desc_pgd_reset (distributes the initial S_vec, no traces).
+// step 3: (sall gathered) scatter S of every edge into the CSR-aligned copy, add the partials of all ranks in
+// rank order, record traces, early-stop rule.
+// initial: 1 = after desc_pgd_reset, before the first all-gather (the reset already put the initial S of the owned
+// edges into the slice: nothing to do); 2 = after that all-gather: distribute the initial S_vec, no traces.
 int desc_pgd_shard_finish(desc_pgd* h, int32_t initial) {
     if (!h || !h->armed || !h->x_sall) return fail(DESC_ERR_STATE, "shard not armed / bound");
     int rc = set_device(h); if (rc) return rc;
     const int t = h->t_done, wr = t & 1;
-    const int g = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (h->slice_len + 255) / 256));
     if (initial && t != 0) return fail(DESC_ERR_STATE, "initial exchange after iterations");
-    if (initial == 1) {
-        const int nloc = (int)(h->seg_hi - h->seg_lo);
-        hipLaunchKernelGGL(k_pack_S, dim3(std::max(1, std::min(1024, (nloc + 255) / 256))), dim3(256), 0, h->stream, h->d_einfo, h->d_S[0],
-                           h->d_partials, 0, h->x_sall + (int64_t)h->rank * h->slice_len, (int)h->seg_lo, (int)h->seg_hi, h->slice_len);
-        DESC_HIP(hipGetLastError());
-        return DESC_OK;        // caller all-gathers, then calls desc_pgd_shard_finish(h, 2)
-    }
-    hipLaunchKernelGGL(k_unpack_S, dim3(g), dim3(256), 0, h->stream, h->d_einfo, h->d_rank_seg, h->world, h->x_sall, h->slice_len,
-                       h->d_S[initial == 2 ? 0 : wr], initial == 2 ? h->d_S[1] : nullptr, h->d_pairs);
-    if (initial != 2)
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, fin_args(h, h->d_pairs, h->world, t, 0));
-    DESC_HIP(hipGetLastError());
-    return DESC_OK;
+    if (initial == 1) return DESC_OK;
+    if (initial == 2) return shard_enqueue_unpack(h, h->stream, h->d_S[0], h->d_S[1], 0, 0, 0);
+    return shard_enqueue_unpack(h, h->stream, h->d_S[wr], nullptr, t, 0, h->last_parts);
 }
 
-// final objective of a sharded run: local partial -> slice tail (then all-gather, then finish(3))
+// final objective of a sharded run: phase 0 puts this rank's partials into its slice (then: all-gather sall),
+// phase 1 adds the partials of all ranks and runs the stop rule for the last iteration.
 int desc_pgd_shard_objective(desc_pgd* h, int32_t phase) {
     if (!h || !h->armed || !h->x_sall) return fail(DESC_ERR_STATE, "shard not armed / bound");
     int rc = set_device(h); if (rc) return rc;
     const int T = h->t_done;
     if (T < 1) return DESC_OK;
-    if (phase == 0) {
-        hipLaunchKernelGGL(k_objective_node, dim3(h->obj_grid), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_einfo + h->seg_lo, h->d_pk,
-                           h->d_w[T & 1], h->d_S[T & 1], (int)(h->seg_hi - h->seg_lo), h->d_partials, h->d_state);
-        hipLaunchKernelGGL(k_pack_S, dim3(1), dim3(256), 0, h->stream, h->d_einfo, h->d_S[T & 1], h->d_partials, h->obj_grid,
-                           h->x_sall + (int64_t)h->rank * h->slice_len, (int)h->seg_lo, (int)h->seg_lo, h->slice_len);
-    } else {
-        hipLaunchKernelGGL(k_gather_pairs, dim3(1), dim3(64), 0, h->stream, h->x_sall, h->slice_len, h->world, h->d_pairs);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, fin_args(h, h->d_pairs, h->world, T, 1));
-        h->objective_done = true;
+    if (phase == 0) return shard_enqueue_objective(h, h->stream);
+    rc = shard_enqueue_unpack(h, h->stream, nullptr, nullptr, T, 1, h->obj_grid);
+    h->objective_done = true; h->final_obj_T = T;
+    return rc;
+}
+
+// ---- the fused protocol: whole iterations enqueued from C, exchange overlapped with the next column-sum pass
+int desc_pgd_shard_set_collectives(desc_pgd* h, const desc_collectives* c) {
+    if (!h) return fail(DESC_ERR_INVALID, "NULL handle");
+    if (h->variant != VARIANT_NODE) return fail(DESC_ERR_STATE, "sharding needs the node layout");
+    if (h->world > 1 && (!c || !c->reduce_scatter || !c->all_gather)) return fail(DESC_ERR_INVALID, "world > 1 needs both collectives");
+    int rc = set_device(h); if (rc) return rc;
+    h->coll = c ? *c : desc_collectives{};
+    // diagnostics: call the collectives even with one rank (plumbing test of the RCCL entry points on a one-GPU box)
+    h->force_coll = env_int("DESC_DEBUG_FORCE_COLLECTIVES", 0) != 0 && h->coll.reduce_scatter && h->coll.all_gather;
+    if (!h->x_sall && (rc = desc_pgd_shard_bind(h, nullptr, nullptr, nullptr, nullptr))) return rc;
+    if (!h->comm_stream) {
+        DESC_HIP(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&h->ev_col, &h->ev_rs, &h->ev_sw, &h->ev_done}) DESC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
-    DESC_HIP(hipGetLastError());
+    return DESC_OK;
+}
+
+namespace {
+int coll_fail(int code, const char* what) { return fail(DESC_ERR_HIP, "%s failed with code %d", what, code); }
+int shard_all_gather(desc_pgd* h) {
+    if (h->world == 1 && !h->force_coll) return DESC_OK;
+    const int rcc = h->coll.all_gather(my_slice(h), h->x_sall, (size_t)h->slice_len, 8 /* ncclDouble */, h->coll.comm, h->comm_stream);
+    return rcc ? coll_fail(rcc, "all_gather") : DESC_OK;
+}
+}  // namespace
+
+// reset + the initial exchange (every rank ends up with the full initial S_vec)
+int desc_pgd_shard_start(desc_pgd* h, const desc_params* p) {
+    if (!h || !p) return fail(DESC_ERR_INVALID, "NULL argument");
+    if (!h->comm_stream) return fail(DESC_ERR_STATE, "desc_pgd_shard_set_collectives must be called first");
+    int rc = desc_pgd_reset(h, p); if (rc) return rc;
+    DESC_HIP(hipEventRecord(h->ev_sw, h->stream));
+    DESC_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_sw, 0));
+    if ((rc = shard_all_gather(h))) return rc;
+    if ((rc = shard_enqueue_unpack(h, h->comm_stream, h->d_S[0], h->d_S[1], 0, 0, 0))) return rc;
+    DESC_HIP(hipEventRecord(h->ev_done, h->comm_stream));
+    return DESC_OK;
+}
+
+// n iterations: compute stream  colsum(t) . . . . . . sweep(t) | colsum(t+1) . . . sweep(t+1)
+//               comm stream               RS(t)                | AG(t), unpack(t) + stop rule, RS(t+1)
+// colsum(t+1) needs only the weights of sweep t, so the all-gather of S and its unpacking overlap it.
+int desc_pgd_shard_iterate(desc_pgd* h, int32_t n_iters) {
+    if (!h || !h->armed) return fail(DESC_ERR_STATE, "desc_pgd_shard_start must be called first");
+    if (!h->comm_stream) return fail(DESC_ERR_STATE, "desc_pgd_shard_set_collectives must be called first");
+    if (n_iters < 0 || h->t_done + n_iters > h->trace_cap) return fail(DESC_ERR_INVALID, "iterating past params.iters = %d", h->p.iters);
+    int rc = set_device(h); if (rc) return rc;
+    for (int q = 0; q < n_iters; ++q) {
+        if ((rc = shard_enqueue_colsum(h, h->stream))) return rc;
+        if (h->world > 1 || h->force_coll) {
+            DESC_HIP(hipEventRecord(h->ev_col, h->stream));
+            DESC_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_col, 0));
+            const int rcc = h->coll.reduce_scatter(h->x_T, h->x_Trecv, (size_t)h->t_part, 8 /* ncclDouble */, 0 /* ncclSum */, h->coll.comm, h->comm_stream);
+            if (rcc) return coll_fail(rcc, "reduce_scatter");
+            DESC_HIP(hipEventRecord(h->ev_rs, h->comm_stream));
+            DESC_HIP(hipStreamWaitEvent(h->stream, h->ev_rs, 0));      // implies S of the previous iteration unpacked (same stream, earlier)
+        } else {
+            DESC_HIP(hipStreamWaitEvent(h->stream, h->ev_done, 0));
+        }
+        if ((rc = shard_enqueue_sweep(h, h->stream))) return rc;
+        DESC_HIP(hipEventRecord(h->ev_sw, h->stream));
+        DESC_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_sw, 0));
+        if ((rc = shard_all_gather(h))) return rc;
+        // one rank: the sweep already wrote S of every edge; only the bookkeeping is left
+        if ((rc = shard_enqueue_unpack(h, h->comm_stream, h->world > 1 ? h->d_S[h->t_done & 1] : nullptr, nullptr, h->t_done, 0, h->last_parts))) return rc;
+        DESC_HIP(hipEventRecord(h->ev_done, h->comm_stream));
+    }
+    return DESC_OK;
+}
+
+// start + iterate (polling the stop flag every check_every iterations) + final objective + download
+int desc_pgd_shard_run(desc_pgd* h, const desc_params* p, desc_result* r) {
+    if (!h || !p || !r) return fail(DESC_ERR_INVALID, "NULL argument");
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = desc_pgd_shard_start(h, p); if (rc) return rc;
+    const int chunk = p->check_every > 0 ? p->check_every : 32;
+    int left = p->iters;
+    while (left > 0) {
+        const int nq = std::min(left, chunk);
+        if ((rc = desc_pgd_shard_iterate(h, nq))) return rc;
+        left -= nq;
+        if (left > 0) { int32_t stop = 0; if ((rc = desc_pgd_stopped(h, &stop))) return rc; if (stop) break; }
+    }
+    if (h->t_done >= 1) {
+        DESC_HIP(hipStreamWaitEvent(h->stream, h->ev_done, 0));
+        if ((rc = shard_enqueue_objective(h, h->stream))) return rc;
+        DESC_HIP(hipEventRecord(h->ev_sw, h->stream));
+        DESC_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_sw, 0));
+        if ((rc = shard_all_gather(h))) return rc;
+        if ((rc = shard_enqueue_unpack(h, h->comm_stream, nullptr, nullptr, h->t_done, 1, h->obj_grid))) return rc;
+        DESC_HIP(hipEventRecord(h->ev_done, h->comm_stream));
+        h->objective_done = true; h->final_obj_T = h->t_done;
+    }
+    rc = desc_pgd_download(h, r); if (rc) return rc;
+    r->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return DESC_OK;
 }
 
@@ -2444,12 +2569,27 @@ int desc_pgd_stopped(desc_pgd* h, int32_t* stopped) {
     int rc = set_device(h); if (rc) return rc;
     DevState st{};
     flush_finalize(h);
+    if (h->comm_stream) DESC_HIP(hipStreamSynchronize(h->comm_stream));
     DESC_HIP(hipMemcpyAsync(&st, h->d_state, sizeof st, hipMemcpyDeviceToHost, h->stream));
     DESC_HIP(hipStreamSynchronize(h->stream));
     *stopped = st.stop;
     return DESC_OK;
 }
 
+
+int desc_device_synchronize(int32_t device) {
+    DESC_HIP(hipSetDevice(device));
+    DESC_HIP(hipDeviceSynchronize());
+    return DESC_OK;
+}
+int desc_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes) {
+    if (bytes) DESC_HIP(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    return DESC_OK;
+}
+int desc_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes) {
+    if (bytes) DESC_HIP(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return DESC_OK;
+}
 
 // test hook: group_sum over a buffer of 64*k doubles
 int desc_selftest_group_sum(const double* in, double* out, int32_t count, int32_t G, int32_t device) {

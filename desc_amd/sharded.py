@@ -15,14 +15,24 @@ Per iteration (node form):
        traces + early-stop rule -> identical decisions on all ranks
 The reference itself is single-process MATLAB; nothing here has a counterpart in it.
 
-``ShardedDriver`` is backend-agnostic: it talks to a *shard* object (``HipShard`` wraps
-the C ABI; the CPU tests plug in a NumPy shard) and a *comm* object (``TorchComm``).
+Two drivers:
+
+* ``NativeShard`` (default on GPUs): the *fused* protocol of the C ABI -- ``desc_pgd_shard_start / _iterate / _run``
+  enqueue whole iterations from C on two streams (the all-gather of S and its unpacking overlap the next column-sum
+  pass); the collectives are function pointers.  ``RcclComm`` hands over the ``ncclReduceScatter`` / ``ncclAllGather``
+  entry points of the ``librccl.so`` PyTorch ships (the copy already mapped into the process) and a communicator created
+  with ``ncclCommInitRank`` from an id broadcast over ``torch.distributed``: no Python between iterations.
+  ``TrampolineComm`` passes Python callbacks instead (staged through host memory over gloo): functional tests only.
+* ``ShardedDriver`` + ``HipShard``: the *piecewise* protocol, one ctypes call per step with ``torch.distributed``
+  collectives in between; backend-agnostic (the CPU tests plug in a NumPy shard), and the fallback of the bench when the
+  native communicator cannot be created.
 """
 from __future__ import annotations
 
 import ctypes as C
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -178,6 +188,111 @@ class ShardedDriver:
         return self.finish()
 
 
+class RcclComm:
+    """RCCL communicator created next to torch's own, for the fused C protocol.  Uses the librccl.so that ships
+    with PyTorch -- the copy torch.distributed's "nccl" backend has already mapped (one ROCm runtime per process)."""
+
+    def __init__(self, rank, world, device):
+        import torch
+        import torch.distributed as dist
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self.lib = C.CDLL(path)
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+
+        uid = UniqueId()
+        if rank == 0:
+            rc = self.lib.ncclGetUniqueId(C.byref(uid))
+            if rc:
+                raise _lib.DescError(f"ncclGetUniqueId failed: {rc}")
+        box = [bytes(C.string_at(C.byref(uid), 128))]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        C.memmove(C.byref(uid), box[0], 128)
+        torch.cuda.set_device(device)
+        self.comm = C.c_void_p()
+        self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        rc = self.lib.ncclCommInitRank(C.byref(self.comm), world, uid, rank)
+        if rc:
+            raise _lib.DescError(f"ncclCommInitRank failed: {rc}")
+        self.reduce_scatter = self.lib.ncclReduceScatter
+        self.all_gather = self.lib.ncclAllGather
+
+    def destroy(self):
+        if self.comm:
+            self.lib.ncclCommDestroy.argtypes = [C.c_void_p]
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = C.c_void_p()
+
+
+class TrampolineComm:
+    """Python callbacks with the RCCL signatures, for the fused C protocol on backends other than RCCL (tests:
+    two processes sharing one GPU over gloo).  Each call drains the device, moves the buffer through host memory
+    and runs the torch.distributed collective: slow by construction."""
+
+    def __init__(self, group=None, device=0):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.comm = None
+        L = _lib.load()               # copies through the library's own HIP runtime (never a second copy of it)
+        self.device = device
+
+        def rs(send, recv, recvcount, dtype, op, comm, stream):
+            try:
+                L.desc_device_synchronize(self.device)
+                h = torch.empty(self.world * recvcount, dtype=torch.float64)
+                L.desc_memcpy_d2h(h.data_ptr(), send, 8 * h.numel())
+                dist.all_reduce(h, group=self.group)
+                mine = h.view(self.world, recvcount)[self.rank].contiguous()
+                L.desc_memcpy_h2d(recv, mine.data_ptr(), 8 * recvcount)
+                L.desc_device_synchronize(self.device)
+                return 0
+            except Exception:            # never raise through the C frame
+                return 1
+
+        def ag(send, recv, sendcount, dtype, comm, stream):
+            try:
+                L.desc_device_synchronize(self.device)
+                mine = torch.empty(sendcount, dtype=torch.float64)
+                L.desc_memcpy_d2h(mine.data_ptr(), send, 8 * sendcount)
+                parts = [torch.empty(sendcount, dtype=torch.float64) for _ in range(self.world)]
+                dist.all_gather(parts, mine, group=self.group)
+                full = torch.cat(parts)
+                L.desc_memcpy_h2d(recv, full.data_ptr(), 8 * full.numel())
+                L.desc_device_synchronize(self.device)
+                return 0
+            except Exception:
+                return 1
+
+        self.reduce_scatter = _lib.RS_FN(rs)
+        self.all_gather = _lib.AG_FN(ag)
+
+    def destroy(self):
+        pass
+
+
+class NativeShard:
+    """One rank's share of the problem driven through the fused C protocol."""
+
+    def __init__(self, prob, structure, device, rank, world, comm=None):
+        self.solver = _lib.Solver(prob, structure, device, rank, world)
+        self.info = self.solver.shard_info()
+        self.comm = comm
+        if comm is None:
+            self.solver.shard_set_collectives()
+        else:
+            self.solver.shard_set_collectives(comm.comm, comm.reduce_scatter, comm.all_gather)
+
+    def start(self, params): self.solver.shard_start(params)
+    def iterate(self, n): self.solver.shard_iterate(n)
+    def run(self, params): return self.solver.shard_run(params)
+    def sync(self): self.solver.sync()
+    def destroy(self): self.solver.destroy()
+
+
 def init_distributed():
     """torchrun-style bootstrap: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env."""
     import torch
@@ -199,8 +314,9 @@ def init_distributed():
     return rank, world, device
 
 
-def _bench_one(name, args, rank, world, device, comm, describe, generate):
-    """K timed sharded iterations of one workload; returns the measurements (identical on every rank)."""
+def _bench_one(name, args, rank, world, device, comm, describe, generate, native_comm):
+    """K timed sharded iterations of one workload; returns the measurements (identical on every rank).
+    native_comm: RcclComm (fused C protocol) or None (piecewise protocol over torch.distributed)."""
     import torch
     K, W = args.steps, args.warmup
     mo, nn, ii, jj, rij = generate(name)                 # identical on every rank (fixed seeds)
@@ -214,30 +330,46 @@ def _bench_one(name, args, rank, world, device, comm, describe, generate):
         st = _lib.Structure.build(prob, 30, args.seed, _lib.BUILD_HOST, device)
     t_struct = time.perf_counter() - t0
     n_sample = st.sizes()["n_sample"]
-    t0 = time.perf_counter()
-    shard = HipShard(prob, st, device, rank, world)
-    t_create = time.perf_counter() - t0
-    st.free()
-    drv = ShardedDriver(shard, comm)
     p = _lib.default_params()
     p.iters = W + K + 4
     p.lr = 0.01
     p.patience = (1 << 31) - 1          # the bench times exactly K sweeps: never stop early
     p.seed = args.seed
-    drv.start(p)
-    drv.iterate(W)
-    with shard.stream_ctx():
-        torch.cuda.synchronize(); comm.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    drv.iterate(K)
-    with shard.stream_ctx():
-        torch.cuda.synchronize(); comm.barrier(); torch.cuda.synchronize()
-    dt = comm.max_float(time.perf_counter() - t0)
-    out = drv.finish()
+    if native_comm is not None or world == 1:
+        shard = NativeShard(prob, st, device, rank, world, native_comm)
+        t_create = time.perf_counter() - t0
+        st.free()
+        shard.start(p)
+        shard.iterate(W)
+        shard.sync(); torch.cuda.synchronize(); comm.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        shard.iterate(K)
+        shard.sync(); torch.cuda.synchronize(); comm.barrier(); torch.cuda.synchronize()
+        dt = comm.max_float(time.perf_counter() - t0)
+        # objective of the last iterate + download through the piecewise calls of the same handle
+        out = shard.solver.download()
+        driver = "fused C protocol (two streams; RCCL entry points called from the library)"
+    else:
+        shard = HipShard(prob, st, device, rank, world)
+        t_create = time.perf_counter() - t0
+        st.free()
+        drv = ShardedDriver(shard, comm)
+        drv.start(p)
+        drv.iterate(W)
+        with shard.stream_ctx():
+            torch.cuda.synchronize(); comm.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        drv.iterate(K)
+        with shard.stream_ctx():
+            torch.cuda.synchronize(); comm.barrier(); torch.cuda.synchronize()
+        dt = comm.max_float(time.perf_counter() - t0)
+        out = drv.finish()
+        driver = "piecewise protocol (torch.distributed collectives between ctypes calls)"
     info = shard.info
     res = dict(name=name, nn=nn, m=shard.solver.m, m_pos=info.m_pos, m_cycle=info.m_cycle, n_sample=int(n_sample), dt=dt,
                t_struct=t_struct, t_create=t_create, err=float(np.mean(np.abs(out["S_vec"] - mo.ErrVec))),
-               workload=describe(name))
+               workload=describe(name), driver=driver)
     shard.destroy()
     return res
 
@@ -254,10 +386,21 @@ def bench_sharded(args, WORKLOADS, describe, generate, cpu_baseline):
     comm = TorchComm()
     K, W = args.steps, args.warmup
     name = args.workload or "C2"
-    r = _bench_one(name, args, rank, world, device, comm, describe, generate)
+    native = None
+    if os.environ.get("DESC_SHARD_DRIVER", "native") == "native" and not comm.staged:
+        try:
+            native = RcclComm(rank, world, device)
+        except Exception as e:             # all ranks fail alike (same library, same call): fall back together
+            if rank == 0:
+                print(f"[desc_amd] native RCCL communicator unavailable ({e!r}); using the piecewise torch.distributed driver", file=sys.stderr, flush=True)
+            native = None
+        ok = comm.max_float(0.0 if native is not None else 1.0)      # any rank without it -> nobody uses it
+        if ok > 0 and native is not None:
+            native.destroy(); native = None
+    r = _bench_one(name, args, rank, world, device, comm, describe, generate, native)
     extra = None
     if args.workload is None:
-        x = _bench_one("C4", args, rank, world, device, comm, describe, generate)
+        x = _bench_one("C4", args, rank, world, device, comm, describe, generate, native)
         xb = 72.0 * x["m_cycle"] + 12.0 * x["m_pos"]
         extra = {"workload": x["workload"], "value": K / x["dt"], "unit": "iters/s", "ms_per_step": x["dt"] / K * 1e3,
                  "m_cycle": x["m_cycle"], "roofline_frac_of_aggregate_hbm": xb / (x["dt"] / K) / 1e9 / (8000.0 * world),
@@ -271,7 +414,7 @@ def bench_sharded(args, WORKLOADS, describe, generate, cpu_baseline):
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": r["workload"], "n": r["nn"], "m": r["m"], "m_pos": r["m_pos"], "m_cycle": r["m_cycle"],
                    "n_sample": r["n_sample"], "sampling_seed": args.seed,
-                   "parallelism": f"edges sharded over {world} GPUs; reduce-scatter of the mirror sums (2 m_pos f64) + all-gather S per iteration"},
+                   "parallelism": f"edges sharded over {world} GPUs; reduce-scatter of the mirror sums (2 m_pos f64) + all-gather S per iteration; " + r["driver"]},
         "roofline": {"bound": "hbm", "achieved": bytes_iter / (dt / K) / 1e9, "peak": 8000.0 * world, "unit": "GB/s",
                      "frac": bytes_iter / (dt / K) / 1e9 / (8000.0 * world), "traffic": None,
                      "kernel": "whole iteration incl. collectives (aggregate over ranks)", "bytes_per_launch": bytes_iter},

@@ -22,6 +22,7 @@
 #ifndef DESC_AMD_H
 #define DESC_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -192,7 +193,8 @@ typedef struct desc_shard_info {
     int32_t rank, world;
     int64_t t_len;            /* doubles in T_send = world*t_part + 1 (owner-sorted mirror sums, last = unused slot) */
     int64_t t_part;           /* doubles in T_recv: T1, T2 of every owned edge-with-cycles, padded to the largest shard */
-    int64_t slice_len;        /* doubles per rank in sall (owned edges + 2 scalars, padded)   */
+    int64_t slice_len;        /* doubles per rank in sall: S of the owned edges (padded to the largest shard), then the
+                                 workgroup partials (objective, sum |dS|) of the rank's last sweep                      */
     int64_t seg_lo, seg_hi;   /* owned range of edges-with-cycles (library order)             */
     int64_t cyc_lo, cyc_hi;   /* owned range of cycles                                        */
     int64_t m_pos, m_cycle;   /* global counts                                                */
@@ -202,17 +204,40 @@ int desc_pgd_create_shard(const desc_problem* prob, const desc_structure* s, int
 int desc_pgd_shard_info(const desc_pgd* h, desc_shard_info* info);
 /* T_send: t_len doubles, zero-initialised by the caller (this rank's partial mirror sums, grouped by
  * owning rank: part r = [r*t_part, (r+1)*t_part)); T_recv: t_part doubles (the caller's
- * reduce-scatter(sum) of every rank's T_send); sall: world*slice_len doubles; all on `device`.
+ * reduce-scatter(sum) of every rank's T_send); sall: world*slice_len doubles, zero-initialised; all on `device`.
+ * All three NULL: the library allocates them itself (the fused protocol below needs no caller buffers).
  * hip_stream: the stream the caller's collectives are ordered on (NULL keeps the handle's own). */
 int desc_pgd_shard_bind(desc_pgd* h, double* T_send, double* T_recv, double* sall, void* hip_stream);
+/* Piecewise protocol (one call per step, the caller runs the collectives in between; kept for drivers that own
+ * the communication, e.g. torch.distributed with a backend other than RCCL, and for single-GPU emulation tests). */
 int desc_pgd_shard_colsum(desc_pgd* h);
 int desc_pgd_shard_sweep(desc_pgd* h);
-/* initial: 0 = after an iteration's all-gather; 1 = pack the initial S_vec (after reset,
- * before the first all-gather); 2 = unpack the initial S_vec (after that all-gather). */
+/* initial: 0 = after an iteration's all-gather; 1 = after reset, before the first all-gather (no-op: the reset
+ * already put the initial S of the owned edges into the slice); 2 = unpack the initial S_vec (after that all-gather). */
 int desc_pgd_shard_finish(desc_pgd* h, int32_t initial);
-/* objective of the last iterate: phase 0 packs this rank's partial (then all-gather sall),
- * phase 1 adds the partials and runs the stop rule for the last iteration. */
+/* objective of the last iterate: phase 0 puts this rank's partials into its slice (then all-gather sall),
+ * phase 1 adds the partials of all ranks and runs the stop rule for the last iteration. */
 int desc_pgd_shard_objective(desc_pgd* h, int32_t phase);
+
+/* Fused protocol: the library enqueues whole iterations itself -- column sums, reduce-scatter, sweep, all-gather,
+ * unpack + stop rule -- on two streams, so that the all-gather of S_vec and its unpacking overlap the next
+ * iteration's column-sum pass (which needs only the weights).  The collectives are the caller's: two function
+ * pointers with the signatures of RCCL's ncclReduceScatter / ncclAllGather (datatype 8 = ncclDouble, op 0 =
+ * ncclSum, hipStream_t stream) and the communicator they take; a binding passes the addresses of the RCCL
+ * symbols of the process (desc_amd/sharded.py: the librccl.so PyTorch ships, communicator created with
+ * ncclCommInitRank from an id broadcast over torch.distributed) or its own trampolines.  world == 1: both may
+ * be NULL.  Nothing in the reference corresponds to this (it is single-process MATLAB). */
+typedef struct desc_collectives {
+    void* comm;               /* ncclComm_t (opaque to the library) */
+    int (*reduce_scatter)(const void* sendbuff, void* recvbuff, size_t recvcount, int datatype, int op, void* comm, void* stream);
+    int (*all_gather)(const void* sendbuff, void* recvbuff, size_t sendcount, int datatype, void* comm, void* stream);
+} desc_collectives;
+int desc_pgd_shard_set_collectives(desc_pgd* h, const desc_collectives* c);
+int desc_pgd_shard_start(desc_pgd* h, const desc_params* p);          /* reset + initial exchange of S_vec        */
+int desc_pgd_shard_iterate(desc_pgd* h, int32_t n_iters);             /* enqueue n_iters iterations               */
+/* start + iterate (the stop flag is polled every p->check_every iterations; identical on all ranks) + objective of
+ * the last iterate + download (S_vec, traces; per-cycle outputs are not gathered across ranks). */
+int desc_pgd_shard_run(desc_pgd* h, const desc_params* p, desc_result* r);
 /* *stopped = 1 once the device-side patience rule (DESC_PGD.m:243-246) has fired; waits for
  * the handle's stream. */
 int desc_pgd_stopped(desc_pgd* h, int32_t* stopped);
@@ -267,6 +292,13 @@ int desc_refine_run(const desc_problem* prob, const double* s_vec, const double*
 /* One-shot: what the MEX shim calls.  Builds the structure (p->build_where),
  * uploads, runs, downloads, frees. */
 int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* r);
+
+/* Binding utilities: synchronous copies between host memory and device memory of the library's own HIP runtime
+ * (a binding that implements the collectives itself, e.g. staged through host memory, must not load a second
+ * runtime), after draining every stream of `device`. */
+int desc_device_synchronize(int32_t device);
+int desc_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);
+int desc_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes);
 
 /* Test hook: sums `in` over aligned groups of G = 16/32/64 lanes with the kernels'
  * DPP / permlane-swap reduction; every element of a group receives the group total. */

@@ -141,3 +141,75 @@ def test_sharded_emulated_device_built_structure(lib, oracle, world, n, p, nmin)
         assert o["iters_run"] == ref["iters_run"]
         assert np.abs(o["S_vec"] - ref["S_vec"]).max() <= TOL
         assert np.allclose(o["obj"], ref["obj"], rtol=1e-12, atol=1e-9)
+
+
+# ---------------------------------------------------------------- fused C protocol
+@pytest.mark.parametrize("case", ["const", "sampling_piecewise", "early_stop"])
+def test_fused_protocol_one_rank(lib, oracle, case, monkeypatch):
+    """desc_pgd_shard_run with world = 1: the whole two-stream iteration loop in C (no collectives) == oracle; then the
+    same with the real RCCL entry points of the process forced on a one-rank communicator (plumbing of the function
+    pointers: signature, datatype / op codes, stream)."""
+    from desc_amd.sharded import NativeShard, RcclComm
+    cfg = dict(const=dict(n=60, p=0.5, iters=40, kw=dict(lr=0.01)),
+               sampling_piecewise=dict(n=150, p=0.6, iters=25, kw=dict(lr=0.05, step_kind=1, decay_interval=4, t0=1)),
+               early_stop=dict(n=40, p=0.5, iters=300, kw=dict(lr=1.0, patience=5, stop_tol=1e-3)))[case]
+    mo, nn, ii, jj, rij = make_problem("uniform", n=cfg["n"], p=cfg["p"], q=0.2, sigma=0.1, seed=5)
+    st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=9, iters=cfg["iters"], **cfg["kw"])
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    for mode in ("none", "rccl"):
+        hst = lib.Structure.build(prob, 30, 9, lib.BUILD_HOST, 0)
+        comm = None
+        if mode == "rccl":
+            monkeypatch.setenv("DESC_DEBUG_FORCE_COLLECTIVES", "1")
+            comm = RcclComm(0, 1, 0)
+        shard = NativeShard(prob, hst, 0, 0, 1, comm)
+        hst.free()
+        out = shard.run(c_params(cfg["iters"], seed=9, check_every=7, **cfg["kw"]))
+        shard.destroy()
+        if comm is not None:
+            comm.destroy()
+        assert out["iters_run"] == ref["iters_run"], mode
+        assert np.abs(out["S_vec"] - ref["S_vec"]).max() <= TOL
+        assert np.allclose(out["obj"], ref["obj"], rtol=1e-12, atol=1e-9)
+        assert np.allclose(out["avg"], ref["avg"], rtol=1e-9, atol=1e-14)
+
+
+def _worker_fused(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", DESC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from desc_amd import _lib
+    from desc_amd.sharded import NativeShard, TrampolineComm, init_distributed
+    import torch.distributed as dist
+    init_distributed()
+    mo, nn, ii, jj, rij = make_problem("uniform", n=90, p=0.5, q=0.2, sigma=0.1, seed=6)
+    prob = _lib.ProblemArrays(nn, ii, jj, rij)
+    st = _lib.Structure.build(prob, 30, 2, _lib.BUILD_DEVICE, 0)
+    comm = TrampolineComm(device=0)
+    shard = NativeShard(prob, st, 0, rank, world, comm)
+    out = shard.run(c_params(30, lr=0.01, seed=2, check_every=4))
+    q.put((rank, out["S_vec"], out["obj"], out["iters_run"]))
+    dist.barrier(); dist.destroy_process_group()
+    shard.destroy()
+
+
+def test_fused_protocol_two_processes_one_gpu(oracle):
+    """The fused C loop with a real exchange between two processes (collectives = Python trampolines staged over gloo)."""
+    import torch.multiprocessing as mp
+    mo, nn, ii, jj, rij = make_problem("uniform", n=90, p=0.5, q=0.2, sigma=0.1, seed=6)
+    st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=2, iters=30, lr=0.01)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_fused, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120); assert p.exitcode == 0
+    for rank, S, obj, it in res:
+        assert it == ref["iters_run"]
+        assert np.abs(S - ref["S_vec"]).max() <= TOL
+        assert np.allclose(obj, ref["obj"], rtol=1e-12, atol=1e-9)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
