@@ -19,7 +19,8 @@ BUILD_HOST, BUILD_DEVICE = 0, 1
 
 # every symbol include/desc_amd.h declares (tests check that the library exports them)
 EXPORTS = [
-    "desc_last_error", "desc_version", "desc_device_count",
+    "desc_last_error", "desc_version", "desc_device_count", "desc_problem_upload", "desc_problem_free",
+    "desc_spectral_run_dev", "desc_cemp_run_dev", "desc_refine_run_dev", "desc_pgd_create_dev",
     "desc_structure_build", "desc_structure_import", "desc_structure_get", "desc_structure_sizes",
     "desc_structure_host_exports", "desc_structure_free",
     "desc_sample_key", "desc_params_default",
@@ -169,6 +170,16 @@ def load():
     L.desc_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.desc_spectral_run.argtypes = [C.POINTER(Problem), F64P, C.c_int32, C.c_double, C.c_int32, C.c_int32, F64P,
                                     C.POINTER(SpectralInfo)]
+    L.desc_problem_upload.argtypes = [C.POINTER(Problem), C.c_int32, C.POINTER(C.c_void_p)]
+    L.desc_problem_free.argtypes = [C.c_void_p]
+    L.desc_problem_free.restype = None
+    L.desc_spectral_run_dev.argtypes = [C.c_void_p, F64P, C.c_int32, C.c_double, C.c_int32, F64P, C.POINTER(SpectralInfo)]
+    L.desc_cemp_run_dev.argtypes = [C.c_void_p, F64P, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, F64P, C.POINTER(C.c_double)]
+    L.desc_refine_run_dev.argtypes = [C.c_void_p, F64P, F64P, C.c_double, C.c_int32, F64P, C.POINTER(RefineInfo)]
+    L.desc_pgd_create_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.desc_cemp_run.argtypes = [C.POINTER(Problem), F64P, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, F64P,
+                                C.POINTER(C.c_double)]
+    L.desc_refine_run.argtypes = [C.POINTER(Problem), F64P, F64P, C.c_double, C.c_int32, C.c_int32, F64P, C.POINTER(RefineInfo)]
     _lib = L
     return L
 
@@ -200,6 +211,27 @@ class ProblemArrays:
         if self.rij is not None and self.rij.shape[0] != 9 * m:
             raise ValueError("rij must hold m*9 doubles")
         self.c = Problem(int(n), m, ptr(self.ind_i, I32P), ptr(self.ind_j, I32P), ptr(self.rij, F64P))
+
+
+class DeviceProblem:
+    """Owner of a desc_device_problem*: Ind / RijMat / CSR index resident in HBM, shared by every stage of DESC()."""
+
+    def __init__(self, prob: ProblemArrays, device=0):
+        h = C.c_void_p()
+        check(load().desc_problem_upload(C.byref(prob.c), device, C.byref(h)))
+        self.handle, self.prob, self.device = h, prob, device
+        self.n, self.m = prob.n, prob.m
+
+    def free(self):
+        if self.handle:
+            load().desc_problem_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def _view_arrays(v: StructureView):
@@ -264,9 +296,12 @@ class Structure:
 class Solver:
     """Owner of a desc_pgd* (problem + structure resident in HBM)."""
 
-    def __init__(self, prob: ProblemArrays, structure: Structure, device=0, rank=0, world=1):
+    def __init__(self, prob, structure: Structure, device=0, rank=0, world=1):
         h = C.c_void_p()
-        check(load().desc_pgd_create_shard(C.byref(prob.c), structure.handle, device, rank, world, C.byref(h)))
+        if isinstance(prob, DeviceProblem):        # rotations and edge list already in HBM
+            check(load().desc_pgd_create_dev(prob.handle, structure.handle, rank, world, C.byref(h)))
+        else:
+            check(load().desc_pgd_create_shard(C.byref(prob.c), structure.handle, device, rank, world, C.byref(h)))
         self.handle = h
         m, mp, mc, mx = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
         check(load().desc_pgd_sizes(h, C.byref(m), C.byref(mp), C.byref(mc), C.byref(mx)))
@@ -401,40 +436,46 @@ def solve(prob: ProblemArrays, params: Params, want_w=False):
                 ms_upload=r.ms_upload, ms_cycle_d=r.ms_cycle_d, ms_pgd=r.ms_pgd, ms_total=r.ms_total, ms_structure=r.ms_structure)
 
 
-def spectral_run(prob: ProblemArrays, weights=None, normalize_rows=False, tol=1e-13, max_iters=500, device=0):
-    """desc_spectral_run -> (R (3,3,n) Fortran-ordered, info dict)."""
-    n = prob.c.n
+def spectral_run(prob, weights=None, normalize_rows=False, tol=1e-13, max_iters=500, device=0):
+    """desc_spectral_run[_dev] -> (R (3,3,n) Fortran-ordered, info dict).  prob: ProblemArrays or DeviceProblem."""
+    n = prob.n
     R = np.zeros(9 * max(n, 1))
     w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
     info = SpectralInfo()
-    check(load().desc_spectral_run(C.byref(prob.c), ptr(w, F64P), 1 if normalize_rows else 0, tol, max_iters, device,
-                                   ptr(R, F64P), C.byref(info)))
+    if isinstance(prob, DeviceProblem):
+        check(load().desc_spectral_run_dev(prob.handle, ptr(w, F64P), 1 if normalize_rows else 0, tol, max_iters, ptr(R, F64P), C.byref(info)))
+    else:
+        check(load().desc_spectral_run(C.byref(prob.c), ptr(w, F64P), 1 if normalize_rows else 0, tol, max_iters, device,
+                                       ptr(R, F64P), C.byref(info)))
     return R[:9 * n].reshape((3, 3, n), order="F"), dict(iters=info.iters, products=info.products, converged=bool(info.converged), residual=info.residual,
                                                         eigenvalues=list(info.eigenvalues), ms_total=info.ms_total)
 
 
-def cemp_run(prob: ProblemArrays, beta, max_iter, nsample, seed=0, device=0):
+def cemp_run(prob, beta, max_iter, nsample, seed=0, device=0):
     b = np.ascontiguousarray(beta, dtype=np.float64).reshape(-1)
-    S = np.zeros(max(prob.c.m, 1))
+    S = np.zeros(max(prob.m, 1))
     ms = C.c_double()
     L = load()
-    L.desc_cemp_run.argtypes = [C.POINTER(Problem), F64P, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, F64P,
-                                C.POINTER(C.c_double)]
-    check(L.desc_cemp_run(C.byref(prob.c), ptr(b, F64P), b.shape[0], int(max_iter), int(nsample), int(seed), device, ptr(S, F64P),
-                          C.byref(ms)))
-    return S[:prob.c.m], ms.value
+    if isinstance(prob, DeviceProblem):
+        check(L.desc_cemp_run_dev(prob.handle, ptr(b, F64P), b.shape[0], int(max_iter), int(nsample), int(seed), ptr(S, F64P), C.byref(ms)))
+    else:
+        check(L.desc_cemp_run(C.byref(prob.c), ptr(b, F64P), b.shape[0], int(max_iter), int(nsample), int(seed), device, ptr(S, F64P),
+                              C.byref(ms)))
+    return S[:prob.m], ms.value
 
 
-def refine_run(prob: ProblemArrays, s_vec, R_init, stop_threshold=1e-3, max_iters=100, device=0, verbose=False):
-    """desc_refine_run -> (R (3,3,n), info)."""
-    n = prob.c.n
+def refine_run(prob, s_vec, R_init, stop_threshold=1e-3, max_iters=100, device=0, verbose=False):
+    """desc_refine_run[_dev] -> (R (3,3,n), info)."""
+    n = prob.n
     S = np.ascontiguousarray(s_vec, dtype=np.float64)
     Ri = np.ascontiguousarray(np.asarray(R_init, dtype=np.float64).reshape(-1, order="F"))
     Ro = np.zeros(9 * max(n, 1))
     info = RefineInfo(); info.verbose = 1 if verbose else 0
     L = load()
-    L.desc_refine_run.argtypes = [C.POINTER(Problem), F64P, F64P, C.c_double, C.c_int32, C.c_int32, F64P, C.POINTER(RefineInfo)]
-    check(L.desc_refine_run(C.byref(prob.c), ptr(S, F64P), ptr(Ri, F64P), stop_threshold, max_iters, device, ptr(Ro, F64P), C.byref(info)))
+    if isinstance(prob, DeviceProblem):
+        check(L.desc_refine_run_dev(prob.handle, ptr(S, F64P), ptr(Ri, F64P), stop_threshold, max_iters, ptr(Ro, F64P), C.byref(info)))
+    else:
+        check(L.desc_refine_run(C.byref(prob.c), ptr(S, F64P), ptr(Ri, F64P), stop_threshold, max_iters, device, ptr(Ro, F64P), C.byref(info)))
     return Ro[:9 * n].reshape((3, 3, n), order="F"), dict(iters=info.iters, cg_iters=info.cg_iters, score=info.score, ms_total=info.ms_total,
                                                         cg_unconverged=info.cg_unconverged, cg_residual=info.cg_residual)
 

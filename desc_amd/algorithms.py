@@ -122,22 +122,26 @@ def make_c_params(params):
     return p, G
 
 
-def DESC_PGD(Ind, RijMat, params, return_info=False):
+def DESC_PGD(Ind, RijMat, params, return_info=False, _marshalled=None):
     """[S_vec] = DESC_PGD(Ind, RijMat, params) -- Algorithms/DESC_PGD.m:14.
 
     Returns the estimated corruption level of every edge (length-m vector in the
     caller's edge order).  With ``return_info`` also a dict with the objective and
-    average-change traces, iteration count, timings and structure sizes."""
+    average-change traces, iteration count, timings and structure sizes.
+    ``_marshalled`` (internal, used by DESC()): (perm, ProblemArrays, DeviceProblem) already prepared."""
     p, G = make_c_params(params)
     if _get(params, "make_plots", False):
         raise NotImplementedError(
             "params.make_plots=true (per-iteration GCW + alignment, DESC_PGD.m:235-239) is outside the "
             "accelerated hot path; run with make_plots=false")
-    n, ii, jj, rij, perm = marshal_edges(Ind, RijMat)
-    m = ii.shape[0]
-    if m == 0:
-        raise ValueError("empty edge list")
-    prob = _lib.ProblemArrays(n, ii, jj, rij)
+    if _marshalled is None:
+        n, ii, jj, rij, perm = marshal_edges(Ind, RijMat)
+        if ii.shape[0] == 0:
+            raise ValueError("empty edge list")
+        prob = _lib.ProblemArrays(n, ii, jj, rij)
+        dprob = prob
+    else:
+        perm, prob, dprob = _marshalled
     verbose = bool(p.verbose)
     try:
         st = _lib.Structure.build(prob, p.n_sample_min, p.seed, p.build_where, p.device)
@@ -149,7 +153,7 @@ def DESC_PGD(Ind, RijMat, params, return_info=False):
     try:
         sizes = st.sizes()                    # O(1): the structure stays on the device
         ms_structure = sizes.pop("ms_build")
-        solver = _lib.Solver(prob, st, p.device)
+        solver = _lib.Solver(dprob, st, p.device)
     finally:
         st.free()
     try:
@@ -233,18 +237,24 @@ def DESC(Ind, RijMat, params, return_info=False):
     """[R_est, R_init, S_vec] = DESC(Ind, RijMat, params) -- Algorithms/DESC.m:14 (the call of
     Demo/compare_algorithms.m:72): DESC_PGD (:16-261) -> GCW initialisation (:263) -> reweighted
     Lie-algebraic refinement (:265-313).  All three stages run on the GPU."""
-    S_vec, info = DESC_PGD(Ind, RijMat, params, return_info=True)
     n, ii, jj, rij, perm = marshal_edges(Ind, RijMat)
-    S_sorted = S_vec if perm is None else S_vec[perm]
+    if ii.shape[0] == 0:
+        raise ValueError("empty edge list")
     prob = _lib.ProblemArrays(n, ii, jj, rij)
     device = int(_get(params, "device", 0))
-    R_init, ginfo = _lib.spectral_run(prob, 1.0 / (S_sorted ** 1.5 + 1e-8), True, device=device)     # GCW.m:20
-    verbose = bool(_get(params, "verbose", True))
-    if verbose:
-        print("Rotation Initialized!"); print("Start DESC refinement ...")                    # DESC.m:283-284
-    R_est, rinfo = _lib.refine_run(prob, S_sorted, R_init, device=device, verbose=verbose)
-    if verbose:
-        print("DONE!")                                                                        # DESC.m:313
+    dprob = _lib.DeviceProblem(prob, device)          # Ind / RijMat / CSR index go to HBM once for all three stages
+    try:
+        S_vec, info = DESC_PGD(Ind, RijMat, params, return_info=True, _marshalled=(perm, prob, dprob))
+        S_sorted = S_vec if perm is None else S_vec[perm]
+        R_init, ginfo = _lib.spectral_run(dprob, 1.0 / (S_sorted ** 1.5 + 1e-8), True)                # GCW.m:20
+        verbose = bool(_get(params, "verbose", True))
+        if verbose:
+            print("Rotation Initialized!"); print("Start DESC refinement ...")                # DESC.m:283-284
+        R_est, rinfo = _lib.refine_run(dprob, S_sorted, R_init, verbose=verbose)
+        if verbose:
+            print("DONE!")                                                                    # DESC.m:313
+    finally:
+        dprob.free()
     if return_info:
         return R_est, R_init, S_vec, dict(pgd=info, gcw=ginfo, refine=rinfo)
     return R_est, R_init, S_vec

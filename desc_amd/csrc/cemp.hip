@@ -125,23 +125,33 @@ using namespace desc;
 extern "C" int desc_cemp_run(const desc_problem* prob, const double* beta, int32_t n_beta, int32_t max_iter, int32_t nsample,
                              uint64_t seed, int32_t device, double* s_vec, double* ms_total) {
     if (!prob || !s_vec || !beta) return fail(DESC_ERR_INVALID, "NULL argument");
-    if (n_beta < 1 || max_iter < 0 || nsample < 1) return fail(DESC_ERR_INVALID, "need n_beta >= 1, max_iter >= 0, nsample >= 1");
-    int rc = validate_problem(prob, true);
-    if (rc) return rc;
     auto t0 = std::chrono::steady_clock::now();
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DESC_ERR_HIP, "no HIP device visible: CEMP has no CPU fallback");
-    if (device < 0 || device >= ndev) return fail(DESC_ERR_INVALID, "device %d out of range", device);
-    DESC_HIP(hipSetDevice(device));
-    const int64_t m = prob->m;
+    desc_device_problem* dp = nullptr;
+    int rc = desc_problem_upload(prob, device, &dp);
+    if (rc) return rc;
+    rc = desc_cemp_run_dev(dp, beta, n_beta, max_iter, nsample, seed, s_vec, nullptr);
+    desc_problem_free(dp);
+    if (ms_total) *ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+extern "C" int desc_cemp_run_dev(const desc_device_problem* dp, const double* beta, int32_t n_beta, int32_t max_iter, int32_t nsample,
+                                 uint64_t seed, double* s_vec, double* ms_total) {
+    if (!dp || !s_vec || !beta) return fail(DESC_ERR_INVALID, "NULL argument");
+    if (n_beta < 1 || max_iter < 0 || nsample < 1) return fail(DESC_ERR_INVALID, "need n_beta >= 1, max_iter >= 0, nsample >= 1");
+    int rc = DESC_OK;
+    auto t0 = std::chrono::steady_clock::now();
+    DESC_HIP(hipSetDevice(dp->device));
+    const int64_t m = dp->m;
     // samples: on the device; graphs beyond the device sampler's staging budget fall back to the host sampler
     int64_t mp = 0;
     int32_t *d_pos = nullptr, *d_k = nullptr, *d_ejk = nullptr, *d_eki = nullptr;
     struct Owned { int32_t **a, **b, **c, **d; ~Owned() { for (int32_t** q : {a, b, c, d}) if (*q) (void)hipFree(*q); } } owned{&d_pos, &d_k, &d_ejk, &d_eki};
-    rc = build_cemp_samples_device(prob, nsample, seed, device, &mp, &d_pos, &d_k, &d_ejk, &d_eki);
+    rc = build_cemp_samples_device(dp, nsample, seed, &mp, &d_pos, &d_k, &d_ejk, &d_eki);
     if (rc == DESC_ERR_TOO_LARGE) {
         std::vector<int32_t> pos_edge, kk, e_jk, e_ki;
-        if ((rc = build_cemp_samples_host(prob, nsample, seed, pos_edge, kk, e_jk, e_ki))) return rc;
+        const desc_problem hv = host_view(dp);
+        if ((rc = build_cemp_samples_host(&hv, nsample, seed, pos_edge, kk, e_jk, e_ki))) return rc;
         mp = (int64_t)pos_edge.size();
         const int64_t mch = mp * nsample;
         if (mch >= (1ll << 31)) return fail(DESC_ERR_TOO_LARGE, "m_pos * nsample exceeds 2^31");
@@ -156,13 +166,9 @@ extern "C" int desc_cemp_run(const desc_problem* prob, const double* beta, int32
     } else if (rc) return rc;
     const int64_t mc = mp * nsample;
     DevC D;
-    int32_t *d_ii, *d_jj; double *d_rij, *d_S0, *d_S[2];
-    if ((rc = D.alloc(&d_ii, m)) || (rc = D.alloc(&d_jj, m)) || (rc = D.alloc(&d_rij, 9 * m)) || (rc = D.alloc(&d_S0, mc)) ||
-        (rc = D.alloc(&d_S[0], m)) || (rc = D.alloc(&d_S[1], m))) return rc;
+    const int32_t *d_ii = dp->d_ii, *d_jj = dp->d_jj; const double* d_rij = dp->d_rij; double *d_S0, *d_S[2];
+    if ((rc = D.alloc(&d_S0, mc)) || (rc = D.alloc(&d_S[0], m)) || (rc = D.alloc(&d_S[1], m))) return rc;
     if (m) {
-        DESC_HIP(hipMemcpy(d_ii, prob->ind_i, sizeof(int32_t) * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_jj, prob->ind_j, sizeof(int32_t) * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_rij, prob->rij, sizeof(double) * 9 * m, hipMemcpyHostToDevice));
         const int g = (int)std::min<int64_t>(1024, (m + 255) / 256);
         hipLaunchKernelGGL(k_fill1, dim3(g), dim3(256), 0, 0, d_S[0], m, 1.0);     // SVec(~IndPosbin) = 1 (:103)
         hipLaunchKernelGGL(k_fill1, dim3(g), dim3(256), 0, 0, d_S[1], m, 1.0);

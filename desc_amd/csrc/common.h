@@ -57,6 +57,17 @@ struct desc_structure {
     uint64_t seed = 0;
 };
 
+// A problem resident in HBM (desc_problem_upload): edge list, rotations and the CSR index of the undirected graph --
+// what DESC()'s three stages (PGD, GCW, refinement), Spectral and CEMP each used to rebuild and re-upload.
+struct desc_device_problem {
+    int device = 0;
+    int64_t n = 0, m = 0;
+    std::vector<int32_t> ii, jj, rowptr;      // host copies of the index data (O(m) host passes: degrees, validation)
+    int32_t *d_ii = nullptr, *d_jj = nullptr, *d_rowptr = nullptr, *d_adj = nullptr, *d_adj_eid = nullptr;
+    double* d_rij = nullptr;
+    double ms_upload = 0.0;
+};
+
 namespace desc {
 // a-1..a-3 on the host (structure_host.cpp)
 int build_structure_host(const desc_problem* prob, int32_t n_sample_min, uint64_t seed,
@@ -74,8 +85,10 @@ int structure_ensure_host(desc_structure* s);      // copy the per-cycle arrays 
 void structure_free_device(desc_structure* s);
 // CEMP.m:44-65 on the device: nsample cycles per edge-with-cycles, with replacement.  The four arrays are
 // hipMalloc'ed on `device` (caller frees); DESC_ERR_TOO_LARGE when a codegree exceeds the LDS staging budget.
-int build_cemp_samples_device(const desc_problem* prob, int32_t nsample, uint64_t seed, int32_t device, int64_t* m_pos,
+int build_cemp_samples_device(const desc_device_problem* dp, int32_t nsample, uint64_t seed, int64_t* m_pos,
                               int32_t** d_pos, int32_t** d_k, int32_t** d_ejk, int32_t** d_eki);
+// the desc_problem view of a device problem's host index copies (rij = NULL)
+inline desc_problem host_view(const desc_device_problem* dp) { return desc_problem{dp->n, dp->m, dp->ii.data(), dp->jj.data(), nullptr}; }
 int build_cemp_samples_host(const desc_problem* prob, int32_t nsample, uint64_t seed, std::vector<int32_t>& pos_edge,
                             std::vector<int32_t>& kk, std::vector<int32_t>& e_jk, std::vector<int32_t>& e_ki);
 }  // namespace desc

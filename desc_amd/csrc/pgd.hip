@@ -1500,7 +1500,7 @@ int choose_grid(desc_pgd* h) {
 }
 
 // ---------------------------------------------------------------- GATHER setup
-int setup_gather(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
+int setup_gather(desc_pgd* h, const desc_problem* prob, const desc_structure* s, const double* shared_rij) {
     const int64_t m = h->m, mp = h->m_pos, mc = h->m_cycle;
     int rc;
     if ((rc = structure_ensure_host(const_cast<desc_structure*>(s)))) return rc;
@@ -1525,7 +1525,8 @@ int setup_gather(desc_pgd* h, const desc_problem* prob, const desc_structure* s)
     if ((rc = dalloc(h, &d_k, mc))) return rc;
     if ((rc = dalloc(h, &d_ii, m))) return rc;
     if ((rc = dalloc(h, &d_jj, m))) return rc;
-    if ((rc = dalloc(h, &d_rij, 9 * (size_t)m))) return rc;
+    if (shared_rij) d_rij = const_cast<double*>(shared_rij);
+    else if ((rc = dalloc(h, &d_rij, 9 * (size_t)m))) return rc;
     if ((rc = upload(h, h->d_cum, cum32.data(), (size_t)mp + 1))) return rc;
     if ((rc = upload(h, h->d_pos_edge, s->pos_edge.data(), (size_t)mp))) return rc;
     if ((rc = upload(h, h->d_ejk, s->e_jk.data(), (size_t)mc))) return rc;
@@ -1535,7 +1536,7 @@ int setup_gather(desc_pgd* h, const desc_problem* prob, const desc_structure* s)
     if ((rc = upload(h, d_k, s->k.data(), (size_t)mc))) return rc;
     if ((rc = upload(h, d_ii, prob->ind_i, (size_t)m))) return rc;
     if ((rc = upload(h, d_jj, prob->ind_j, (size_t)m))) return rc;
-    if ((rc = upload(h, d_rij, prob->rij, 9 * (size_t)m))) return rc;
+    if (!shared_rij && (rc = upload(h, d_rij, prob->rij, 9 * (size_t)m))) return rc;
     DESC_HIP(hipStreamSynchronize(h->stream));
     h->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
@@ -1553,7 +1554,7 @@ int setup_gather(desc_pgd* h, const desc_problem* prob, const desc_structure* s)
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     h->ms_cycle_d = ms;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    dfree(h, d_k); dfree(h, d_ii); dfree(h, d_jj); dfree(h, d_rij);
+    dfree(h, d_k); dfree(h, d_ii); dfree(h, d_jj); if (!shared_rij) dfree(h, d_rij);
     if (e != hipSuccess) return fail(DESC_ERR_HIP, "k_cycle_d: %s", hipGetErrorString(e));
     return DESC_OK;
 }
@@ -1640,7 +1641,7 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
     return DESC_OK;
 }
 
-int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
+int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, const double* shared_rij) {
     const int64_t n = h->n, m = h->m, mp = h->m_pos;
     auto t0 = std::chrono::steady_clock::now();
     auto t_lap = t0;
@@ -1902,14 +1903,15 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
         if ((rc = dalloc(h, &d_kf, mcl))) return rc;
     }
     if ((rc = dalloc(h, &d_pos_edge2, mp))) return rc;
-    if ((rc = dalloc(h, &d_rij, 9 * (size_t)m))) return rc;
+    if (shared_rij) d_rij = const_cast<double*>(shared_rij);          // the device problem's copy: no 72-B-per-edge upload
+    else if ((rc = dalloc(h, &d_rij, 9 * (size_t)m))) return rc;
     std::vector<int32_t> rank_seg32(h->rank_seg.begin(), h->rank_seg.end());
     if ((rc = upload(h, h->d_cum, cum_loc.data(), (size_t)mp + 1))) return rc;
     if ((rc = upload(h, h->d_src_start, src_start.data(), (size_t)mp))) return rc;
     if ((rc = upload(h, h->d_chunk_desc, chunk_desc.data(), chunk_desc.size()))) return rc;
     if ((rc = upload(h, h->d_rank_seg, rank_seg32.data(), rank_seg32.size()))) return rc;
     if ((rc = upload(h, d_pos_edge2, pos_edge2.data(), (size_t)mp))) return rc;
-    if ((rc = upload(h, d_rij, prob->rij, 9 * (size_t)m))) return rc;
+    if (!shared_rij && (rc = upload(h, d_rij, prob->rij, 9 * (size_t)m))) return rc;
     if (h->band_ok) {
         if ((rc = upload(h, h->d_pieces, pieces.data(), pieces.size()))) return rc;
         if ((rc = upload(h, h->d_piece_ptr, piece_ptr.data(), piece_ptr.size()))) return rc;
@@ -2008,7 +2010,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s) {
     lap("layout kernels");
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (!dev_cycles) { dfree(h, d_ii); dfree(h, d_jj); dfree(h, d_adj); dfree(h, d_adj_eid); dfree(h, d_kf); }
-    dfree(h, d_pos_edge2); dfree(h, d_rij);
+    dfree(h, d_pos_edge2); if (!shared_rij) dfree(h, d_rij);
     if (e != hipSuccess) return fail(DESC_ERR_HIP, "k_layout_node: %s", hipGetErrorString(e));
     return DESC_OK;
 }
@@ -2051,14 +2053,27 @@ int desc_pgd_create(const desc_problem* prob, const desc_structure* s, int32_t d
     return desc_pgd_create_shard(prob, s, device, 0, 1, out);
 }
 
+static int create_impl(const desc_problem* prob, const double* shared_rij, const desc_structure* s, int32_t device, int32_t rank, int32_t world, desc_pgd** out);
+
 int desc_pgd_create_shard(const desc_problem* prob, const desc_structure* s, int32_t device, int32_t rank, int32_t world,
                           desc_pgd** out) {
+    return create_impl(prob, nullptr, s, device, rank, world, out);
+}
+// the same with the problem already resident in HBM (desc_problem_upload): nothing but O(m_pos) plan tables is uploaded
+int desc_pgd_create_dev(const desc_device_problem* dp, const desc_structure* s, int32_t rank, int32_t world, desc_pgd** out) {
+    if (!dp) return fail(DESC_ERR_INVALID, "NULL argument");
+    const desc_problem hv = host_view(dp);
+    return create_impl(&hv, dp->d_rij, s, dp->device, rank, world, out);
+}
+
+static int create_impl(const desc_problem* prob, const double* shared_rij, const desc_structure* s, int32_t device, int32_t rank, int32_t world,
+                       desc_pgd** out) {
     if (!out) return fail(DESC_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!prob || !s) return fail(DESC_ERR_INVALID, "NULL argument");
     if (world < 1 || rank < 0 || rank >= world) return fail(DESC_ERR_INVALID, "rank %d / world %d", rank, world);
     if (prob->m != s->m) return fail(DESC_ERR_INVALID, "structure was built for m = %lld, problem has m = %lld", (long long)s->m, (long long)prob->m);
-    if (prob->m > 0 && !prob->rij) return fail(DESC_ERR_INVALID, "rij is NULL");
+    if (prob->m > 0 && !prob->rij && !shared_rij) return fail(DESC_ERR_INVALID, "rij is NULL");
     if (prob->n < s->n) return fail(DESC_ERR_INVALID, "problem n smaller than structure n");
     int ndev = desc_device_count();
     if (ndev < 0) return ndev;
@@ -2101,7 +2116,7 @@ int desc_pgd_create_shard(const desc_problem* prob, const desc_structure* s, int
         rc = upload(h, h->d_nv, nv.data(), nv.size());
         if (!rc) { hipError_t e = hipStreamSynchronize(h->stream); if (e != hipSuccess) rc = fail(DESC_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
     }
-    if (!rc) rc = (h->variant == VARIANT_NODE) ? setup_node(h, prob, s) : setup_gather(h, prob, s);
+    if (!rc) rc = (h->variant == VARIANT_NODE) ? setup_node(h, prob, s, shared_rij) : setup_gather(h, prob, s, shared_rij);
     if (!rc) rc = dalloc(h, &h->d_partials, 2 * (size_t)std::max(std::max(h->grid, h->obj_grid), h->band_grid));
     if (rc) { free_all(h); return rc; }
     *out = h;
@@ -2374,10 +2389,16 @@ int desc_pgd_shard_bind(desc_pgd* h, double* T_send, double* T_recv, double* sal
 
 namespace {
 // the pieces of one sharded iteration, each enqueued on the stream given
+// One rank and nothing forcing the exchange layout: the column sums stay in CSR order (coalesced row writes) exactly as in
+// the unsharded path.  With more ranks every rank writes all 2m slots of the owner-sorted layout, 8 bytes at a time
+// (measured at C4: +74 us on the column-sum pass, independent of the number of ranks).
+bool shard_direct(const desc_pgd* h) { return h->world == 1 && !h->force_coll && h->comm_stream != nullptr; }
 int shard_enqueue_colsum(desc_pgd* h, hipStream_t st) {
     const int rd = h->t_done & 1;
+    const bool direct = shard_direct(h);
     hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 2 * sizeof(int)), st,
-                       h->d_rowptr, h->d_adj_seg, h->d_pk, h->d_w[rd], h->x_T, (int)h->n, h->colsum_stride, h->d_state, h->d_xpos, FinArgs{});
+                       h->d_rowptr, h->d_adj_seg, h->d_pk, h->d_w[rd], direct ? h->d_T : h->x_T, (int)h->n, h->colsum_stride, h->d_state,
+                       direct ? (const int32_t*)nullptr : h->d_xpos, FinArgs{});
     DESC_HIP(hipGetLastError());
     return DESC_OK;
 }
@@ -2391,6 +2412,7 @@ int shard_enqueue_sweep(desc_pgd* h, hipStream_t st) {
     a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
     a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_Trecv; a.t_seg_lo = (int32_t)h->seg_lo; a.nv_tab = h->d_nv;
     a.s_slice = my_slice(h); a.partials = my_slice(h) + h->slice_S;       // S and the workgroup partials go straight into the slice
+    if (shard_direct(h)) { a.Tfull = h->d_T; a.t_seg_lo = -1; a.s_slice = nullptr; }
     a.state = h->d_state; a.st = sa; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks;
     a.max_cnt = h->max_cnt; a.ablate = 0;
     const hipStream_t keep = h->stream; h->stream = st;

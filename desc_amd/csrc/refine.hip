@@ -257,54 +257,62 @@ struct DevR {
 
 using namespace desc;
 
+// Build_Amatrix.m:10: -1 at the smaller endpoint i, +1 at j -- per CSR slot
+__global__ void k_incidence_sign(const int32_t* rowptr, const int32_t* adj, int8_t* sgn, int n) {
+    const int l16 = threadIdx.x & 15;
+    const int row0 = (blockIdx.x * 256 + threadIdx.x) >> 4, nrows = (gridDim.x * 256) >> 4;
+    for (int v = row0; v < n; v += nrows)
+        for (int t = rowptr[v] + l16; t < rowptr[v + 1]; t += 16) sgn[t] = v < adj[t] ? -1 : +1;
+}
+
 extern "C" int desc_refine_run(const desc_problem* prob, const double* s_vec, const double* R_init, double stop_threshold,
                                int32_t max_iters, int32_t device, double* R_out, desc_refine_info* info) {
     if (!prob || !s_vec || !R_init || !R_out) return fail(DESC_ERR_INVALID, "NULL argument");
-    int rc = validate_problem(prob, true);
+    if (prob->n == 0) return validate_problem(prob, true);
+    auto t0 = std::chrono::steady_clock::now();
+    desc_device_problem* dp = nullptr;
+    int rc = desc_problem_upload(prob, device, &dp);
     if (rc) return rc;
-    const int64_t n = prob->n, m = prob->m;
+    rc = desc_refine_run_dev(dp, s_vec, R_init, stop_threshold, max_iters, R_out, info);
+    desc_problem_free(dp);
+    if (!rc && info) info->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+extern "C" int desc_refine_run_dev(const desc_device_problem* dp, const double* s_vec, const double* R_init, double stop_threshold,
+                                   int32_t max_iters, double* R_out, desc_refine_info* info) {
+    if (!dp || !s_vec || !R_init || !R_out) return fail(DESC_ERR_INVALID, "NULL argument");
+    int rc = DESC_OK;
+    const int64_t n = dp->n, m = dp->m;
     if (n == 0) return DESC_OK;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DESC_ERR_HIP, "no HIP device visible: the refinement has no CPU fallback");
-    if (device < 0 || device >= ndev) return fail(DESC_ERR_INVALID, "device %d out of range", device);
-    DESC_HIP(hipSetDevice(device));
+    DESC_HIP(hipSetDevice(dp->device));
     auto t0 = std::chrono::steady_clock::now();
     if (stop_threshold <= 0) stop_threshold = 1e-3;      // DESC.m:272
     if (max_iters <= 0) max_iters = 100;
     const double weight_max = 1e4, weight_min = 1e-4;    // DESC.m:280-281
 
-    // CSR with edge ids and incidence signs
-    std::vector<int32_t> rowptr, adj, eid;
-    build_csr(n, m, prob->ind_i, prob->ind_j, rowptr, adj, eid);
-    std::vector<int8_t> sgn((size_t)2 * m);
-    for (int64_t v = 0; v < n; ++v)                      // Build_Amatrix.m:10: -1 at the smaller endpoint i, +1 at j
-        for (int32_t t = rowptr[v]; t < rowptr[v + 1]; ++t) sgn[t] = v < adj[t] ? -1 : +1;
     // initial weights (DESC.m:274-282): quantile(S_vec, 1) = max -> nothing is truncated yet; evaluated on
     // the device by the same kernel as the re-weighting steps
     double thresh0 = -INFINITY;
     for (int64_t e = 0; e < m; ++e) thresh0 = std::max(thresh0, s_vec[e]);
     DevR D;
-    int32_t *d_rowptr, *d_adj, *d_eid, *d_ii, *d_jj; int8_t* d_sgn;
-    double *d_rij, *d_Rinit, *d_w, *d_S, *d_B, *d_RS, *d_rhs, *d_diag, *d_x, *d_r, *d_z, *d_p, *d_q, *d_Wv, *d_score, *d_Rout;
+    const int32_t *d_rowptr = dp->d_rowptr, *d_adj = dp->d_adj, *d_eid = dp->d_adj_eid, *d_ii = dp->d_ii, *d_jj = dp->d_jj;
+    const double* d_rij = dp->d_rij;
+    int8_t* d_sgn;
+    double *d_Rinit, *d_w, *d_S, *d_B, *d_RS, *d_rhs, *d_diag, *d_x, *d_r, *d_z, *d_p, *d_q, *d_Wv, *d_score, *d_Rout;
     Quat *d_Q, *d_QQ; CgScal* d_sc;
     const int sgrid = 64;
-    if ((rc = D.alloc(&d_rowptr, n + 1)) || (rc = D.alloc(&d_adj, 2 * m)) || (rc = D.alloc(&d_eid, 2 * m)) || (rc = D.alloc(&d_sgn, 2 * m)) ||
-        (rc = D.alloc(&d_ii, m)) || (rc = D.alloc(&d_jj, m)) || (rc = D.alloc(&d_rij, 9 * m)) || (rc = D.alloc(&d_Rinit, 9 * n)) ||
+    if ((rc = D.alloc(&d_sgn, 2 * m)) || (rc = D.alloc(&d_Rinit, 9 * n)) ||
         (rc = D.alloc(&d_w, m)) || (rc = D.alloc(&d_S, m)) || (rc = D.alloc(&d_B, 3 * m)) || (rc = D.alloc(&d_RS, m)) ||
         (rc = D.alloc(&d_rhs, 3 * n)) || (rc = D.alloc(&d_diag, n)) || (rc = D.alloc(&d_x, 3 * n)) || (rc = D.alloc(&d_r, 3 * n)) ||
         (rc = D.alloc(&d_z, 3 * n)) || (rc = D.alloc(&d_p, 3 * n)) || (rc = D.alloc(&d_q, 3 * n)) || (rc = D.alloc(&d_Wv, 3 * n)) ||
         (rc = D.alloc(&d_score, sgrid)) || (rc = D.alloc(&d_Rout, 9 * n)) || (rc = D.alloc(&d_Q, n)) || (rc = D.alloc(&d_QQ, m)) ||
         (rc = D.alloc(&d_sc, 1))) return rc;
-    DESC_HIP(hipMemcpy(d_rowptr, rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
     DESC_HIP(hipMemcpy(d_Rinit, R_init, sizeof(double) * 9 * n, hipMemcpyHostToDevice));
     if (m) {
-        DESC_HIP(hipMemcpy(d_adj, adj.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_eid, eid.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_sgn, sgn.data(), sizeof(int8_t) * 2 * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_ii, prob->ind_i, sizeof(int32_t) * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_jj, prob->ind_j, sizeof(int32_t) * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_rij, prob->rij, sizeof(double) * 9 * m, hipMemcpyHostToDevice));
         DESC_HIP(hipMemcpy(d_S, s_vec, sizeof(double) * m, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_incidence_sign, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256))), dim3(256), 0, 0,
+                           d_rowptr, d_adj, d_sgn, (int)n);
     }
     const int egrid = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (m + 255) / 256));
     if (m) hipLaunchKernelGGL(k_weights, dim3(egrid), dim3(256), 0, 0, d_S, d_w, m, thresh0, weight_max, weight_min);

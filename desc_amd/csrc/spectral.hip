@@ -244,26 +244,35 @@ using namespace desc;
 extern "C" int desc_spectral_run(const desc_problem* prob, const double* weights, int32_t normalize_rows, double tol,
                                  int32_t max_iters, int32_t device, double* R_out, desc_spectral_info* info) {
     if (!prob || !R_out) return fail(DESC_ERR_INVALID, "NULL argument");
-    int rc = validate_problem(prob, true);
+    if (prob->n == 0) return validate_problem(prob, true);
+    auto t0 = std::chrono::steady_clock::now();
+    desc_device_problem* dp = nullptr;
+    int rc = desc_problem_upload(prob, device, &dp);
     if (rc) return rc;
-    const int64_t n = prob->n, m = prob->m;
+    rc = desc_spectral_run_dev(dp, weights, normalize_rows, tol, max_iters, R_out, info);
+    desc_problem_free(dp);
+    if (!rc && info) info->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+extern "C" int desc_spectral_run_dev(const desc_device_problem* dp, const double* weights, int32_t normalize_rows, double tol,
+                                     int32_t max_iters, double* R_out, desc_spectral_info* info) {
+    if (!dp || !R_out) return fail(DESC_ERR_INVALID, "NULL argument");
+    int rc = DESC_OK;
+    const int64_t n = dp->n, m = dp->m;
     if (n == 0) return DESC_OK;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DESC_ERR_HIP, "no HIP device visible: the eigen-solve has no CPU fallback");
-    if (device < 0 || device >= ndev) return fail(DESC_ERR_INVALID, "device %d out of range", device);
-    DESC_HIP(hipSetDevice(device));
+    DESC_HIP(hipSetDevice(dp->device));
     auto t0 = std::chrono::steady_clock::now();
     if (tol <= 0) tol = 1e-13;
     if (max_iters <= 0) max_iters = 500;
 
-    // block CSR: every edge in both endpoint rows (index part on the host, the 2m blocks are assembled on the device)
-    std::vector<int32_t> rowptr, adj, adj_eid;             // (i,j) slot = R, (j,i) slot = R'
-    build_csr(n, m, prob->ind_i, prob->ind_j, rowptr, adj, adj_eid);
+    // block CSR: every edge in both endpoint rows; the index part lives with the device problem, the 2m blocks are
+    // assembled on the device ((i,j) slot = R, (j,i) slot = R')
     std::vector<double> deg((size_t)n, 0.0);
     for (int64_t e = 0; e < m; ++e) {
         const double w = weights ? weights[e] : 1.0;
         if (!(w >= 0) || !std::isfinite(w)) return fail(DESC_ERR_INVALID, "weight %lld is not a finite non-negative number", (long long)e);
-        deg[prob->ind_i[e]] += w; deg[prob->ind_j[e]] += w;
+        deg[dp->ii[e]] += w; deg[dp->jj[e]] += w;
     }
     double sigma = 0.0;
     std::vector<double> dinv((size_t)n, 1.0);               // D^-1/2
@@ -279,18 +288,14 @@ extern "C" int desc_spectral_run(const desc_problem* prob, const double* weights
     for (size_t t = 0; t < X0.size(); ++t) X0[t] = (double)(int64_t)(mix64(0xC0FFEEull + t) >> 11) / 4503599627370496.0 - 1.0;
 
     Dev D;
-    int32_t *d_rowptr, *d_adj; double *d_blocks, *d_X, *d_Y, *d_part;
+    const int32_t *d_rowptr = dp->d_rowptr, *d_adj = dp->d_adj; double *d_blocks, *d_X, *d_Y, *d_part;
     const int ggrid = 256;
-    if ((rc = D.alloc(&d_rowptr, n + 1)) || (rc = D.alloc(&d_adj, 2 * m)) || (rc = D.alloc(&d_blocks, 18 * m)) ||
+    if ((rc = D.alloc(&d_blocks, 18 * m)) ||
         (rc = D.alloc(&d_X, rows * BW)) || (rc = D.alloc(&d_Y, rows * BW)) || (rc = D.alloc(&d_part, (size_t)ggrid * 2 * BW * BW))) return rc;
-    DESC_HIP(hipMemcpy(d_rowptr, rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
     if (m) {
         Dev T;                                               // assembly inputs, released before the iteration starts
-        int32_t* d_eid; double *d_rij, *d_w = nullptr, *d_dinv;
-        if ((rc = T.alloc(&d_eid, 2 * m)) || (rc = T.alloc(&d_rij, 9 * m)) || (rc = T.alloc(&d_dinv, n)) || (weights && (rc = T.alloc(&d_w, m)))) return rc;
-        DESC_HIP(hipMemcpy(d_adj, adj.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_eid, adj_eid.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_rij, prob->rij, sizeof(double) * 9 * m, hipMemcpyHostToDevice));
+        const int32_t* d_eid = dp->d_adj_eid; const double* d_rij = dp->d_rij; double *d_w = nullptr, *d_dinv;
+        if ((rc = T.alloc(&d_dinv, n)) || (weights && (rc = T.alloc(&d_w, m)))) return rc;
         DESC_HIP(hipMemcpy(d_dinv, dinv.data(), sizeof(double) * n, hipMemcpyHostToDevice));
         if (weights) DESC_HIP(hipMemcpy(d_w, weights, sizeof(double) * m, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_assemble_blocks, dim3((unsigned)std::min<int64_t>(4096, (n + 3) / 4)), dim3(256), 0, 0, d_rowptr, d_adj, d_eid, d_rij, d_w,

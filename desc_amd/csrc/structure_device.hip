@@ -422,29 +422,20 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
     return DESC_OK;
 }
 
-int build_cemp_samples_device(const desc_problem* prob, int32_t nsample, uint64_t seed, int32_t device, int64_t* m_pos,
+int build_cemp_samples_device(const desc_device_problem* dp, int32_t nsample, uint64_t seed, int64_t* m_pos,
                               int32_t** o_pos, int32_t** o_k, int32_t** o_ejk, int32_t** o_eki) {
-    const int64_t n = prob->n, m = prob->m;
+    const int64_t n = dp->n, m = dp->m;
     const int64_t words = (n + 63) / 64;
     *m_pos = 0; *o_pos = *o_k = *o_ejk = *o_eki = nullptr;
     if ((double)n * (double)words * 12.0 > 64.0 * 1073741824.0) return fail(DESC_ERR_TOO_LARGE, "adjacency bitmaps do not fit the device budget");
-    DESC_HIP(hipSetDevice(device));
-    std::vector<int32_t> rowptr, adj, adj_eid;
-    build_csr(n, m, prob->ind_i, prob->ind_j, rowptr, adj, adj_eid);
+    DESC_HIP(hipSetDevice(dp->device));
     DevBuf D;
     int rc;
-    int32_t *d_rowptr, *d_adj, *d_adj_eid, *d_ii, *d_jj, *d_codeg, *d_hist;
+    const int32_t *d_rowptr = dp->d_rowptr, *d_adj = dp->d_adj, *d_adj_eid = dp->d_adj_eid, *d_ii = dp->d_ii, *d_jj = dp->d_jj;   // CSR index: the device problem's
+    int32_t *d_codeg, *d_hist;
     unsigned long long* d_bits; uint32_t* d_rank;
-    if ((rc = D.alloc(&d_rowptr, n + 1)) || (rc = D.alloc(&d_adj, 2 * m)) || (rc = D.alloc(&d_adj_eid, 2 * m)) || (rc = D.alloc(&d_ii, m)) ||
-        (rc = D.alloc(&d_jj, m)) || (rc = D.alloc(&d_codeg, m)) || (rc = D.alloc(&d_hist, n + 1)) ||
+    if ((rc = D.alloc(&d_codeg, m)) || (rc = D.alloc(&d_hist, n + 1)) ||
         (rc = D.alloc(&d_bits, (size_t)n * words)) || (rc = D.alloc(&d_rank, (size_t)n * words))) return rc;
-    DESC_HIP(hipMemcpy(d_rowptr, rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
-    if (m) {
-        DESC_HIP(hipMemcpy(d_adj, adj.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_adj_eid, adj_eid.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_ii, prob->ind_i, sizeof(int32_t) * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(d_jj, prob->ind_j, sizeof(int32_t) * m, hipMemcpyHostToDevice));
-    }
     DESC_HIP(hipMemset(d_bits, 0, sizeof(unsigned long long) * (size_t)n * words));
     DESC_HIP(hipMemset(d_hist, 0, sizeof(int32_t) * (n + 1)));
     if (n > 0) {

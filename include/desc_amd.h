@@ -58,6 +58,14 @@ typedef struct desc_problem {
     const double* rij;      /* m*9, may be NULL for structure-only calls  DESC_PGD.m:7 */
 } desc_problem;
 
+/* A problem resident in the HBM of `device`: edge list, rotations and the CSR index of the graph.  DESC()'s three stages
+ * (DESC_PGD -> GCW -> refinement, Algorithms/DESC.m:16-313) and the stand-alone Spectral / CEMP all read the same Ind /
+ * RijMat; uploading them once removes two of three 72-B-per-edge host->device copies and CSR passes of a DESC() call.
+ * The *_dev entry points below take it in place of a desc_problem.  The caller may free its host arrays afterwards. */
+typedef struct desc_device_problem desc_device_problem;   /* opaque, library-owned */
+int desc_problem_upload(const desc_problem* prob, int32_t device, desc_device_problem** out);
+void desc_problem_free(desc_device_problem* dp);
+
 /* -------------------------------------------------------------- structure -- */
 /* The sampled 3-cycle structure of DESC_PGD.m:29-127, sparse.  Cycle c of the
  * l-th edge-with-cycles (edge id pos_edge[l] = (i,j)) lives at
@@ -165,6 +173,8 @@ typedef struct desc_pgd desc_pgd;   /* opaque solver handle: one per (problem, d
  * S0_long (DESC_PGD.m:129-147).  The structure may be freed afterwards. */
 int desc_pgd_create(const desc_problem* prob, const desc_structure* s, int32_t device,
                     desc_pgd** out);
+/* the same for a problem already resident in HBM (same device); rank 0 of world 1 = the whole problem */
+int desc_pgd_create_dev(const desc_device_problem* dp, const desc_structure* s, int32_t rank, int32_t world, desc_pgd** out);
 void desc_pgd_destroy(desc_pgd* h);
 /* Full run: init (DESC_PGD.m:148-167) + loop (:182-261) + download. */
 int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r);
@@ -260,6 +270,8 @@ typedef struct desc_spectral_info {
 } desc_spectral_info;
 int desc_spectral_run(const desc_problem* prob, const double* weights, int32_t normalize_rows, double tol,
                       int32_t max_iters, int32_t device, double* R_out, desc_spectral_info* info);
+int desc_spectral_run_dev(const desc_device_problem* dp, const double* weights, int32_t normalize_rows, double tol,
+                          int32_t max_iters, double* R_out, desc_spectral_info* info);
 
 /* ------------------------------------------------------------ CEMP (next row f-2) -- */
 /* SVec = CEMP(Ind, RijMat, CEMP_parameters) -- Algorithms/CEMP.m:24-132.  beta[0..n_beta-1] =
@@ -268,6 +280,8 @@ int desc_spectral_run(const desc_problem* prob, const double* weights, int32_t n
  * RNG is replaced by CoInd[desc_sample_key(seed, edge, t) mod codeg]).  s_vec: m doubles out. */
 int desc_cemp_run(const desc_problem* prob, const double* beta, int32_t n_beta, int32_t max_iter, int32_t nsample,
                   uint64_t seed, int32_t device, double* s_vec, double* ms_total);
+int desc_cemp_run_dev(const desc_device_problem* dp, const double* beta, int32_t n_beta, int32_t max_iter, int32_t nsample,
+                      uint64_t seed, double* s_vec, double* ms_total);
 
 /* ----------------------------------------- DESC refinement tail (next row f-3) -- */
 /* Reweighted Lie-algebraic averaging, Algorithms/DESC.m:265-313 with Utils/Weighted_LAA.m,
@@ -288,6 +302,8 @@ typedef struct desc_refine_info {
 } desc_refine_info;
 int desc_refine_run(const desc_problem* prob, const double* s_vec, const double* R_init, double stop_threshold,
                     int32_t max_iters, int32_t device, double* R_out, desc_refine_info* info);
+int desc_refine_run_dev(const desc_device_problem* dp, const double* s_vec, const double* R_init, double stop_threshold,
+                        int32_t max_iters, double* R_out, desc_refine_info* info);
 
 /* One-shot: what the MEX shim calls.  Builds the structure (p->build_where),
  * uploads, runs, downloads, frees. */

@@ -55,3 +55,23 @@ t0 = time.perf_counter()
 Sc, ms = _lib.cemp_run(prob, beta, len(beta), 50)
 out["cemp"] = dict(ms_wall=(time.perf_counter() - t0) * 1e3, ms_lib=ms, rounds=len(beta), nsample=50, mean_abs_err_s=float(np.mean(np.abs(Sc - mo.ErrVec))))
 print(json.dumps(out))
+
+# ---- the same stages on one device-resident problem (desc_problem_upload): what DESC() does since round 2
+from desc_amd import DESC, DESC_PGD, ConstantStepSize
+t0 = time.perf_counter()
+dp = _lib.DeviceProblem(prob, 0)
+t_up = time.perf_counter() - t0
+res = {"upload_ms": t_up * 1e3}
+t0 = time.perf_counter(); Rg2, gi = _lib.spectral_run(dp, weights=1.0 / (S ** 1.5 + 1e-8), normalize_rows=True); res["gcw_ms"] = (time.perf_counter() - t0) * 1e3
+t0 = time.perf_counter(); Rr2, ri = _lib.refine_run(dp, S, Rg2); res["refine_ms"] = (time.perf_counter() - t0) * 1e3
+t0 = time.perf_counter(); Rs2, si = _lib.spectral_run(dp); res["spectral_ms"] = (time.perf_counter() - t0) * 1e3
+t0 = time.perf_counter(); Sc2, _ = _lib.cemp_run(dp, beta, len(beta), 50); res["cemp_ms"] = (time.perf_counter() - t0) * 1e3
+res["same_results"] = bool(np.array_equal(Rg2, Rg) and np.array_equal(Rr2, Rr) and np.array_equal(Sc2, Sc))
+dp.free()
+params = dict(iters=100, learning_rate=0.01, make_plots=False, Gradient=ConstantStepSize(0.01), verbose=False)
+t0 = time.perf_counter(); Sp = DESC_PGD(mo.Ind, mo.RijMat, params); res["DESC_PGD_wrapper_ms"] = (time.perf_counter() - t0) * 1e3
+t0 = time.perf_counter(); Re, Ri, Sv = DESC(mo.Ind, mo.RijMat, params); res["DESC_wrapper_ms"] = (time.perf_counter() - t0) * 1e3
+res["DESC_minus_DESC_PGD_ms"] = res["DESC_wrapper_ms"] - res["DESC_PGD_wrapper_ms"]
+res["desc_pgd_solve_ms"] = out["desc_pgd_solve"]["ms_wall"]
+res["DESC_rot_err"] = rot_err(Re)
+print(json.dumps({"device_resident_problem": res}))
