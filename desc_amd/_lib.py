@@ -20,7 +20,7 @@ BUILD_HOST, BUILD_DEVICE = 0, 1
 # every symbol include/desc_amd.h declares (tests check that the library exports them)
 EXPORTS = [
     "desc_last_error", "desc_version", "desc_device_count", "desc_problem_upload", "desc_problem_free",
-    "desc_spectral_run_dev", "desc_cemp_run_dev", "desc_refine_run_dev", "desc_pgd_create_dev",
+    "desc_spectral_run_dev", "desc_gcw_run_dev", "desc_cemp_run_dev", "desc_refine_run_dev", "desc_pgd_create_dev",
     "desc_structure_build", "desc_structure_import", "desc_structure_get", "desc_structure_sizes",
     "desc_structure_host_exports", "desc_structure_free",
     "desc_sample_key", "desc_params_default",
@@ -174,6 +174,7 @@ def load():
     L.desc_problem_free.argtypes = [C.c_void_p]
     L.desc_problem_free.restype = None
     L.desc_spectral_run_dev.argtypes = [C.c_void_p, F64P, C.c_int32, C.c_double, C.c_int32, F64P, C.POINTER(SpectralInfo)]
+    L.desc_gcw_run_dev.argtypes = [C.c_void_p, F64P, C.c_double, C.c_int32, F64P, C.POINTER(SpectralInfo)]
     L.desc_cemp_run_dev.argtypes = [C.c_void_p, F64P, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, F64P, C.POINTER(C.c_double)]
     L.desc_refine_run_dev.argtypes = [C.c_void_p, F64P, F64P, C.c_double, C.c_int32, F64P, C.POINTER(RefineInfo)]
     L.desc_pgd_create_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
@@ -447,6 +448,17 @@ def spectral_run(prob, weights=None, normalize_rows=False, tol=1e-13, max_iters=
     else:
         check(load().desc_spectral_run(C.byref(prob.c), ptr(w, F64P), 1 if normalize_rows else 0, tol, max_iters, device,
                                        ptr(R, F64P), C.byref(info)))
+    return R[:9 * n].reshape((3, 3, n), order="F"), dict(iters=info.iters, products=info.products, converged=bool(info.converged), residual=info.residual,
+                                                        eigenvalues=list(info.eigenvalues), ms_total=info.ms_total)
+
+
+def gcw_run(dprob: DeviceProblem, s_vec, tol=1e-13, max_iters=500):
+    """desc_gcw_run_dev: GCW with the weights formed on the device from S_vec -> (R (3,3,n), info)."""
+    n = dprob.n
+    R = np.zeros(9 * max(n, 1))
+    S = np.ascontiguousarray(s_vec, dtype=np.float64)
+    info = SpectralInfo()
+    check(load().desc_gcw_run_dev(dprob.handle, ptr(S, F64P), tol, max_iters, ptr(R, F64P), C.byref(info)))
     return R[:9 * n].reshape((3, 3, n), order="F"), dict(iters=info.iters, products=info.products, converged=bool(info.converged), residual=info.residual,
                                                         eigenvalues=list(info.eigenvalues), ms_total=info.ms_total)
 

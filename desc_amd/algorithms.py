@@ -209,7 +209,7 @@ def GCW(Ind, AdjMat, RijMat, S_vec, device=0, return_info=False):
         raise ValueError("S_vec must have one entry per edge")
     if perm is not None:
         S = S[perm]
-    w = 1.0 / (S ** 1.5 + 1e-8)                               # GCW.m:20
+    w = 1.0 / (S * np.sqrt(S) + 1e-8)                         # GCW.m:20: SVec.^(1.5) (sqrt form: 5x cheaper than pow; S >= 0)
     prob = _lib.ProblemArrays(n, ii, jj, rij)
     R, info = _lib.spectral_run(prob, w, True, device=device)
     return (R, info) if return_info else R
@@ -246,7 +246,7 @@ def DESC(Ind, RijMat, params, return_info=False):
     try:
         S_vec, info = DESC_PGD(Ind, RijMat, params, return_info=True, _marshalled=(perm, prob, dprob))
         S_sorted = S_vec if perm is None else S_vec[perm]
-        R_init, ginfo = _lib.spectral_run(dprob, 1.0 / (S_sorted ** 1.5 + 1e-8), True)                # GCW.m:20
+        R_init, ginfo = _lib.gcw_run(dprob, S_sorted)                    # GCW.m:9-36, weights (GCW.m:20) formed on the device
         verbose = bool(_get(params, "verbose", True))
         if verbose:
             print("Rotation Initialized!"); print("Start DESC refinement ...")                # DESC.m:283-284

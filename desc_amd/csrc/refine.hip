@@ -226,6 +226,40 @@ __global__ void k_weights(const double* RS, double* wts, int64_t m, double thres
     }
 }
 
+// ---- MATLAB's quantile on the device: a 4096-bin histogram over [lo, hi] locates the two order statistics the Hazen
+// interpolation needs, the values of their bins (a few hundred of m) are collected and ordered on the host.
+constexpr int QBINS = 4096;
+__device__ __forceinline__ int qbin(double x, double lo, double scale) {
+    const int b = (int)((x - lo) * scale);
+    return b < 0 ? 0 : (b >= QBINS ? QBINS - 1 : b);
+}
+__global__ __launch_bounds__(256) void k_minmax(const double* x, int64_t m, double* out /* [grid][2] */) {
+    double lo = INFINITY, hi = -INFINITY;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < m; e += (int64_t)gridDim.x * 256) { lo = fmin(lo, x[e]); hi = fmax(hi, x[e]); }
+    __shared__ double sl[256], sh[256];
+    sl[threadIdx.x] = lo; sh[threadIdx.x] = hi;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) { sl[threadIdx.x] = fmin(sl[threadIdx.x], sl[threadIdx.x + s2]); sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s2]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = sl[0]; out[2 * blockIdx.x + 1] = sh[0]; }
+}
+__global__ __launch_bounds__(256) void k_qhist(const double* x, int64_t m, double lo, double scale, unsigned* hist) {
+    __shared__ unsigned h[QBINS];
+    for (int t = threadIdx.x; t < QBINS; t += 256) h[t] = 0;
+    __syncthreads();
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < m; e += (int64_t)gridDim.x * 256) atomicAdd(&h[qbin(x[e], lo, scale)], 1u);
+    __syncthreads();
+    for (int t = threadIdx.x; t < QBINS; t += 256) if (h[t]) atomicAdd(&hist[t], h[t]);
+}
+__global__ __launch_bounds__(256) void k_qcollect(const double* x, int64_t m, double lo, double scale, int b0, int b1, double* out, unsigned* count, unsigned cap) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < m; e += (int64_t)gridDim.x * 256) {
+        const int b = qbin(x[e], lo, scale);
+        if (b == b0 || b == b1) { const unsigned p = atomicAdd(count, 1u); if (p < cap) out[p] = x[e]; }
+    }
+}
+
 // MATLAB quantile(x, p): Hazen plotting positions (k-0.5)/n, linear interpolation, clamped
 double matlab_quantile(std::vector<double>& x, double p) {
     const size_t n = x.size();
@@ -239,6 +273,52 @@ double matlab_quantile(std::vector<double>& x, double p) {
     const double a = x[lo];
     const double b = *std::min_element(x.begin() + lo + 1, x.end());
     return a + fr * (b - a);
+}
+
+// quantile(x, p) of a device vector, MATLAB's definition (the same order statistics as matlab_quantile above);
+// scratch: d_mm [64][2] doubles, d_hist QBINS unsigned + 1 counter, d_cand cap doubles
+int device_quantile(const double* d_x, int64_t m, double p, double* d_mm, unsigned* d_hist, double* d_cand, unsigned cap, double* result) {
+    if (m == 0) { *result = NAN; return DESC_OK; }
+    const int g = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (m + 255) / 256));
+    hipLaunchKernelGGL(k_minmax, dim3(64), dim3(256), 0, 0, d_x, m, d_mm);
+    double mm[128];
+    DESC_HIP(hipMemcpy(mm, d_mm, sizeof mm, hipMemcpyDeviceToHost));
+    double lo = INFINITY, hi = -INFINITY;
+    for (int b = 0; b < 64; ++b) { lo = std::min(lo, mm[2 * b]); hi = std::max(hi, mm[2 * b + 1]); }
+    const double pos = p * (double)m + 0.5;                 // 1-based fractional index
+    if (pos <= 1.0) { *result = lo; return DESC_OK; }
+    if (pos >= (double)m) { *result = hi; return DESC_OK; }
+    if (!(hi > lo)) { *result = lo; return DESC_OK; }
+    const int64_t k0 = (int64_t)std::floor(pos) - 1;        // 0-based rank of the lower order statistic; the upper one is k0 + 1
+    const double fr = pos - std::floor(pos);
+    const double scale = (double)QBINS / (hi - lo) * (1.0 - 1e-12);
+    DESC_HIP(hipMemset(d_hist, 0, sizeof(unsigned) * (QBINS + 1)));
+    hipLaunchKernelGGL(k_qhist, dim3(g), dim3(256), 0, 0, d_x, m, lo, scale, d_hist);
+    std::vector<unsigned> hist(QBINS);
+    DESC_HIP(hipMemcpy(hist.data(), d_hist, sizeof(unsigned) * QBINS, hipMemcpyDeviceToHost));
+    int64_t acc = 0; int b0 = -1, b1 = -1; int64_t base0 = 0;
+    for (int b = 0; b < QBINS; ++b) {
+        if (b0 < 0 && acc + hist[b] > (uint64_t)k0) { b0 = b; base0 = acc; }
+        if (b0 >= 0 && acc + hist[b] > (uint64_t)(k0 + 1)) { b1 = b; break; }
+        acc += hist[b];
+    }
+    if (b0 < 0 || b1 < 0) return fail(DESC_ERR_STATE, "quantile histogram inconsistent");
+    const uint64_t need = (uint64_t)hist[b0] + (b1 != b0 ? hist[b1] : 0);
+    if (need > cap) {                                       // a bin too full to collect (heavily tied data): exact host path
+        std::vector<double> all((size_t)m);
+        DESC_HIP(hipMemcpy(all.data(), d_x, sizeof(double) * m, hipMemcpyDeviceToHost));
+        *result = matlab_quantile(all, p);
+        return DESC_OK;
+    }
+    hipLaunchKernelGGL(k_qcollect, dim3(g), dim3(256), 0, 0, d_x, m, lo, scale, b0, b1, d_cand, d_hist + QBINS, cap);
+    std::vector<double> cand((size_t)need);
+    DESC_HIP(hipMemcpy(cand.data(), d_cand, sizeof(double) * need, hipMemcpyDeviceToHost));
+    std::sort(cand.begin(), cand.end());
+    // cand = bin b0 (ranks base0 ...) followed, if different, by bin b1 (which starts at rank >= k0 + 1)
+    const double a = cand[(size_t)(k0 - base0)];
+    const double bnext = (b1 == b0) ? cand[(size_t)(k0 + 1 - base0)] : cand[(size_t)hist[b0] + 0 + (size_t)0];
+    *result = a + fr * (bnext - a);
+    return DESC_OK;
 }
 
 struct DevR {
@@ -325,7 +405,10 @@ extern "C" int desc_refine_run_dev(const desc_device_problem* dp, const double* 
     const double quant_ratio_min = 0.8;
     int Iteration = 1, cg_total = 0, cg_unconverged = 0;
     double cg_worst = 0.0;
-    std::vector<double> part(sgrid), rs((size_t)m);
+    std::vector<double> part(sgrid);
+    constexpr unsigned QCAP = 1u << 20;
+    double *d_mm, *d_cand; unsigned* d_qh;
+    if ((rc = D.alloc(&d_mm, 128)) || (rc = D.alloc(&d_cand, QCAP)) || (rc = D.alloc(&d_qh, QBINS + 1))) return rc;
     CgScal hs;
     while (score > stop_threshold && Iteration < max_iters) {                               // DESC.m:287
         const double lam = 1.0 / (Iteration + 1);
@@ -364,9 +447,9 @@ extern "C" int desc_refine_run_dev(const desc_device_problem* dp, const double* 
         // ---- residuals and new weights (DESC.m:289-303)
         if (m) {
             hipLaunchKernelGGL(k_rsvec, dim3(egrid), dim3(256), 0, 0, d_Wv, d_B, d_ii, d_jj, d_S, d_RS, m, lam);
-            DESC_HIP(hipMemcpy(rs.data(), d_RS, sizeof(double) * m, hipMemcpyDeviceToHost));
             quant_ratio = std::max(quant_ratio_min, quant_ratio - 0.05);
-            const double thresh = matlab_quantile(rs, quant_ratio);
+            double thresh = 0.0;                                                            // quantile(RSVec, quant_ratio)  (DESC.m:299)
+            if ((rc = device_quantile(d_RS, m, quant_ratio, d_mm, d_qh, d_cand, QCAP, &thresh))) return rc;
             hipLaunchKernelGGL(k_weights, dim3(egrid), dim3(256), 0, 0, d_RS, d_w, m, thresh, weight_max, weight_min);
         }
         DESC_HIP(hipGetLastError());

@@ -28,7 +28,10 @@ constexpr int BW = 6;    // block width of the subspace iteration
 
 // y[v] = alpha * sum_t blocks[t] * x[adj[t]] + s1 * x[v] + s2 * z[v];  x, y, z: (3n x BW) row-major
 // (z may alias y: every element is read before it is written by the same lane); 16 lanes per node row
-__global__ __launch_bounds__(256) void k_bsr_spmm(const int32_t* rowptr, const int32_t* adj, const double* blocks, const double* x,
+// The 2m blocks are stored component-major (blocks[q * nslots + t], q = r + 3k): the 16 lanes of a row read 16
+// consecutive doubles per component (coalesced) instead of nine 8-byte picks at a 72-byte stride; the operand
+// rows of x (144 B, L2-resident) come in as nine 16-byte loads.
+__global__ __launch_bounds__(256) void k_bsr_spmm(const int32_t* rowptr, const int32_t* adj, const double* blocks, int64_t nslots, const double* x,
                                                   const double* z, double* y, int n, double alpha, double s1, double s2) {
     const int lane = threadIdx.x & 63, l16 = lane & 15;
     const int row0 = (blockIdx.x * 256 + threadIdx.x) >> 4;
@@ -42,13 +45,18 @@ __global__ __launch_bounds__(256) void k_bsr_spmm(const int32_t* rowptr, const i
             for (int c = 0; c < BW; ++c) acc[r][c] = 0.0;
         if (v < n) {
             for (int t = rowptr[v] + l16; t < rowptr[v + 1]; t += 16) {
-                const double* B = blocks + 9 * (int64_t)t;          // column-major 3x3: B(r,k) = B[r + 3k]
-                const double* xj = x + (int64_t)3 * BW * adj[t];
+                double B[9];                                         // column-major 3x3: B(r,k) = B[r + 3k]
+#pragma unroll
+                for (int q = 0; q < 9; ++q) B[q] = blocks[(int64_t)q * nslots + t];
+                const double2* xj = reinterpret_cast<const double2*>(x + (int64_t)3 * BW * adj[t]);
+                double xr[3 * BW];
+#pragma unroll
+                for (int q = 0; q < 3 * BW / 2; ++q) { const double2 v2 = xj[q]; xr[2 * q] = v2.x; xr[2 * q + 1] = v2.y; }
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
 #pragma unroll
                     for (int c = 0; c < BW; ++c) {
-                        const double xv = xj[k * BW + c];
+                        const double xv = xr[k * BW + c];
 #pragma unroll
                         for (int r = 0; r < 3; ++r) acc[r][c] += B[r + 3 * k] * xv;
                     }
@@ -105,7 +113,7 @@ struct SmallMat { double c[BW * BW]; };
 // blocks[t] (column-major 3x3) of CSR slot t in row v: w_e * dinv[v] * dinv[u] * (v < u ? R_e : R_e')
 // -- Spectral.m:24-33 / GCW.m:14-21 without the dense matrix; one wave per row, lanes over its slots
 __global__ __launch_bounds__(256) void k_assemble_blocks(const int32_t* rowptr, const int32_t* adj, const int32_t* adj_eid, const double* rij,
-                                                         const double* wts, const double* dinv, double* blocks, int n) {
+                                                         const double* wts, const double* dinv, double* blocks, int64_t nslots, int n) {
     const int lane = threadIdx.x & 63;
     const int w0 = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = (gridDim.x * 256) >> 6;
     for (int v = w0; v < n; v += nw) {
@@ -115,10 +123,27 @@ __global__ __launch_bounds__(256) void k_assemble_blocks(const int32_t* rowptr, 
             const double du = dinv[u];
             const double w = (wts ? wts[e] : 1.0) * (v < u ? dv : du) * (v < u ? du : dv);     // same rounding in (v,u) and (u,v): exactly symmetric
             const double* R = rij + 9 * (int64_t)e;
-            double* b = blocks + 9 * (int64_t)t;
-            if (v < u) { for (int q = 0; q < 9; ++q) b[q] = w * R[q]; }
-            else { for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) b[r + 3 * c] = w * R[c + 3 * r]; }
+            double* b = blocks + t;                                  // component q at b[q * nslots]
+            if (v < u) { for (int q = 0; q < 9; ++q) b[(int64_t)q * nslots] = w * R[q]; }
+            else { for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) b[(int64_t)(r + 3 * c) * nslots] = w * R[c + 3 * r]; }
         }
+    }
+}
+
+// GCW.m:20 on the device: Weights = 1 ./ (SVec.^(1.5) + 1e-8) per edge
+__global__ void k_gcw_weights(const double* S, double* w, int64_t m) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < m; e += (int64_t)gridDim.x * blockDim.x) w[e] = 1.0 / (pow(S[e], 1.5) + 1e-8);
+}
+// weighted degree of every node (GCW.m:21 sum(Weights, 2)): 16 lanes per CSR row, fixed order
+__global__ __launch_bounds__(256) void k_row_wsum(const int32_t* rowptr, const int32_t* adj_eid, const double* w, double* deg, int n) {
+    const int l16 = threadIdx.x & 15;
+    const int row0 = (blockIdx.x * 256 + threadIdx.x) >> 4, nrows = (gridDim.x * 256) >> 4;
+    for (int vb = row0 - (row0 % 4); vb < n; vb += nrows) {
+        const int v = vb + (row0 % 4);
+        double acc = 0.0;
+        if (v < n) for (int t = rowptr[v] + l16; t < rowptr[v + 1]; t += 16) acc += w ? w[adj_eid[t]] : 1.0;
+        acc = group16_sum(acc);
+        if (v < n && l16 == 0) deg[v] = acc;
     }
 }
 
@@ -255,8 +280,22 @@ extern "C" int desc_spectral_run(const desc_problem* prob, const double* weights
     return rc;
 }
 
+static int spectral_impl(const desc_device_problem* dp, const double* weights, const double* gcw_svec, int32_t normalize_rows, double tol,
+                         int32_t max_iters, double* R_out, desc_spectral_info* info);
+
 extern "C" int desc_spectral_run_dev(const desc_device_problem* dp, const double* weights, int32_t normalize_rows, double tol,
                                      int32_t max_iters, double* R_out, desc_spectral_info* info) {
+    return spectral_impl(dp, weights, nullptr, normalize_rows, tol, max_iters, R_out, info);
+}
+// R_est = GCW(Ind, AdjMat, RijMat, SVec) -- Utils/GCW.m:9-36 with the weights formed on the device from SVec (m doubles)
+extern "C" int desc_gcw_run_dev(const desc_device_problem* dp, const double* s_vec, double tol, int32_t max_iters, double* R_out,
+                                desc_spectral_info* info) {
+    if (!s_vec) return fail(DESC_ERR_INVALID, "NULL argument");
+    return spectral_impl(dp, nullptr, s_vec, 1, tol, max_iters, R_out, info);
+}
+
+static int spectral_impl(const desc_device_problem* dp, const double* weights, const double* gcw_svec, int32_t normalize_rows, double tol,
+                         int32_t max_iters, double* R_out, desc_spectral_info* info) {
     if (!dp || !R_out) return fail(DESC_ERR_INVALID, "NULL argument");
     int rc = DESC_OK;
     const int64_t n = dp->n, m = dp->m;
@@ -269,10 +308,28 @@ extern "C" int desc_spectral_run_dev(const desc_device_problem* dp, const double
     // block CSR: every edge in both endpoint rows; the index part lives with the device problem, the 2m blocks are
     // assembled on the device ((i,j) slot = R, (j,i) slot = R')
     std::vector<double> deg((size_t)n, 0.0);
-    for (int64_t e = 0; e < m; ++e) {
-        const double w = weights ? weights[e] : 1.0;
-        if (!(w >= 0) || !std::isfinite(w)) return fail(DESC_ERR_INVALID, "weight %lld is not a finite non-negative number", (long long)e);
-        deg[dp->ii[e]] += w; deg[dp->jj[e]] += w;
+    Dev W;                                                  // edge weights on the device (NULL: all ones)
+    double* d_w = nullptr;
+    if (gcw_svec) {                                         // weights and weighted degrees entirely on the device
+        double *d_s, *d_deg;
+        Dev Tmp;
+        if ((rc = W.alloc(&d_w, m)) || (rc = Tmp.alloc(&d_s, m)) || (rc = Tmp.alloc(&d_deg, n))) return rc;
+        if (m) DESC_HIP(hipMemcpy(d_s, gcw_svec, sizeof(double) * m, hipMemcpyHostToDevice));
+        if (m) hipLaunchKernelGGL(k_gcw_weights, dim3((unsigned)std::min<int64_t>(2048, (m + 255) / 256)), dim3(256), 0, 0, d_s, d_w, m);
+        hipLaunchKernelGGL(k_row_wsum, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256))), dim3(256), 0, 0,
+                           dp->d_rowptr, dp->d_adj_eid, d_w, d_deg, (int)n);
+        DESC_HIP(hipMemcpy(deg.data(), d_deg, sizeof(double) * n, hipMemcpyDeviceToHost));
+        for (int64_t v = 0; v < n; ++v) if (!std::isfinite(deg[v])) return fail(DESC_ERR_INVALID, "S_vec holds a negative or non-finite entry (node %lld)", (long long)v);
+    } else {
+        for (int64_t e = 0; e < m; ++e) {
+            const double w = weights ? weights[e] : 1.0;
+            if (!(w >= 0) || !std::isfinite(w)) return fail(DESC_ERR_INVALID, "weight %lld is not a finite non-negative number", (long long)e);
+            deg[dp->ii[e]] += w; deg[dp->jj[e]] += w;
+        }
+        if (weights && m) {
+            if ((rc = W.alloc(&d_w, m))) return rc;
+            DESC_HIP(hipMemcpy(d_w, weights, sizeof(double) * m, hipMemcpyHostToDevice));
+        }
     }
     double sigma = 0.0;
     std::vector<double> dinv((size_t)n, 1.0);               // D^-1/2
@@ -294,12 +351,11 @@ extern "C" int desc_spectral_run_dev(const desc_device_problem* dp, const double
         (rc = D.alloc(&d_X, rows * BW)) || (rc = D.alloc(&d_Y, rows * BW)) || (rc = D.alloc(&d_part, (size_t)ggrid * 2 * BW * BW))) return rc;
     if (m) {
         Dev T;                                               // assembly inputs, released before the iteration starts
-        const int32_t* d_eid = dp->d_adj_eid; const double* d_rij = dp->d_rij; double *d_w = nullptr, *d_dinv;
-        if ((rc = T.alloc(&d_dinv, n)) || (weights && (rc = T.alloc(&d_w, m)))) return rc;
+        const int32_t* d_eid = dp->d_adj_eid; const double* d_rij = dp->d_rij; double* d_dinv;
+        if ((rc = T.alloc(&d_dinv, n))) return rc;
         DESC_HIP(hipMemcpy(d_dinv, dinv.data(), sizeof(double) * n, hipMemcpyHostToDevice));
-        if (weights) DESC_HIP(hipMemcpy(d_w, weights, sizeof(double) * m, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_assemble_blocks, dim3((unsigned)std::min<int64_t>(4096, (n + 3) / 4)), dim3(256), 0, 0, d_rowptr, d_adj, d_eid, d_rij, d_w,
-                           d_dinv, d_blocks, (int)n);
+                           d_dinv, d_blocks, (int64_t)2 * m, (int)n);
         DESC_HIP(hipGetLastError());
         DESC_HIP(hipDeviceSynchronize());
     }
@@ -353,7 +409,7 @@ extern "C" int desc_spectral_run_dev(const desc_device_problem* dp, const double
     bool converged = false;
     const int sgrid = (int)std::min<int64_t>(4096, (n * 16 + 255) / 256);
     auto spmm = [&](const double* x, const double* z, double* y, double alpha, double s1, double s2) {
-        hipLaunchKernelGGL(k_bsr_spmm, dim3(sgrid), dim3(256), 0, 0, d_rowptr, d_adj, d_blocks, x, z, y, (int)n, alpha, s1, s2);
+        hipLaunchKernelGGL(k_bsr_spmm, dim3(sgrid), dim3(256), 0, 0, d_rowptr, d_adj, d_blocks, (int64_t)2 * m, x, z, y, (int)n, alpha, s1, s2);
         ++products;
     };
     const double lo = -sigma;

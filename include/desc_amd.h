@@ -272,6 +272,10 @@ int desc_spectral_run(const desc_problem* prob, const double* weights, int32_t n
                       int32_t max_iters, int32_t device, double* R_out, desc_spectral_info* info);
 int desc_spectral_run_dev(const desc_device_problem* dp, const double* weights, int32_t normalize_rows, double tol,
                           int32_t max_iters, double* R_out, desc_spectral_info* info);
+/* R_est = GCW(Ind, AdjMat, RijMat, SVec) -- Utils/GCW.m:9-36 -- with the weights 1/(SVec.^1.5 + 1e-8) (GCW.m:20) and the
+ * weighted degrees formed on the device from s_vec (m doubles, host). */
+int desc_gcw_run_dev(const desc_device_problem* dp, const double* s_vec, double tol, int32_t max_iters, double* R_out,
+                     desc_spectral_info* info);
 
 /* ------------------------------------------------------------ CEMP (next row f-2) -- */
 /* SVec = CEMP(Ind, RijMat, CEMP_parameters) -- Algorithms/CEMP.m:24-132.  beta[0..n_beta-1] =
