@@ -144,7 +144,7 @@ def load_traffic(name):
     return None, None
 
 
-def measure(lib, name, K, W, seed, convergence, keep_arrays):
+def measure(lib, name, K, W, seed, convergence, keep_arrays, n_sample_min=30):
     """One workload on one GPU: K timed iterations (inputs resident in HBM), the per-kernel roofline leg, one really
     timed desc_pgd_solve call (host arrays in -> S_vec out, 100 iterations), optionally the run to the patience exit."""
     t0 = time.perf_counter()
@@ -152,7 +152,7 @@ def measure(lib, name, K, W, seed, convergence, keep_arrays):
     t_gen = time.perf_counter() - t0
     prob = lib.ProblemArrays(nn, ii, jj, rij)
     t0 = time.perf_counter()
-    st = lib.Structure.build(prob, 30, seed, lib.BUILD_DEVICE, 0)
+    st = lib.Structure.build(prob, n_sample_min, seed, lib.BUILD_DEVICE, 0)
     t_struct = time.perf_counter() - t0
     t0 = time.perf_counter()
     solver = lib.Solver(prob, st, 0)
@@ -192,7 +192,7 @@ def measure(lib, name, K, W, seed, convergence, keep_arrays):
     solver.destroy()
     # ---- end to end, really timed: one desc_pgd_solve call = structure build + upload + layout + S0_long +
     #      100 iterations + download (what DESC_PGD() / the MEX shim pay per call in a warm process)
-    pe = lib.default_params(); pe.iters = 100; pe.lr = 0.01; pe.seed = seed; pe.patience = (1 << 31) - 1
+    pe = lib.default_params(); pe.iters = 100; pe.lr = 0.01; pe.seed = seed; pe.patience = (1 << 31) - 1; pe.n_sample_min = n_sample_min
     t0 = time.perf_counter()
     e2e = lib.solve(prob, pe)
     t_e2e = time.perf_counter() - t0
@@ -228,6 +228,8 @@ def main():
     ap.add_argument("--no-convergence", action="store_true", help="skip the run to the patience exit (profiling: keeps the kernel statistics to the timed sweeps)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the extra C4 measurement of the default run")
     ap.add_argument("--seed", type=int, default=0, help="cycle-sampling seed")
+    ap.add_argument("--full", action="store_true", help="no cycle sampling: n_sample_min above every codegree, all triangles swept "
+                    "(BASELINE configs[4]: ~1.7e8 triangles = 5e8 edge-cycle slots at C5)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,13 +241,15 @@ def main():
     name = args.workload or "C2"
     K, W = args.steps, args.warmup
     warm_up(_lib)
-    r = measure(_lib, name, K, W, args.seed, not args.no_convergence, not args.no_cpu_baseline)
+    nsm = (1 << 16) if args.full else 30
+    # (unsampled: ConstantStepSize(1) never meets the patience rule -- 5000 sweeps measured at C5 -- so that leg is skipped)
+    r = measure(_lib, name, K, W, args.seed, not args.no_convergence and not args.full, not args.no_cpu_baseline, nsm)
     dt = r["dt"]
     line = {
         "metric": "DESC_PGD iters/sec", "value": K / dt, "unit": "iters/s", "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": describe(name), "n": r["nn"], "m": r["m"], "m_pos": r["m_pos"], "m_cycle": r["m_cycle"],
+        "config": {"workload": describe(name) + ("; all triangles (no cycle sampling)" if args.full else ""), "n": r["nn"], "m": r["m"], "m_pos": r["m_pos"], "m_cycle": r["m_cycle"],
                    "n_sample": r["n_sample"], "sampling_seed": args.seed, "parallelism": "1 GPU"},
         "roofline": r["roofline"],
         "cycle_updates_per_s": r["m_cycle"] * K / dt,
