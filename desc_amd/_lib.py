@@ -60,7 +60,10 @@ class Params(C.Structure):
                 ("hybrid_strategy", C.c_int32), ("t0", C.c_int32), ("patience", C.c_int32),
                 ("stop_tol", C.c_double), ("n_sample_min", C.c_int32), ("seed", C.c_uint64),
                 ("verbose", C.c_int32), ("device", C.c_int32), ("build_where", C.c_int32),
-                ("check_every", C.c_int32)]
+                ("check_every", C.c_int32), ("progress", C.c_void_p), ("progress_user", C.c_void_p)]
+
+
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_double, C.c_double)
 
 
 class Result(C.Structure):

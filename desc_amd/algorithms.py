@@ -20,6 +20,8 @@ over the same ABI are in matlab/.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
 from . import _lib
@@ -130,10 +132,11 @@ def DESC_PGD(Ind, RijMat, params, return_info=False, _marshalled=None):
     average-change traces, iteration count, timings and structure sizes.
     ``_marshalled`` (internal, used by DESC()): (perm, ProblemArrays, DeviceProblem) already prepared."""
     p, G = make_c_params(params)
-    if _get(params, "make_plots", False):
-        raise NotImplementedError(
-            "params.make_plots=true (per-iteration GCW + alignment, DESC_PGD.m:235-239) is outside the "
-            "accelerated hot path; run with make_plots=false")
+    make_plots = bool(_get(params, "make_plots", False))
+    if make_plots and (_get(params, "ErrVec") is None or _get(params, "R_orig") is None):
+        raise ValueError("params.make_plots=true reads params.ErrVec and params.R_orig (DESC_PGD.m:236-238)")
+    if make_plots and isinstance(G, HybridGradient) and G.strategy == 0:
+        raise NotImplementedError("make_plots with the Adam plugin: the per-iteration path does not carry m_t / v_t")
     if _marshalled is None:
         n, ii, jj, rij, perm = marshal_edges(Ind, RijMat)
         if ii.shape[0] == 0:
@@ -143,6 +146,13 @@ def DESC_PGD(Ind, RijMat, params, return_info=False, _marshalled=None):
     else:
         perm, prob, dprob = _marshalled
     verbose = bool(p.verbose)
+    cb = None
+    if verbose:        # the reference's per-iteration line (DESC_PGD.m:241), streamed by the library while the loop runs
+        def _line(user, it, avg, obj):
+            print("iter %d: average change in S_vec %f, objective value: %f" % (it, avg, obj), flush=True)
+        cb = _lib.PROGRESS_FN(_line)
+        p.progress = C.cast(cb, C.c_void_p)
+        p.verbose = 0
     try:
         st = _lib.Structure.build(prob, p.n_sample_min, p.seed, p.build_where, p.device)
     except _lib.DescError as e:
@@ -169,7 +179,10 @@ def DESC_PGD(Ind, RijMat, params, return_info=False, _marshalled=None):
             if mt.shape[0] != solver.m_cycle:
                 raise ValueError("HybridGradient state has a different length than this problem's cycle vector")
             adam = (np.ascontiguousarray(mt, dtype=np.float64).copy(), np.ascontiguousarray(vt, dtype=np.float64).copy())
-        out = solver.run(p, adam=adam)
+        if not make_plots:
+            out = solver.run(p, adam=adam)
+        else:
+            out = _run_with_plots(solver, p, params, prob, dprob, perm, verbose)
     finally:
         solver.destroy()
     # plugin state after the run (handle-object semantics)
@@ -189,6 +202,62 @@ def DESC_PGD(Ind, RijMat, params, return_info=False, _marshalled=None):
         info["ms_structure"] = ms_structure
         return S_vec, info
     return S_vec
+
+
+def _run_with_plots(solver, p, params, prob, dprob, perm, verbose):
+    """params.make_plots = true (DESC_PGD.m:235-239): after every iteration the error of S_vec against params.ErrVec and
+    the rotation error of GCW(S_vec) against params.R_orig (GlobalSOdCorrectRight = the alignment of Rotation_Alignment).
+    A composition of device rows: one sweep, one S_vec download and one GCW eigen-solve per iteration."""
+    own = None
+    if not isinstance(dprob, _lib.DeviceProblem):
+        own = dprob = _lib.DeviceProblem(prob, p.device)
+    ErrVec = np.asarray(_get(params, "ErrVec"), dtype=np.float64).reshape(-1)
+    R_orig = np.asarray(_get(params, "R_orig"), dtype=np.float64)
+    if perm is not None:
+        ErrVec = ErrVec[perm]
+    svec_errors, mse_means, mse_medians = [], [], []
+    try:
+        solver.reset(p)
+        done = 0
+        while done < p.iters:
+            solver.iterate(1); done += 1
+            mid = solver.download()                                  # also evaluates the objective of this iteration
+            if mid["iters_run"] < done:                              # the patience rule fired at an earlier iteration
+                break
+            S = mid["S_vec"]
+            svec_errors.append(float(np.mean(np.abs(ErrVec - S))))                           # :236
+            R_est, _ = _lib.gcw_run(dprob, S)                                                # :237
+            _, _, mean_e, med_e = Rotation_Alignment(R_est, R_orig)                          # :238
+            mse_means.append(mean_e); mse_medians.append(med_e)
+            if verbose:
+                print("iter %d: average change in S_vec %f, objective value: %f" % (done, mid["avg"][done - 1], mid["obj"][done - 1]), flush=True)
+        out = solver.download()
+    finally:
+        if own is not None:
+            own.free()
+    k = out["iters_run"]
+    out["svec_errors"] = np.array(svec_errors[:k]); out["MSE_means"] = np.array(mse_means[:k]); out["MSE_medians"] = np.array(mse_medians[:k])
+    return out
+
+
+def plot_convergence(info, path=None):
+    """The 2 x 2 figure of DESC.m:315-344 from the traces of a make_plots run (matplotlib, if it is installed)."""
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except ImportError:
+        return None
+    fig, ax = plt.subplots(2, 2, figsize=(10, 8))
+    for a, key, title, yl in ((ax[0, 0], "svec_errors", "Convergence of Corruption Estimate Vector (S_vec, sampled)", "Average distance to true corruption"),
+                              (ax[0, 1], "obj", "Convergence of Objective Function (sampled)", "Value of Objective Function"),
+                              (ax[1, 0], "MSE_means", "Convergence of Rotation Estimate, Mean (sampled)", "Mean Error in R estimate (degrees)"),
+                              (ax[1, 1], "MSE_medians", "Convergence of Rotation Estimate, Median (sampled)", "Median Error in R estimate (degrees)")):
+        a.plot(np.arange(1, len(info[key]) + 1), info[key]); a.set_title(title, fontsize=9); a.set_xlabel("Iteration number"); a.set_ylabel(yl)
+    fig.tight_layout()
+    if path:
+        fig.savefig(path)
+    return fig
 
 
 def Spectral(Ind, RijMat, device=0, return_info=False):

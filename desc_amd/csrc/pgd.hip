@@ -2328,7 +2328,26 @@ int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r) {
         rc = cycles_to_device(h, r->adam_v, h->d_adam_v[0]); if (rc) return rc;
         DESC_HIP(hipStreamSynchronize(h->stream));
     }
-    const int chunk = p->check_every > 0 ? p->check_every : 32;
+    // progress lines (DESC_PGD.m:241) are streamed while the loop runs: at every poll of the stop flag the traces of the
+    // iterations that became final since the last poll are fetched and handed to the callback (or printed)
+    const bool stream_lines = (p->progress != nullptr || p->verbose) && h->m_pos > 0;
+    int chunk = p->check_every > 0 ? p->check_every : 32;
+    if (stream_lines && p->check_every <= 0) chunk = 10;
+    int reported = 0;
+    std::vector<double> lo, la;
+    auto emit = [&](int it, double avg, double obj) {
+        if (p->progress) p->progress(p->progress_user, it, avg, obj);
+        else { printf("iter %d: average change in S_vec %f, objective value: %f\n", it, avg, obj); fflush(stdout); }
+    };
+    auto report_upto = [&](int upto) -> int {              // iterations reported+1 .. upto have both trace entries final
+        if (upto <= reported) return DESC_OK;
+        lo.resize((size_t)upto - reported); la.resize((size_t)upto - reported);
+        DESC_HIP(hipMemcpy(lo.data(), h->d_obj + reported, sizeof(double) * (upto - reported), hipMemcpyDeviceToHost));
+        DESC_HIP(hipMemcpy(la.data(), h->d_avg + reported, sizeof(double) * (upto - reported), hipMemcpyDeviceToHost));
+        for (int it = reported + 1; it <= upto; ++it) emit(it, la[it - 1 - reported], lo[it - 1 - reported]);
+        reported = upto;
+        return DESC_OK;
+    };
     int left = p->iters;
     while (left > 0) {
         const int nq = std::min(left, chunk);
@@ -2340,13 +2359,15 @@ int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r) {
             flush_finalize(h);
             DESC_HIP(hipStreamSynchronize(h->stream));
             DESC_HIP(hipMemcpy(&st, h->d_state, sizeof st, hipMemcpyDeviceToHost));
+            // the objective of iteration t becomes known with sweep t+1: lines up to t_done - 1 (or the stop iteration) are final
+            if (stream_lines && (rc = report_upto(st.stop ? st.iters_run : h->t_done - 1))) return rc;
             if (st.stop) break;
         }
     }
     rc = desc_pgd_download(h, r); if (rc) return rc;
-    if (p->verbose && r->obj_trace && r->avg_change_trace)
-        for (int it = 1; it <= r->iters_run; ++it)                       // DESC_PGD.m:241
-            printf("iter %d: average change in S_vec %f, objective value: %f\n", it, r->avg_change_trace[it - 1], r->obj_trace[it - 1]);
+    if (stream_lines) { if ((rc = report_upto(r->iters_run))) return rc; }
+    else if ((p->verbose || p->progress) && r->obj_trace && r->avg_change_trace)      // no cycles at all: constant traces
+        for (int it = 1; it <= r->iters_run; ++it) emit(it, r->avg_change_trace[it - 1], r->obj_trace[it - 1]);
     r->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return DESC_OK;
 }

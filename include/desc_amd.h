@@ -147,6 +147,12 @@ typedef struct desc_params {
     int32_t build_where;      /* DESC_BUILD_*  (one-shot desc_pgd_solve only)                 */
     int32_t check_every;      /* host polls the device stop flag every this many iterations
                                  (0 = library default); results do not depend on it           */
+    /* progress lines of DESC_PGD.m:241, streamed while the loop runs (every check_every iterations, 10 by default when
+     * a callback or verbose is set): called once per finished iteration, in order, from the thread inside desc_pgd_run /
+     * desc_pgd_solve.  NULL with verbose != 0: the reference's fprintf line on stdout.  A MEX shim passes a function that
+     * calls mexPrintf. */
+    void (*progress)(void* user, int32_t iter, double average_change, double objective);
+    void* progress_user;
 } desc_params;
 void desc_params_default(desc_params* p);
 

@@ -34,7 +34,7 @@ function [S_vec] = DESC_PGD(Ind, RijMat, params)
     end
     opt.seed = 0;   if isfield(params, 'seed'),   opt.seed = params.seed;     end
     opt.device = 0; if isfield(params, 'device'), opt.device = params.device; end
-    opt.verbose = 0;
+    opt.verbose = 1;   % the per-iteration line of DESC_PGD.m:241 is printed by the MEX shim while the loop runs
 
     disp('compute R cycle')                  % DESC_PGD.m:132
     disp('S0Mat')                            % :145
@@ -43,9 +43,6 @@ function [S_vec] = DESC_PGD(Ind, RijMat, params)
     adam_m = []; adam_v = [];
     if isa(G, 'HybridGradient') && G.t > 0, adam_m = G.m_t; adam_v = G.v_t; end
     [S_sorted, info] = desc_pgd_mex(int32(IndS - 1), double(RijMat), opt, adam_m, adam_v);
-    for it = 1:info.iters_run                % DESC_PGD.m:241
-        fprintf('iter %d: average change in S_vec %f, objective value: %f\n', it, info.avg_change(it), info.obj_vals(it));
-    end
     % handle-object state after the run
     if isa(G, 'PiecewiseStepSize') || isa(G, 'HybridGradient'), G.t = info.t_end; end
     if isa(G, 'HybridGradient') && G.strategy == 0, G.m_t = info.adam_m; G.v_t = info.adam_v; end

@@ -5,7 +5,7 @@
  *     RijMat  3 x 3 x m double  -- passed through untouched: MATLAB's column-major layout of a
  *             3x3xm array IS the library's m x 9 layout (element (r,c,l) at 9*l + r + 3*c)
  *     opt     struct: iters, step_kind, lr, beta1, beta2, decay_interval, hybrid_strategy, t0,
- *             seed, device, verbose
+ *             seed, device, verbose (1: the reference's per-iteration line, printed while the loop runs)
  *     adam_m/adam_v   [] or 1 x m_cycle (HybridGradient.m_t / v_t carried between calls)
  *   info: iters_run, t_end, obj_vals, avg_change, adam_m, adam_v, ms_structure, ms_pgd, ms_total
  *
@@ -18,6 +18,12 @@
 
 #include "mex.h"
 #include "desc_amd.h"
+
+/* DESC_PGD.m:241, streamed by the library while the loop runs */
+static void mex_progress(void* user, int32_t it, double avg, double obj) {
+    (void)user;
+    mexPrintf("iter %d: average change in S_vec %f, objective value: %f\n", (int)it, avg, obj);
+}
 
 static double field_or(const mxArray* s, const char* name, double dflt) {
     const mxArray* f = mxGetField(s, 0, name);
@@ -56,7 +62,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     p.t0 = (int32_t)field_or(prhs[2], "t0", 0);
     p.seed = (uint64_t)field_or(prhs[2], "seed", 0);
     p.device = (int32_t)field_or(prhs[2], "device", 0);
-    p.verbose = 0;                                                   /* the .m wrapper prints */
+    p.verbose = 0;
+    if (field_or(prhs[2], "verbose", 0) != 0) p.progress = mex_progress;    /* per-iteration lines through mexPrintf, as they happen */
 
     /* sizes of the per-cycle vectors are only known after the structure is built */
     desc_structure* st = NULL;

@@ -421,3 +421,46 @@ def test_download_between_iterations_does_not_double_count(lib, oracle):
     assert out["iters_run"] == ref["iters_run"]
     assert np.abs(out["S_vec"] - ref["S_vec"]).max() <= TOL and np.abs(out["w"] - ref["w"]).max() <= TOL
     assert np.allclose(out["obj"], ref["obj"], rtol=1e-12, atol=1e-9)
+
+
+def test_progress_lines_are_streamed_in_order(lib, oracle, capfd):
+    """DESC_PGD.m:241: one line per finished iteration, in order, while the loop runs -- through the ABI's callback
+    (what a MEX shim wires to mexPrintf) and through the Python wrapper's verbose printing; early stop included."""
+    import ctypes as C
+    mo, nn, ii, jj, rij = make_problem("uniform", n=40, p=0.5, q=0.1, sigma=0.0, seed=10)
+    st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=1, iters=400, lr=1.0, patience=5, stop_tol=1e-3)
+    got = []
+    cb = lib.PROGRESS_FN(lambda user, it, avg, obj: got.append((it, avg, obj)))
+    p = c_params(400, lr=1.0, seed=1, patience=5, stop_tol=1e-3, check_every=3)
+    p.progress = C.cast(cb, C.c_void_p)
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    hst = lib.Structure.build(prob, 30, 1, lib.BUILD_HOST, 0)
+    solver = lib.Solver(prob, hst, 0)
+    out = solver.run(p)
+    solver.destroy(); hst.free()
+    assert [g[0] for g in got] == list(range(1, ref["iters_run"] + 1))
+    assert np.allclose([g[2] for g in got], ref["obj"], rtol=1e-12, atol=1e-9) and np.allclose([g[1] for g in got], ref["avg"], rtol=1e-9, atol=1e-14)
+    assert np.array_equal([g[2] for g in got], out["obj"])
+    from desc_amd import ConstantStepSize, DESC_PGD
+    capfd.readouterr()
+    DESC_PGD(mo.Ind, mo.RijMat, dict(iters=12, Gradient=ConstantStepSize(0.01), seed=1, verbose=True))
+    lines = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("iter ")]
+    assert len(lines) == 12 and lines[0].startswith("iter 1: average change in S_vec ") and "objective value: " in lines[-1]
+
+
+def test_make_plots_traces(lib):
+    """params.make_plots = true (DESC_PGD.m:235-239): per-iteration error of S_vec and of GCW(S_vec) against the ground
+    truth, as a composition of device rows; the run itself is unchanged."""
+    from desc_amd import GCW, ConstantStepSize, DESC_PGD, Rotation_Alignment
+    mo, nn, ii, jj, rij = make_problem("uniform", n=70, p=0.5, q=0.2, sigma=0.1, seed=23)
+    base = dict(iters=15, Gradient=ConstantStepSize(0.01), seed=2, verbose=False)
+    S_plain = DESC_PGD(mo.Ind, mo.RijMat, dict(base, make_plots=False))
+    S, info = DESC_PGD(mo.Ind, mo.RijMat, dict(base, make_plots=True, ErrVec=mo.ErrVec, R_orig=mo.R_orig), return_info=True)
+    assert np.array_equal(S, S_plain) and info["iters_run"] == 15
+    assert len(info["svec_errors"]) == len(info["MSE_means"]) == len(info["MSE_medians"]) == 15
+    assert abs(info["svec_errors"][-1] - np.mean(np.abs(mo.ErrVec - S))) < 1e-15
+    _, _, mean_e, med_e = Rotation_Alignment(GCW(mo.Ind, mo.AdjMat, mo.RijMat, S), mo.R_orig)
+    assert abs(info["MSE_means"][-1] - mean_e) < 1e-6 and abs(info["MSE_medians"][-1] - med_e) < 1e-6
+    assert info["svec_errors"][-1] < info["svec_errors"][0]
+    with pytest.raises(ValueError):
+        DESC_PGD(mo.Ind, mo.RijMat, dict(base, make_plots=True))          # ErrVec / R_orig are read when plotting (:236-238)

@@ -33,7 +33,7 @@ def test_abi_exports_every_declared_symbol(lib):
 def test_struct_layouts_match_header(lib):
     """ctypes mirrors of the ABI structs have the C sizes (x86-64 SysV)."""
     assert C.sizeof(lib.Problem) == 40
-    assert C.sizeof(lib.Params) == 96
+    assert C.sizeof(lib.Params) == 112
     assert C.sizeof(lib.Result) == 96
     assert C.sizeof(lib.StructureView) == 104
     assert C.sizeof(lib.StructureInfo) == 56
