@@ -1,6 +1,7 @@
 // Host side of the C ABI that needs no device code: error text, parameter
 // defaults, structure objects, and the one-shot desc_pgd_solve.
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -132,20 +133,35 @@ void desc_structure_free(desc_structure* s) { if (s) { structure_free_device(s);
 int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* r) {
     if (!p || !r) return fail(DESC_ERR_INVALID, "NULL argument");
     auto t0 = std::chrono::steady_clock::now();
+    auto t_lap = t0;
+    const char* tenv = std::getenv("DESC_DEBUG_TIMING");
+    const bool timing = tenv && std::atoi(tenv) != 0;
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[desc_amd] solve %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_lap).count());
+        t_lap = now;
+    };
     desc_structure* s = nullptr;
     int rc = validate_problem(prob, true);
     if (rc) return rc;
+    lap("validate");
     rc = desc_structure_build(prob, p->n_sample_min > 0 ? p->n_sample_min : 30, p->seed, p->build_where, p->device, &s);
     if (rc == DESC_ERR_TOO_LARGE && p->build_where == DESC_BUILD_DEVICE)      // device budget exceeded: host builder
         rc = desc_structure_build(prob, p->n_sample_min > 0 ? p->n_sample_min : 30, p->seed, DESC_BUILD_HOST, p->device, &s);
     if (rc) return rc;
     double ms_structure = s->ms_build;
+    lap("structure");
     desc_pgd* h = nullptr;
     rc = desc_pgd_create(prob, s, p->device, &h);
+    lap("create");
     desc_structure_free(s);
+    lap("structure free");
     if (rc) return rc;
     rc = desc_pgd_run(h, p, r);
+    lap("run + download");
     desc_pgd_destroy(h);
+    lap("destroy");
     r->ms_structure = ms_structure;
     r->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;

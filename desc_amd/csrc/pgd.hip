@@ -384,7 +384,8 @@ struct NodeSweepArgs {
     const double* S_old;       // Sfull, 2m
     double* S_new;
     const double* Tfull;       // 2m: Tfull[rowptr[v]+t] = sum_k w(v,k; nbr_t), masked; sharded runs: T1, T2 per owned segment
-    int32_t t_seg_lo;          // >= 0: Tfull holds {T1, T2} of segment l at 2*(l - t_seg_lo) (after the reduce-scatter)
+    int32_t t_seg_lo;          // >= 0: Tfull holds T1 of segment l at l - t_seg_lo and T2 at t_half + l - t_seg_lo (after the reduce-scatter)
+    int32_t t_half;            //       (T1 block, then T2 block: the column-sum pass then writes runs of consecutive positions)
     double* s_slice;           // sharded runs: the new S of segment l also goes to s_slice[l - t_seg_lo] (this rank's all-gather slice)
     const double* nv_tab;
     double* partials;
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
             if (a.ablate & 16) sj = (int)((p >> 16) & 511u);                            // only the j-row gathers redirected
             g.sjk[e] = a.S_old[sj]; g.ski[e] = a.S_old[si];
         }
-        const int ta = a.t_seg_lo >= 0 ? 2 * (r.seg - a.t_seg_lo) : r.sa, tb = a.t_seg_lo >= 0 ? ta + 1 : r.sb;
+        const int ta = a.t_seg_lo >= 0 ? r.seg - a.t_seg_lo : r.sa, tb = a.t_seg_lo >= 0 ? ta + a.t_half : r.sb;
         g.T1 = a.Tfull[ta];                      // column j of node i = sum(wijk(IKJ(mask)))  (:189)
         g.T2 = a.Tfull[tb];                      // column i of node j = sum(wijk(JKI(mask)))  (:190)
         g.So = a.S_old[r.sa];
@@ -767,7 +768,7 @@ __global__ __launch_bounds__(BAND_THREADS, 1) void k_sweep_band(BandSweepArgs b)
                         : a.S_old[((DESC_BAND_ABLATE & 64) ? (r.rbj & 0x1FFFF) : r.rbj) + (int)((p >> 16) & 0x7FFFu)];   // 64: rows confined to 1 MiB (L2 hits)
                 g.si[e] = (DESC_BAND_ABLATE & 16) ? 0.5 : s_rows[r.rbi + (int)(p & 0x7FFFu)];
             }
-            const int ta = a.t_seg_lo >= 0 ? 2 * (r.seg - a.t_seg_lo) : r.sa, tb = a.t_seg_lo >= 0 ? ta + 1 : r.sb;
+            const int ta = a.t_seg_lo >= 0 ? r.seg - a.t_seg_lo : r.sa, tb = a.t_seg_lo >= 0 ? ta + a.t_half : r.sb;
             g.T1 = (DESC_BAND_ABLATE & 32) ? 0.25 : a.Tfull[ta];                      // column j of node i = sum(wijk(IKJ(mask)))  (:189)
             g.T2 = (DESC_BAND_ABLATE & 32) ? 0.25 : a.Tfull[tb];                      // column i of node j = sum(wijk(JKI(mask)))  (:190)
             g.So = (DESC_BAND_ABLATE & 16) ? 0.5 : s_rows[r.sa - pd.row_lo];
@@ -1148,7 +1149,7 @@ __global__ __launch_bounds__(256) void k_adj_seg(const int32_t* rowptr, const in
 }
 
 // exchange position of every CSR slot for the sharded runs: slot (v,u) of edge e owned by rank r lands at
-// r*t_part + 2*(q - rank_seg[r]) + (v is the larger endpoint), q = device position of e; edges without
+// r*t_part + (q - rank_seg[r]) + (v is the larger endpoint ? t_part/2 : 0), q = device position of e; edges without
 // cycles go to the spare last element
 __global__ __launch_bounds__(256) void k_xpos(const int32_t* rowptr, const int32_t* adj, const int32_t* adj_eid, const int32_t* devpos,
                                               const int32_t* rank_seg, int world, int64_t t_part, int32_t* xpos, int n) {
@@ -1161,7 +1162,7 @@ __global__ __launch_bounds__(256) void k_xpos(const int32_t* rowptr, const int32
             if (q >= 0) {
                 int r = 0;
                 while (r + 1 < world && q >= rank_seg[r + 1]) ++r;
-                pos = (int64_t)r * t_part + 2 * (int64_t)(q - rank_seg[r]) + (v < adj[t] ? 0 : 1);
+                pos = (int64_t)r * t_part + (int64_t)(q - rank_seg[r]) + (v < adj[t] ? 0 : t_part / 2);
             }
             xpos[t] = (int32_t)pos;
         }
@@ -1857,7 +1858,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
                     if (q >= 0) {
                         int r = 0;
                         while (r + 1 < h->world && q >= h->rank_seg[r + 1]) ++r;
-                        pos = (int64_t)r * h->t_part + 2 * (int64_t)(q - h->rank_seg[r]) + (v < adj[t] ? 0 : 1);
+                        pos = (int64_t)r * h->t_part + (int64_t)(q - h->rank_seg[r]) + (v < adj[t] ? 0 : h->t_part / 2);
                     }
                     xpos[t] = (int32_t)pos;
                 }
@@ -2431,7 +2432,7 @@ int shard_enqueue_sweep(desc_pgd* h, hipStream_t st) {
     const StepArgs sa = make_step(h, &adam, rd, wr);
     NodeSweepArgs a{};
     a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
-    a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_Trecv; a.t_seg_lo = (int32_t)h->seg_lo; a.nv_tab = h->d_nv;
+    a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_Trecv; a.t_seg_lo = (int32_t)h->seg_lo; a.t_half = (int32_t)(h->t_part / 2); a.nv_tab = h->d_nv;
     a.s_slice = my_slice(h); a.partials = my_slice(h) + h->slice_S;       // S and the workgroup partials go straight into the slice
     if (shard_direct(h)) { a.Tfull = h->d_T; a.t_seg_lo = -1; a.s_slice = nullptr; }
     a.state = h->d_state; a.st = sa; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks;
