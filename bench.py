@@ -205,7 +205,7 @@ def measure(lib, name, K, W, seed, convergence, keep_arrays, n_sample_min=30):
         n_sample=int(sizes["n_sample"]),
         roofline={"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                   "traffic": traffic, "traffic_source": traffic_src,
-                  "kernel": ("k_colsum_node + " + kname + "0> (one iteration = both launches)") if "node" in kname else kname,
+                  "kernel": ("k_colsum_node + " + kname + "0> (one iteration = both launches)") if ("node" in kname or "band" in kname) else kname,
                   "bytes_per_launch": bytes_per_launch, "kernel_ms": ms_kernel},
         setup_ms={"generate": t_gen * 1e3, "structure_device": t_struct * 1e3, "upload_layout_cycle_d": t_create * 1e3},
         end_to_end={"ms": t_e2e * 1e3, "what": "one timed desc_pgd_solve call: host arrays in -> S_vec out, 100 iterations, warm process",

@@ -755,7 +755,9 @@ __global__ __launch_bounds__(BAND_THREADS, 1) void k_sweep_band(BandSweepArgs b)
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int64_t c = (int64_t)r.c0 + min(rr + LPS * e, max(r.cnt, 1) - 1);
-                x.pk[e] = a.pk[c]; x.w[e] = a.w_old[c]; x.d[e] = a.S0[c];
+                if (DESC_BAND_ABLATE & 128) {       // streamed once: non-temporal, so that the j-rows of S keep their place in the L2
+                    x.pk[e] = __builtin_nontemporal_load(&a.pk[c]); x.w[e] = __builtin_nontemporal_load(&a.w_old[c]); x.d[e] = __builtin_nontemporal_load(&a.S0[c]);
+                } else { x.pk[e] = a.pk[c]; x.w[e] = a.w_old[c]; x.d[e] = a.S0[c]; }
             }
             return x;
         };
@@ -840,7 +842,10 @@ __global__ __launch_bounds__(BAND_THREADS, 1) void k_sweep_band(BandSweepArgs b)
             if (DESC_BAND_ABLATE & 8) { obj_acc += ws[0] + ws[E - 1] + part; return; }
 #pragma unroll
             for (int e = 0; e < E; ++e)
-                if ((okm >> e) & 1u) a.w_new[(int64_t)r.c0 + rr + LPS * e] = ws[e];
+                if ((okm >> e) & 1u) {
+                    if (DESC_BAND_ABLATE & 256) __builtin_nontemporal_store(ws[e], &a.w_new[(int64_t)r.c0 + rr + LPS * e]);
+                    else a.w_new[(int64_t)r.c0 + rr + LPS * e] = ws[e];
+                }
             if (cnt > 0 && rr == 0) {
                 chg_acc += fabs(part - g.So);                                                            // :232
                 a.S_new[r.sa] = part; a.S_new[r.sb] = part;

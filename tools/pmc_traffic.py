@@ -5,11 +5,12 @@ MI355X_MICROARCH.md, "rocprofv3 PMC slots").
     tools/pmc_traffic.py <workload> <fetch_dir> <write_dir> [--into profiles/r02_traffic.json]
 
 Units and corrections, as the guide's HBM section prescribes: both counters are in KiB (x 1024 -> bytes); on
-gfx950 FETCH_SIZE reports exactly half the bytes of a wide coalesced (16 B/lane) streaming read, so the sweep
-kernel -- whose HBM reads are the 16-B streaming loads of w / S0 / pk; its 8-B row gathers of S are served by
-L2/MALL and are uncalibrated, included at the same factor: an upper estimate -- is doubled; the column-sum
-kernel issues 4/8-B loads on 16-lane pieces (uncalibrated width) and is taken raw; WRITE_SIZE is exact for
-streaming stores.  Per iteration = one launch of each of the iteration's kernels."""
+gfx950 FETCH_SIZE reports exactly half the bytes of a coalesced streaming read -- the guide states it for 16 B per
+lane; tools/probes/fetch_calib.hip (profiles/r02_fetch_calibration.txt) measured the same factor 0.5 for the 8- and
+4-byte-per-lane loads the sweep kernels issue -- so the sweep kernel is doubled (its 8-B row gathers of S, served by
+L2 / Infinity Cache, ride at the same factor: an upper estimate); the column-sum kernel reads short scattered runs on
+16-lane pieces (uncalibrated pattern): raw in per_iteration_bytes, doubled in per_iteration_bytes_upper; WRITE_SIZE
+is exact for streaming stores.  Per iteration = one launch of each of the iteration's kernels."""
 import argparse
 import collections
 import csv
@@ -48,7 +49,13 @@ def main():
                                      "launches_sampled": len(fetch.get(kname, []))})
         e["fetch_raw_bytes"] += fr; e["write_bytes"] += wr; e["traffic_bytes"] += fac * fr + wr
         total += fac * fr + wr
+    # kernels of the per-process warm-up problem (a handful of launches) are not part of an iteration
+    most = max((e["launches_sampled"] for e in entry.values()), default=0)
+    for k in [k for k, e in entry.items() if e["launches_sampled"] * 4 < most]:
+        total -= entry[k]["traffic_bytes"]; del entry[k]
     entry["per_iteration_bytes"] = total
+    # upper bound: the same x2 for the column-sum kernel's short scattered runs (uncalibrated width)
+    entry["per_iteration_bytes_upper"] = sum(2.0 * e["fetch_raw_bytes"] + e["write_bytes"] for e in entry.values() if isinstance(e, dict))
     if a.algorithmic:
         entry["algorithmic_bytes"] = a.algorithmic
     print(json.dumps({a.workload: entry}, indent=1))
