@@ -943,16 +943,21 @@ constexpr int COLSUM_U = 8;
 // The LAST workgroup of the launch does no column at all: it runs the bookkeeping of the previous sweep (traces,
 // stop rule) that used to be a separate one-wave launch per iteration.  If it sets the stop flag while the
 // node workgroups of this launch are running, they finish a T that nobody reads: the sweep that follows returns at once.
-__global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, const int2* adj_seg, const uint32_t* pk, const double* w,
+// The column of every contributing cycle comes from `midx`: a static stream of 16-bit column indices in exactly the order this
+// kernel consumes them (node-major, then incident segment, then contributing cycle; `moff` = start of a CSR slot's run), read
+// sequentially -- instead of the 4-byte packed words of the cycles, which sit in scattered 50-byte runs next to the weights
+// (round 2: -25 % of this pass's sectors).
+__global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, const int2* adj_seg, const uint32_t* moff, const uint16_t* midx, const double* w,
                                                      double* Tfull, int n, int stride_cols, const DevState* st, const int32_t* xpos, FinArgs fin) {
     if (blockIdx.x == gridDim.x - 1) {
         if (fin.t > 0 && threadIdx.x < 64) finalize_wave(fin);
         return;
     }
     if (st->stop) return;
-    extern __shared__ double acc[];                   // [4][stride_cols] doubles, then 2 ints per incident edge
+    extern __shared__ double acc[];                   // [4][stride_cols] doubles, then 3 ints per incident edge
     int* seg_base = (int*)(acc + 4 * stride_cols);
     int* seg_cf = seg_base + stride_cols;             // n_both | n_i << 9 | n_jonly << 18 | (v is the smaller endpoint) << 31
+    uint32_t* seg_mo = (uint32_t*)(seg_cf + stride_cols);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int v = blockIdx.x; v < n; v += gridDim.x - 1) {
         const int r0 = rowptr[v], deg = rowptr[v + 1] - r0;
@@ -960,7 +965,7 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
         for (int t = threadIdx.x; t < 4 * stride_cols; t += 256) acc[t] = 0.0;
         for (int t = threadIdx.x; t < deg; t += 256) {     // CSR-aligned segment records: one coalesced load
             const int2 rec = adj_seg[r0 + t];
-            seg_base[t] = rec.x; seg_cf[t] = rec.y;
+            seg_base[t] = rec.x; seg_cf[t] = rec.y; seg_mo[t] = moff[r0 + t];
         }
         __syncthreads();
         double* mine = acc + wv * stride_cols;
@@ -975,17 +980,16 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
             // pieces 0 and 1 (contributing cycles 0..31 of each segment) are loaded together;
             // segments with more take further rounds
             for (int round = 0; round < MAX_SEG_CYCLES / 32; ++round) {
-                uint32_t pv[2 * COLSUM_U]; double wvv[2 * COLSUM_U]; uint32_t sh[COLSUM_U];
+                uint32_t pv[2 * COLSUM_U]; double wvv[2 * COLSUM_U];
                 bool more = false;
 #pragma unroll
                 for (int u = 0; u < COLSUM_U; ++u) {
                     const int tt = 4 * (g0 + 4 * u) + sub;
-                    pv[2 * u] = 0; pv[2 * u + 1] = 0; wvv[2 * u] = 0.0; wvv[2 * u + 1] = 0.0; sh[u] = 16;
+                    pv[2 * u] = 0xFFFFu; pv[2 * u + 1] = 0xFFFFu; wvv[2 * u] = 0.0; wvv[2 * u + 1] = 0.0;
                     if (tt < deg) {
                         const uint32_t cf = (uint32_t)seg_cf[tt];
                         const int n_both = cf & 0x1FFu, n_i = (cf >> 9) & 0x1FFu, n_jo = (cf >> 18) & 0x1FFu;
                         const bool v_is_i = cf & 0x80000000u;
-                        sh[u] = v_is_i ? 0u : 16u;
                         const int nact = v_is_i ? n_i : n_both + n_jo;
                         more |= nact > 32 * (round + 1);
 #pragma unroll
@@ -994,17 +998,15 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
                             if (q < nact) {
                                 const int off = (v_is_i || q < n_both) ? q : n_i + (q - n_both);
                                 const int64_t c = (int64_t)seg_base[tt] + off;
-                                pv[2 * u + h2] = pk[c];
+                                pv[2 * u + h2] = midx[(size_t)seg_mo[tt] + q];
                                 wvv[2 * u + h2] = w[c];
                             }
                         }
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 2 * COLSUM_U; ++u) {
-                    const uint32_t half = (pv[u] >> sh[u >> 1]) & 0xFFFFu;
-                    if (half & 0x8000u) unsafeAtomicAdd(&mine[half & 0x7FFFu], wvv[u]);   // ds_add_f64
-                }
+                for (int u = 0; u < 2 * COLSUM_U; ++u)
+                    if (pv[u] != 0xFFFFu) unsafeAtomicAdd(&mine[pv[u]], wvv[u]);          // ds_add_f64
                 if (!__any(more)) break;
             }
         }
@@ -1151,6 +1153,61 @@ __global__ __launch_bounds__(256) void k_adj_seg(const int32_t* rowptr, const in
             if (q >= seg_lo && q < seg_hi) { rec.x = cum[q]; rec.y = (int)(seg_counts[q] | (v < adj[t] ? 0x80000000u : 0u)); }
             adj_seg[t] = rec;
         }
+}
+
+// ---- the column-index stream of the column-sum pass
+__device__ __forceinline__ int slot_nact(int2 rec) {          // contributing cycles of the segment behind a CSR slot, seen from the row's node
+    const uint32_t cf = (uint32_t)rec.y;
+    const int n_both = cf & 0x1FFu, n_i = (cf >> 9) & 0x1FFu, n_jo = (cf >> 18) & 0x1FFu;
+    return (cf & 0x80000000u) ? n_i : n_both + n_jo;
+}
+// entries per node row (16 lanes per row)
+__global__ __launch_bounds__(256) void k_midx_rowsum(const int32_t* rowptr, const int2* adj_seg, uint32_t* rowsum, int n) {
+    const int l16 = threadIdx.x & 15;
+    const int row0 = (blockIdx.x * 256 + threadIdx.x) >> 4, nrows = (gridDim.x * 256) >> 4;
+    for (int vb = row0 - (row0 % 4); vb < n; vb += nrows) {
+        const int v = vb + (row0 % 4);
+        int acc = 0;
+        if (v < n) for (int t = rowptr[v] + l16; t < rowptr[v + 1]; t += 16) acc += slot_nact(adj_seg[t]);
+        acc = group16_sum(acc);
+        if (v < n && l16 == 0) rowsum[v] = (uint32_t)acc;
+    }
+}
+// moff[t] = rowbase[v] + (entries of the earlier slots of row v); midx filled from the packed words.  16 lanes per row, each
+// walking one contiguous sixteenth of the row's slots (offsets by a 16-lane exclusive scan of the chunk totals)
+__global__ __launch_bounds__(256) void k_midx_fill(const int32_t* rowptr, const int2* adj_seg, const uint32_t* rowbase, const uint32_t* pk,
+                                                   uint32_t* moff, uint16_t* midx, int n) {
+    const int l16 = threadIdx.x & 15;
+    const int row0 = (blockIdx.x * 256 + threadIdx.x) >> 4, nrows = (gridDim.x * 256) >> 4;
+    for (int vb = row0 - (row0 % 4); vb < n; vb += nrows) {      // the 4 rows of a wave advance together (full-wave shuffles)
+        const int v = vb + (row0 % 4);
+        int t0 = 0, t1 = 0;
+        if (v < n) {
+            const int r0 = rowptr[v], r1 = rowptr[v + 1], chunk = (r1 - r0 + 15) / 16;
+            t0 = min(r0 + l16 * chunk, r1); t1 = min(t0 + chunk, r1);
+        }
+        int mine = 0;
+        for (int t = t0; t < t1; ++t) mine += slot_nact(adj_seg[t]);
+        int incl = mine;                                          // inclusive scan over the 16 lanes of the row
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) { const int up = __shfl_up(incl, d, 16); if (l16 >= d) incl += up; }
+        if (v >= n) continue;
+        uint32_t o = rowbase[v] + (uint32_t)(incl - mine);
+        for (int t = t0; t < t1; ++t) {
+            const int2 rec = adj_seg[t];
+            const uint32_t cf = (uint32_t)rec.y;
+            const int n_both = cf & 0x1FFu, n_i = (cf >> 9) & 0x1FFu;
+            const bool v_is_i = cf & 0x80000000u;
+            const int nact = slot_nact(rec);
+            moff[t] = o;
+            for (int q = 0; q < nact; ++q) {
+                const int off = (v_is_i || q < n_both) ? q : n_i + (q - n_both);
+                const uint32_t p = pk[(int64_t)rec.x + off];
+                midx[(size_t)o + q] = (uint16_t)((v_is_i ? p : p >> 16) & 0x7FFFu);
+            }
+            o += (uint32_t)nact;
+        }
+    }
 }
 
 // exchange position of every CSR slot for the sharded runs: slot (v,u) of edge e owned by rank r lands at
@@ -1308,6 +1365,8 @@ struct desc_pgd {
     // node variant
     EdgeInfo* d_einfo = nullptr;
     uint32_t* d_pk = nullptr;
+    uint32_t* d_moff = nullptr;  // per CSR slot: start of its run in d_midx
+    uint16_t* d_midx = nullptr;  // column index of every contributing cycle, in the order the column-sum pass reads them
     int2* d_adj_seg = nullptr;   // per CSR slot: {first cycle of the incident edge's segment, cnt | (row node is the smaller endpoint) << 31}
     int32_t *d_rowptr = nullptr, *d_src_start = nullptr, *d_eslot = nullptr;
     ChunkDesc* d_chunk_desc = nullptr;
@@ -1472,8 +1531,8 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
     const StepArgs st = make_step(h, &adam, rd, wr);
     if (ev0) (void)hipEventRecord(ev0, h->stream);
     if (h->variant == VARIANT_NODE) {
-        hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 2 * sizeof(int)), h->stream,
-                           h->d_rowptr, h->d_adj_seg, h->d_pk, h->d_w[rd], h->d_T, (int)h->n,
+        hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int)), h->stream,
+                           h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, h->d_w[rd], h->d_T, (int)h->n,
                            h->colsum_stride, h->d_state, (const int32_t*)nullptr, fin_args(h, h->d_partials, h->pending_parts, h->pending_fin, 0));
         h->pending_fin = 0;
         NodeSweepArgs a{};
@@ -1959,7 +2018,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     h->colsum_stride = (h->max_deg + 1) | 1;                 // odd stride: the 4 copies start on different banks
     h->colsum_grid = (int)std::max<int64_t>(1, n);            // one node per workgroup: the dispatcher balances
     {
-        const size_t lds = (size_t)h->colsum_stride * (4 * sizeof(double) + 2 * sizeof(int));
+        const size_t lds = (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int));
         if (lds > 64 * 1024)
             DESC_HIP(hipFuncSetAttribute((const void*)k_colsum_node, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
@@ -2007,6 +2066,24 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
                            h->d_rowptr, d_adj, d_adj_eid, d_devpos, h->d_rank_seg, h->world, h->t_part, h->d_xpos, (int)n);
         DESC_HIP(hipStreamSynchronize(h->stream));
         dfree(h, d_devpos); dfree(h, d_counts);
+    }
+    {   // the column-index stream of the column-sum pass (needs adj_seg and pk: both complete on the stream by now)
+        uint32_t *d_rowsum = nullptr, *d_rowbase = nullptr;
+        if ((rc = dalloc(h, &d_rowsum, n)) || (rc = dalloc(h, &d_rowbase, n)) || (rc = dalloc(h, &h->d_moff, 2 * m))) return rc;
+        const unsigned g16 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256));
+        hipLaunchKernelGGL(k_midx_rowsum, dim3(g16), dim3(256), 0, h->stream, h->d_rowptr, h->d_adj_seg, d_rowsum, (int)n);
+        std::vector<uint32_t> rs((size_t)n), rb((size_t)n);
+        DESC_HIP(hipMemcpyAsync(rs.data(), d_rowsum, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, h->stream));
+        DESC_HIP(hipStreamSynchronize(h->stream));
+        uint64_t tot = 0;
+        for (int64_t v = 0; v < n; ++v) { rb[v] = (uint32_t)tot; tot += rs[v]; }
+        if (tot >= (1ull << 32)) return fail(DESC_ERR_TOO_LARGE, "column-index stream exceeds 2^32 entries");
+        if ((rc = dalloc(h, &h->d_midx, (size_t)tot + 8))) return rc;
+        if ((rc = upload(h, d_rowbase, rb.data(), (size_t)n))) return rc;
+        hipLaunchKernelGGL(k_midx_fill, dim3(g16), dim3(256), 0, h->stream,
+                           h->d_rowptr, h->d_adj_seg, d_rowbase, h->d_pk, h->d_moff, h->d_midx, (int)n);
+        DESC_HIP(hipStreamSynchronize(h->stream));
+        dfree(h, d_rowsum); dfree(h, d_rowbase);
     }
     (void)hipEventRecord(e1, h->stream);
     hipError_t e = hipStreamSynchronize(h->stream);
@@ -2103,7 +2180,7 @@ static int create_impl(const desc_problem* prob, const double* shared_rij, const
 
     // variant: NODE unless the packed per-cycle word or the LDS column copies do not fit
     const int forced = env_int("DESC_DEBUG_VARIANT", 0);
-    const bool node_ok = h->max_deg < 32768 && (size_t)(h->max_deg + 2) * 40 <= 150 * 1024 && h->max_cnt <= MAX_SEG_CYCLES && h->m_pos > 0;
+    const bool node_ok = h->max_deg < 32768 && (size_t)(h->max_deg + 2) * 44 <= 150 * 1024 && h->max_cnt <= MAX_SEG_CYCLES && h->m_pos > 0;
     h->variant = (forced == VARIANT_GATHER || !node_ok) ? VARIANT_GATHER : VARIANT_NODE;
     if (world > 1 && h->variant != VARIANT_NODE) {
         rc = fail(DESC_ERR_INVALID, "multi-GPU sharding needs the node layout (max degree < 2^15, segments <= 64 cycles)");
@@ -2423,8 +2500,8 @@ bool shard_direct(const desc_pgd* h) { return h->world == 1 && !h->force_coll &&
 int shard_enqueue_colsum(desc_pgd* h, hipStream_t st) {
     const int rd = h->t_done & 1;
     const bool direct = shard_direct(h);
-    hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 2 * sizeof(int)), st,
-                       h->d_rowptr, h->d_adj_seg, h->d_pk, h->d_w[rd], direct ? h->d_T : h->x_T, (int)h->n, h->colsum_stride, h->d_state,
+    hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int)), st,
+                       h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, h->d_w[rd], direct ? h->d_T : h->x_T, (int)h->n, h->colsum_stride, h->d_state,
                        direct ? (const int32_t*)nullptr : h->d_xpos, FinArgs{});
     DESC_HIP(hipGetLastError());
     return DESC_OK;
