@@ -718,14 +718,6 @@ __global__ __launch_bounds__(BAND_THREADS, 1) void k_sweep_band(BandSweepArgs b)
     for (int pc = p0; pc < p1; ++pc) {
         const PieceDesc pd = uniform_load_piece(b.pieces, pc);
         __syncthreads();                                   // every wave is done with the previous band's rows
-        for (int base = 0; base < pd.row_len; base += 8 * BAND_THREADS) {     // 8 independent loads in flight per thread
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = a.S_old[pd.row_lo + min(base + u * BAND_THREADS + tid, pd.row_len - 1)];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) if (base + u * BAND_THREADS + tid < pd.row_len) s_rows[base + u * BAND_THREADS + tid] = v[u];
-        }
-        __syncthreads();
         const int nit = (pd.seg_hi - pd.seg_lo + NW * SPW - 1) / (NW * SPW);
 
         auto load_raw = [&](int it) -> RecRaw {            // past the end: the piece's last segment, cnt = 0
@@ -860,6 +852,15 @@ __global__ __launch_bounds__(BAND_THREADS, 1) void k_sweep_band(BandSweepArgs b)
         { const RecRaw q = load_raw(1); R1 = land(q); S1 = load_stream(R1); }
         { const RecRaw q = load_raw(2); R2 = land(q); S2 = load_stream(R2); }
         Q = load_raw(3);
+        // the band's rows of S_old -> LDS, while the first streams are in flight
+        for (int base = 0; base < pd.row_len; base += 8 * BAND_THREADS) {     // 8 independent loads in flight per thread
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = a.S_old[pd.row_lo + min(base + u * BAND_THREADS + tid, pd.row_len - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (base + u * BAND_THREADS + tid < pd.row_len) s_rows[base + u * BAND_THREADS + tid] = v[u];
+        }
+        __syncthreads();
         G0 = issue_gathers(R0, S0);
         // one iteration: Ra/Sa/Ga = group g (computed), Rb/Sb = g+1 (gathers issued into Gb), Rd/Sd <- g+3
         auto step = [&](int g, const Rec& Ra, const Str& Sa, const Gat& Ga, const Rec& Rb, const Str& Sb, Gat& Gb, Rec& Rd, Str& Sd) {
