@@ -1707,6 +1707,92 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
     return DESC_OK;
 }
 
+// The work of every workgroup of the band sweep as a list of pieces (band rows + a range of that band's segments).
+//  * Sfull fits the L2s (small graphs): one contiguous range of segments per workgroup (equal cycle counts), split at band
+//    boundaries -- each workgroup loads one or two bands.
+//  * otherwise S({j,k}) rows would be fetched from the Infinity Cache once per (band, j) (measured: 8 % of the iteration at C4,
+//    17 % at C5): the (band, j) plane is cut into units (band b, block of JB consecutive j) whose j-rows (~1.5 MiB) fit an
+//    XCD's L2, and the units are dealt in j-block-major order to the least-loaded workgroup (deterministic list scheduling), so
+//    that at any moment all workgroups gather from the same block of rows.
+// Host only: no device call (also reachable through desc_debug_band_plan, which the CPU tests and sanitizer builds use).
+void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const NodePlan& P, int64_t seg_lo, int64_t seg_hi, int64_t cyc_lo, int64_t mcl,
+                      int G, std::vector<PieceDesc>& pieces, std::vector<int32_t>& piece_ptr, int& band_rows, bool& jmajor_out) {
+    const std::vector<int32_t>& cum2 = P.cum2;
+    const int64_t n = prob->n, m = prob->m;
+    band_rows = 0;
+    const int64_t nbands = (int64_t)P.band_lo.size() - 1;
+    std::vector<std::vector<PieceDesc>> per_wg((size_t)G);
+    auto piece_of = [&](int64_t bd, int64_t q0, int64_t q1) {
+        const int32_t row_lo = P.rowptr[P.band_lo[bd]], row_len = P.rowptr[P.band_lo[bd + 1]] - row_lo;
+        band_rows = std::max(band_rows, (int)row_len);
+        return PieceDesc{row_lo, row_len, (int32_t)q0, (int32_t)q1};
+    };
+    const int jmajor_env = env_int("DESC_DEBUG_JMAJOR", -1);
+    const bool jmajor = jmajor_env >= 0 ? jmajor_env != 0 : (int64_t)2 * m * 8 > (12ll << 20);      // C3 (6.4 MB): contiguous 0.167 ms, units 0.184
+    jmajor_out = jmajor;
+    if (!jmajor) {
+        int64_t q = seg_lo, bd = 0;
+        for (int b = 0; b < G; ++b) {
+            const int64_t target = cyc_lo + (b + 1 == G ? mcl : mcl * (b + 1) / G);
+            int64_t qe = q;
+            while (qe < seg_hi && (cum2[qe + 1] <= target || b + 1 == G)) ++qe;
+            while (q < qe) {
+                while (bd + 1 < nbands && P.bstart[bd + 1] <= q) ++bd;
+                const int64_t e = std::min<int64_t>(qe, P.bstart[bd + 1]);
+                per_wg[b].push_back(piece_of(bd, q, e));
+                q = e;
+            }
+        }
+    } else {
+        const int64_t avg_deg = std::max<int64_t>(1, 2 * m / std::max<int64_t>(1, n));
+        int64_t JB = env_int("DESC_DEBUG_JBLOCK", 0);
+        if (JB <= 0) JB = std::max<int64_t>(32, (3ll << 19) / (8 * avg_deg));
+        const int64_t cap = std::max<int64_t>(16384, mcl / (4 * (int64_t)G));        // cycles per unit at most
+        const int64_t nJ = (n + JB - 1) / JB;
+        auto j_of = [&](int64_t q) { return (int64_t)prob->ind_j[s->pos_edge[P.order[q]]]; };
+        // position of the first segment of band bd with j >= jlim, inside the rank's range
+        std::vector<int64_t> cur((size_t)nbands), bend((size_t)nbands);
+        for (int64_t bd = 0; bd < nbands; ++bd) {
+            cur[bd] = std::min(std::max(P.bstart[bd], seg_lo), seg_hi);
+            bend[bd] = std::min(std::max(P.bstart[bd + 1], seg_lo), seg_hi);
+        }
+        // min-heap over (load, wg): the next unit goes to the workgroup that would be free first
+        std::vector<std::pair<int64_t, int>> heap; heap.reserve((size_t)G);
+        for (int b = 0; b < G; ++b) heap.push_back({0, b});
+        auto cmp = [](const std::pair<int64_t, int>& x, const std::pair<int64_t, int>& y) { return x > y; };
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        for (int64_t J = 0; J < nJ; ++J) {
+            const int64_t jlim = (J + 1) * JB;
+            for (int64_t bd = 0; bd < nbands; ++bd) {
+                int64_t lo = cur[bd]; const int64_t hi = bend[bd];
+                if (lo >= hi) continue;
+                int64_t a0 = lo, a1 = hi;                   // first q in [lo, hi) with j(q) >= jlim
+                while (a0 < a1) { const int64_t mid = (a0 + a1) >> 1; if (j_of(mid) < jlim) a0 = mid + 1; else a1 = mid; }
+                const int64_t e = a0;
+                cur[bd] = e;
+                while (lo < e) {                             // split units above the cap
+                    int64_t x = lo;
+                    while (x < e && cum2[x + 1] - cum2[lo] <= cap) ++x;
+                    if (x == lo) x = lo + 1;
+                    std::pop_heap(heap.begin(), heap.end(), cmp);
+                    auto& top = heap.back();
+                    per_wg[top.second].push_back(piece_of(bd, lo, x));
+                    top.first += cum2[x] - cum2[lo] + 4096;  // + the row load and pipeline fill of a piece, in cycle units
+                    std::push_heap(heap.begin(), heap.end(), cmp);
+                    lo = x;
+                }
+            }
+        }
+    }
+    pieces.clear();
+    piece_ptr.assign((size_t)G + 1, 0);
+    for (int b = 0; b < G; ++b) {
+        pieces.insert(pieces.end(), per_wg[b].begin(), per_wg[b].end());
+        piece_ptr[b + 1] = (int32_t)pieces.size();
+    }
+    if (pieces.empty()) pieces.push_back(PieceDesc{0, 0, 0, 0});
+}
+
 int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, const double* shared_rij) {
     const int64_t n = h->n, m = h->m, mp = h->m_pos;
     auto t0 = std::chrono::steady_clock::now();
@@ -1748,90 +1834,14 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     h->t_part = 2 * std::max<int64_t>(max_local, 1);
     const int64_t mcl = h->cyc_hi - h->cyc_lo;            // local cycles
     const int64_t nsl = h->seg_hi - h->seg_lo;            // local segments
-    // band sweep: the work of every workgroup as a list of pieces (band rows + a range of that band's segments).
-    //  * Sfull fits the L2s (small graphs): one contiguous range of segments per workgroup (equal cycle counts), split at band
-    //    boundaries -- each workgroup loads one or two bands.
-    //  * otherwise S({j,k}) rows would be fetched from the Infinity Cache once per (band, j) (measured: 8 % of the iteration at C4,
-    //    17 % at C5): the (band, j) plane is cut into units (band b, block of JB consecutive j) whose j-rows (~1.5 MiB) fit an
-    //    XCD's L2, and the units are dealt in j-block-major order to the least-loaded workgroup (deterministic list scheduling), so
-    //    that at any moment all workgroups gather from the same block of rows.
+    // band sweep: the work of every workgroup as a list of pieces (plan_band_pieces)
     std::vector<PieceDesc> pieces; std::vector<int32_t> piece_ptr;
     if (h->band_ok) {
         h->band_grid = ncu;
-        h->band_rows = 0;
-        const int G = h->band_grid;
-        const int64_t nbands = (int64_t)P.band_lo.size() - 1;
-        std::vector<std::vector<PieceDesc>> per_wg((size_t)G);
-        auto piece_of = [&](int64_t bd, int64_t q0, int64_t q1) {
-            const int32_t row_lo = P.rowptr[P.band_lo[bd]], row_len = P.rowptr[P.band_lo[bd + 1]] - row_lo;
-            h->band_rows = std::max(h->band_rows, (int)row_len);
-            return PieceDesc{row_lo, row_len, (int32_t)q0, (int32_t)q1};
-        };
-        const int jmajor_env = env_int("DESC_DEBUG_JMAJOR", -1);
-        const bool jmajor = jmajor_env >= 0 ? jmajor_env != 0 : (int64_t)2 * m * 8 > (12ll << 20);      // C3 (6.4 MB): contiguous 0.167 ms, units 0.184
-        if (!jmajor) {
-            int64_t q = h->seg_lo, bd = 0;
-            for (int b = 0; b < G; ++b) {
-                const int64_t target = h->cyc_lo + (b + 1 == G ? mcl : mcl * (b + 1) / G);
-                int64_t qe = q;
-                while (qe < h->seg_hi && (cum2[qe + 1] <= target || b + 1 == G)) ++qe;
-                while (q < qe) {
-                    while (bd + 1 < nbands && P.bstart[bd + 1] <= q) ++bd;
-                    const int64_t e = std::min<int64_t>(qe, P.bstart[bd + 1]);
-                    per_wg[b].push_back(piece_of(bd, q, e));
-                    q = e;
-                }
-            }
-        } else {
-            const int64_t avg_deg = std::max<int64_t>(1, 2 * m / std::max<int64_t>(1, n));
-            int64_t JB = env_int("DESC_DEBUG_JBLOCK", 0);
-            if (JB <= 0) JB = std::max<int64_t>(32, (3ll << 19) / (8 * avg_deg));
-            const int64_t cap = std::max<int64_t>(16384, mcl / (4 * (int64_t)G));        // cycles per unit at most
-            const int64_t nJ = (n + JB - 1) / JB;
-            auto j_of = [&](int64_t q) { return (int64_t)prob->ind_j[s->pos_edge[P.order[q]]]; };
-            // position of the first segment of band bd with j >= jlim, inside the rank's range
-            std::vector<int64_t> cur((size_t)nbands), bend((size_t)nbands);
-            for (int64_t bd = 0; bd < nbands; ++bd) {
-                cur[bd] = std::min(std::max(P.bstart[bd], h->seg_lo), h->seg_hi);
-                bend[bd] = std::min(std::max(P.bstart[bd + 1], h->seg_lo), h->seg_hi);
-            }
-            std::vector<int64_t> load((size_t)G, 0);
-            // min-heap over (load, wg): the next unit goes to the workgroup that would be free first
-            std::vector<std::pair<int64_t, int>> heap; heap.reserve((size_t)G);
-            for (int b = 0; b < G; ++b) heap.push_back({0, b});
-            auto cmp = [](const std::pair<int64_t, int>& x, const std::pair<int64_t, int>& y) { return x > y; };
-            std::make_heap(heap.begin(), heap.end(), cmp);
-            for (int64_t J = 0; J < nJ; ++J) {
-                const int64_t jlim = (J + 1) * JB;
-                for (int64_t bd = 0; bd < nbands; ++bd) {
-                    int64_t lo = cur[bd], hi = bend[bd];
-                    if (lo >= hi) continue;
-                    int64_t a0 = lo, a1 = hi;                   // first q in [lo, hi) with j(q) >= jlim
-                    while (a0 < a1) { const int64_t mid = (a0 + a1) >> 1; if (j_of(mid) < jlim) a0 = mid + 1; else a1 = mid; }
-                    const int64_t e = a0;
-                    cur[bd] = e;
-                    while (lo < e) {                             // split units above the cap
-                        int64_t x = lo;
-                        while (x < e && cum2[x + 1] - cum2[lo] <= cap) ++x;
-                        if (x == lo) x = lo + 1;
-                        std::pop_heap(heap.begin(), heap.end(), cmp);
-                        auto& top = heap.back();
-                        per_wg[top.second].push_back(piece_of(bd, lo, x));
-                        top.first += cum2[x] - cum2[lo] + 4096;  // + the row load and pipeline fill of a piece, in cycle units
-                        std::push_heap(heap.begin(), heap.end(), cmp);
-                        lo = x;
-                    }
-                }
-            }
-        }
-        piece_ptr.assign((size_t)G + 1, 0);
-        for (int b = 0; b < G; ++b) {
-            pieces.insert(pieces.end(), per_wg[b].begin(), per_wg[b].end());
-            piece_ptr[b + 1] = (int32_t)pieces.size();
-        }
-        if (pieces.empty()) pieces.push_back(PieceDesc{0, 0, 0, 0});
-        if (timing) fprintf(stderr, "[desc_amd] band sweep: %lld bands, %zu pieces over %d workgroups, %s, rows <= %d\n", (long long)nbands, pieces.size(), G,
-                            jmajor ? "j-block-major units" : "contiguous ranges", h->band_rows);
+        bool jmajor = false;
+        plan_band_pieces(prob, s, P, h->seg_lo, h->seg_hi, h->cyc_lo, mcl, h->band_grid, pieces, piece_ptr, h->band_rows, jmajor);
+        if (timing) fprintf(stderr, "[desc_amd] band sweep: %zu bands, %zu pieces over %d workgroups, %s, rows <= %d\n", P.band_lo.size() - 1, pieces.size(),
+                            h->band_grid, jmajor ? "j-block-major units" : "contiguous ranges", h->band_rows);
     }
 
     // A structure built on this device brings its CSR, edge tables and sampled k along in HBM: the
@@ -2715,6 +2725,54 @@ int desc_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes) {
 }
 int desc_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes) {
     if (bytes) DESC_HIP(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return DESC_OK;
+}
+
+// Test hook, host only (no device call): the band-sweep work plan of `rank` of `world` for `grid` workgroups -- bands, ranks' segment
+// ranges, pieces -- checked for its invariants (every owned segment in exactly one piece, a piece inside one band, band rows within
+// the LDS budget).  stats[8] = {bands, pieces, largest band's row entries, max / min cycles per workgroup, j-block-major?, seg_lo, seg_hi}.
+int desc_debug_band_plan(const desc_problem* prob, const desc_structure* s, int32_t world, int32_t rank, int32_t grid, int64_t* stats) {
+    if (!prob || !s || !stats || world < 1 || rank < 0 || rank >= world || grid < 1) return fail(DESC_ERR_INVALID, "bad argument");
+    if (s->m_pos == 0) return fail(DESC_ERR_INVALID, "no edge with cycles");
+    int32_t max_deg = 0;
+    {
+        std::vector<int32_t> deg((size_t)prob->n, 0);
+        for (int64_t e = 0; e < prob->m; ++e) { deg[prob->ind_i[e]]++; deg[prob->ind_j[e]]++; }
+        for (int32_t d : deg) max_deg = std::max(max_deg, d);
+    }
+    if (max_deg > BAND_ROW_CAP) return fail(DESC_ERR_TOO_LARGE, "a row exceeds the LDS budget");
+    NodePlan P;
+    int rc = make_node_plan(prob, s, max_deg, world, s->max_cnt <= 32 ? 32 : s->max_cnt <= 128 ? 16 : 8, BAND_ROW_CAP, P);
+    if (rc) return rc;
+    const int64_t seg_lo = P.chunk_seg[P.rank_chunk[rank]], seg_hi = P.chunk_seg[P.rank_chunk[rank + 1]];
+    const int64_t cyc_lo = P.cum2[seg_lo], mcl = P.cum2[seg_hi] - cyc_lo;
+    std::vector<PieceDesc> pieces; std::vector<int32_t> piece_ptr; int band_rows = 0; bool jmajor = false;
+    plan_band_pieces(prob, s, P, seg_lo, seg_hi, cyc_lo, mcl, grid, pieces, piece_ptr, band_rows, jmajor);
+    const int64_t nbands = (int64_t)P.band_lo.size() - 1;
+    std::vector<uint8_t> seen((size_t)(seg_hi - seg_lo), 0);
+    int64_t wmax = 0, wmin = INT64_MAX;
+    for (int b = 0; b < grid; ++b) {
+        int64_t cyc = 0;
+        for (int32_t pc = piece_ptr[b]; pc < piece_ptr[b + 1]; ++pc) {
+            const PieceDesc& pd = pieces[pc];
+            if (pd.seg_lo < seg_lo || pd.seg_hi > seg_hi || pd.seg_lo >= pd.seg_hi) return fail(DESC_ERR_STATE, "piece %d out of the rank's range", pc);
+            int64_t bd = 0;
+            while (bd + 1 < nbands && P.bstart[bd + 1] <= pd.seg_lo) ++bd;
+            if (pd.seg_hi > P.bstart[bd + 1]) return fail(DESC_ERR_STATE, "piece %d straddles two bands", pc);
+            if (pd.row_lo != P.rowptr[P.band_lo[bd]] || pd.row_len != P.rowptr[P.band_lo[bd + 1]] - pd.row_lo || pd.row_len > BAND_ROW_CAP)
+                return fail(DESC_ERR_STATE, "piece %d carries the wrong band rows", pc);
+            for (int64_t q = pd.seg_lo; q < pd.seg_hi; ++q) {
+                const int32_t i = prob->ind_i[s->pos_edge[P.order[q]]];
+                if (i < P.band_lo[bd] || i >= P.band_lo[bd + 1]) return fail(DESC_ERR_STATE, "segment %lld is not in the band of its piece", (long long)q);
+                if (seen[q - seg_lo]++) return fail(DESC_ERR_STATE, "segment %lld is in two pieces", (long long)q);
+            }
+            cyc += P.cum2[pd.seg_hi] - P.cum2[pd.seg_lo];
+        }
+        wmax = std::max(wmax, cyc); wmin = std::min(wmin, cyc);
+    }
+    for (size_t q = 0; q < seen.size(); ++q) if (!seen[q]) return fail(DESC_ERR_STATE, "segment %lld is in no piece", (long long)(q + seg_lo));
+    stats[0] = nbands; stats[1] = (int64_t)pieces.size(); stats[2] = band_rows; stats[3] = wmax; stats[4] = wmin; stats[5] = jmajor ? 1 : 0;
+    stats[6] = seg_lo; stats[7] = seg_hi;
     return DESC_OK;
 }
 

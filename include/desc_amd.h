@@ -326,6 +326,11 @@ int desc_device_synchronize(int32_t device);
 int desc_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);
 int desc_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes);
 
+/* Test hook, host only (runs without a GPU): plans the band sweep of `rank` of `world` for `grid` workgroups and checks the plan's
+ * invariants.  stats: 8 values out (bands, pieces, largest band's row entries, max / min cycles per workgroup, j-block-major?,
+ * first / end segment of the rank). */
+int desc_debug_band_plan(const desc_problem* prob, const desc_structure* s, int32_t world, int32_t rank, int32_t grid, int64_t* stats);
+
 /* Test hook: sums `in` over aligned groups of G = 16/32/64 lanes with the kernels'
  * DPP / permlane-swap reduction; every element of a group receives the group total. */
 int desc_selftest_group_sum(const double* in, double* out, int32_t count, int32_t G, int32_t device);

@@ -268,3 +268,27 @@ def test_mex_shims_are_syntactically_valid_c(shim):
         pytest.skip("no gcc")
     subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Werror", "-fsyntax-only",
                            "-I", os.path.join(root, "tests", "mock_mex"), "-I", os.path.join(root, "include"), os.path.join(root, "matlab", shim)])
+
+
+@pytest.mark.parametrize("kind,n,p,world,grid,jm", [("uniform", 300, 0.5, 1, 256, "0"), ("uniform", 300, 0.5, 1, 256, "1"), ("uniform", 900, 0.12, 3, 64, "1"),
+                                                    ("nonuniform", 400, 0.3, 2, 256, "0"), ("uniform", 1500, 0.05, 1, 17, "1"), ("uniform", 60, 0.9, 1, 8, "1")])
+def test_band_sweep_work_plan_invariants(lib, kind, n, p, world, grid, jm, monkeypatch):
+    """Host-side plan of the band sweep (desc_debug_band_plan: bands sized for the LDS, ranks' ranges, pieces in contiguous
+    or j-block-major mode): every owned segment lies in exactly one piece, every piece inside one band with that band's rows,
+    and the per-workgroup cycle counts are balanced.  Runs without a GPU."""
+    monkeypatch.setenv("DESC_DEBUG_JMAJOR", jm)
+    monkeypatch.setenv("DESC_DEBUG_JBLOCK", "40")
+    mo, nn, ii, jj, _ = make_problem(kind, n=n, p=p, seed=n)
+    prob = lib.ProblemArrays(nn, ii, jj)
+    st = lib.Structure.build(prob, 30, 3)
+    covered = 0
+    for rank in range(world):
+        stats = np.zeros(8, dtype=np.int64)
+        lib.check(lib.load().desc_debug_band_plan(C.byref(prob.c), st.handle, world, rank, grid, lib.ptr(stats, lib.I64P)))
+        bands, pieces, rows, wmax, wmin, jmajor, seg_lo, seg_hi = stats
+        assert bands >= 1 and pieces >= 1 and 0 < rows <= 19200 and jmajor == int(jm)
+        assert seg_lo == covered
+        covered = seg_hi
+        if pieces >= 4 * grid or not jmajor:                      # enough units to balance (forced j-block mode on a tiny graph has few)
+            assert wmax <= 2.0 * max(wmin, 1) + 16384, (wmax, wmin)  # list scheduling / equal-cycle cuts: no starved or overloaded workgroup
+    assert covered == st.sizes()["m_pos"]
