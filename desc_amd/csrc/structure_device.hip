@@ -258,6 +258,10 @@ __global__ __launch_bounds__(256) void k_mirror(const int32_t* pos_edge, const i
     }
 }
 
+__global__ void k_iota(int32_t* p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = (int32_t)i;
+}
+
 struct DevBuf {
     std::vector<void*> p;
     ~DevBuf() { for (void* q : p) if (q) (void)hipFree(q); }
@@ -445,11 +449,19 @@ int build_cemp_samples_device(const desc_device_problem* dp, int32_t nsample, ui
     if (m > 0)
         hipLaunchKernelGGL(k_codeg, dim3((unsigned)std::min<int64_t>(2048, (m + 3) / 4)), dim3(256), 0, 0, d_ii, d_jj, d_bits, d_codeg, d_hist, m, (int)words, (int)(n + 1));
     DESC_HIP(hipGetLastError());
-    std::vector<int32_t> codeg((size_t)m), pos_edge;
-    if (m) DESC_HIP(hipMemcpy(codeg.data(), d_codeg, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+    // edges with cycles: the codegree histogram says how many have none.  Usually (dense measurement graphs) every edge lies
+    // on a triangle and pos_edge is the identity: filled on the device, no O(m) round trip through the host.
+    std::vector<int32_t> hist((size_t)n + 1), pos_edge;
+    DESC_HIP(hipMemcpy(hist.data(), d_hist, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost));
     int32_t max_codeg = 0;
-    for (int64_t e = 0; e < m; ++e) if (codeg[e] > 0) { pos_edge.push_back((int32_t)e); max_codeg = std::max(max_codeg, codeg[e]); }
-    const int64_t mp = (int64_t)pos_edge.size(), mc = mp * nsample;
+    for (int64_t c = 1; c <= n; ++c) if (hist[c]) max_codeg = (int32_t)c;
+    const bool all_pos = m > 0 && hist[0] == 0;
+    if (!all_pos) {
+        std::vector<int32_t> codeg((size_t)m);
+        if (m) DESC_HIP(hipMemcpy(codeg.data(), d_codeg, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+        for (int64_t e = 0; e < m; ++e) if (codeg[e] > 0) pos_edge.push_back((int32_t)e);
+    }
+    const int64_t mp = all_pos ? m : (int64_t)pos_edge.size(), mc = mp * nsample;
     if (mc >= (1ll << 31)) return fail(DESC_ERR_TOO_LARGE, "m_pos * nsample exceeds 2^31");
     if (max_codeg > 4 * MAX_CODEG_LDS) return fail(DESC_ERR_TOO_LARGE, "an edge has %d common neighbours: host sampler", max_codeg);
     *m_pos = mp;
@@ -464,7 +476,8 @@ int build_cemp_samples_device(const desc_device_problem* dp, int32_t nsample, ui
         for (int32_t** q : {o_pos, o_k, o_ejk, o_eki}) { if (*q) (void)hipFree(*q); *q = nullptr; }
         return rc;
     }
-    DESC_HIP(hipMemcpy(*o_pos, pos_edge.data(), sizeof(int32_t) * mp, hipMemcpyHostToDevice));
+    if (all_pos) hipLaunchKernelGGL(k_iota, dim3((unsigned)std::min<int64_t>(2048, (mp + 255) / 256)), dim3(256), 0, 0, *o_pos, mp);
+    else DESC_HIP(hipMemcpy(*o_pos, pos_edge.data(), sizeof(int32_t) * mp, hipMemcpyHostToDevice));
     int cap = 64;
     while (cap < max_codeg) cap <<= 1;
     const size_t lds = (size_t)4 * cap * 4;
