@@ -1987,7 +1987,8 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     if ((rc = upload(h, h->d_chunk_desc, chunk_desc.data(), chunk_desc.size()))) return rc;
     if ((rc = upload(h, h->d_rank_seg, rank_seg32.data(), rank_seg32.size()))) return rc;
     if ((rc = upload(h, d_pos_edge2, pos_edge2.data(), (size_t)mp))) return rc;
-    if (!shared_rij && (rc = upload(h, d_rij, prob->rij, 9 * (size_t)m))) return rc;
+    // (a synchronous copy from pageable memory runs 2-3x faster than an asynchronous one on this runtime)
+    if (!shared_rij && m) DESC_HIP(hipMemcpy(d_rij, prob->rij, sizeof(double) * 9 * (size_t)m, hipMemcpyHostToDevice));
     if (h->band_ok) {
         if ((rc = upload(h, h->d_pieces, pieces.data(), pieces.size()))) return rc;
         if ((rc = upload(h, h->d_piece_ptr, piece_ptr.data(), piece_ptr.size()))) return rc;

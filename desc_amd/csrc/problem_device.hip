@@ -1,6 +1,7 @@
 // desc_device_problem: the measurement graph resident in HBM, shared by every entry point of the library.
 // (Nothing in the reference corresponds to this: there, RijMat and Ind are MATLAB arrays every function indexes.)
 #include <chrono>
+#include <cstdlib>
 #include <new>
 #include <thread>
 #include <vector>
@@ -38,7 +39,14 @@ int desc_problem_upload(const desc_problem* prob, int32_t device, desc_device_pr
         build_csr(n, m, prob->ind_i, prob->ind_j, dp->rowptr, adj, adj_eid);
     });
     hipError_t e = hipSuccess;
+    // the caller's rotation array is pinned in place for the duration of the copy when it is large: a registered buffer is copied
+    // by DMA at PCIe speed, a pageable one is staged through the runtime's bounce buffers (DESC_UPLOAD_PIN=0 disables)
+    const char* pin_env = std::getenv("DESC_UPLOAD_PIN");
+    const bool pin = m >= (1 << 18) && !(pin_env && std::atoi(pin_env) == 0);
+    bool pinned = false;
+    if (pin) { pinned = hipHostRegister((void*)prob->rij, sizeof(double) * 9 * m, hipHostRegisterDefault) == hipSuccess; if (!pinned) (void)hipGetLastError(); }
     if (m) e = hipMemcpy(dp->d_rij, prob->rij, sizeof(double) * 9 * m, hipMemcpyHostToDevice);
+    if (pinned) (void)hipHostUnregister((void*)prob->rij);
     if (m && e == hipSuccess) e = hipMemcpy(dp->d_ii, prob->ind_i, sizeof(int32_t) * m, hipMemcpyHostToDevice);
     if (m && e == hipSuccess) e = hipMemcpy(dp->d_jj, prob->ind_j, sizeof(int32_t) * m, hipMemcpyHostToDevice);
     csr.join();
