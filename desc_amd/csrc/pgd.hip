@@ -9,9 +9,9 @@
 //   :208-230  per-edge simplex projection, new S_vec
 //   :232-257  average_change, objective, early stop (evaluated on the device)
 //
-// Two layouts of the same arithmetic (SWEEP VARIANTS):
+// Two layouts of the same arithmetic, three sweep kernels (SWEEP VARIANTS):
 //
-//  NODE (default).  Edges with cycles are stored band-major: nodes are cut into bands
+//  NODE layout (default).  Edges with cycles are stored band-major: nodes are cut into bands
 //  of B consecutive ids and the edges (i,j) of a band are ordered by (j,i), so that a
 //  run of consecutive segments shares j (its row of S stays in the CU's L1) while the
 //  band's i-rows stay in the XCD's L2.  S_vec is kept CSR-aligned (`Sfull`, every edge
@@ -24,8 +24,12 @@
 //  private copies, fixed order -> bitwise reproducible); k_sweep_node then needs no gather
 //  of w at all.
 //    HBM traffic per cycle and iteration: sweep 28 B (w r/w 16, S0 8, packed word 4)
-//    + column sums (w 8 + packed word 4 for the mirrored cycles only), plus the row
+//    + column sums (w 8 + a 2-byte column index for the mirrored cycles only), plus the row
 //    gathers of S served by L1/L2.
+//    Two sweeps run on this layout.  k_sweep_band (default since round 2, segments <= 64 cycles): bands sized so that their
+//    CSR rows fit the LDS of a CU, one 1024-thread workgroup per CU, S({k,i}) from the LDS, register-pipelined waves, work
+//    dealt in j-block-major units so that the rows of S({j,k}) stay in the L2s.  k_sweep_node (round 1; long segments, tiny
+//    graphs, the Adam plugin): L2-sized bands, 512-thread workgroups, chunks staged through the LDS.
 //
 //  GATHER (fallback: max degree >= 32768, more LDS than a workgroup may hold, or
 //  segments longer than 64 cycles).  Natural edge order; per cycle e_jk, e_ki, ikj, jki

@@ -62,3 +62,24 @@ def test_rotation_alignment_restatements_agree():
     R = spectral_oracle(mo.Ind, mo.RijMat)
     a = Rotation_Alignment(R, mo.R_orig); b = rotation_alignment(R, mo.R_orig)
     assert np.abs(a[0] - b[0]).max() < 1e-13 and abs(a[2] - b[2]) < 1e-10 and abs(a[3] - b[3]) < 1e-10
+
+
+def test_gcw_on_device_problem_matches_dense_oracle(oracle):
+    """desc_gcw_run_dev (what DESC() calls): weights 1/(S^1.5 + 1e-8) and weighted degrees formed on the device from S_vec, on a
+    device-resident problem shared with a Spectral call -- against the dense restatement of GCW.m and against the host-weights path."""
+    from desc_amd import _lib
+    from desc_amd.algorithms import marshal_edges
+    mo = Uniform_Topology(90, 0.5, 0.25, 0.1, "uniform", seed=8)
+    nn, ii, jj, rij, _ = marshal_edges(mo.Ind, mo.RijMat)
+    st = oracle.build_structure(nn, ii, jj, seed=0)
+    S = oracle.pgd_run(st, oracle.cycle_d(ii, jj, rij.reshape(-1, 9), st), 100, lr=0.01)["S_vec"]
+    dp = _lib.DeviceProblem(_lib.ProblemArrays(nn, ii, jj, rij), 0)
+    R, info = _lib.gcw_run(dp, S)
+    Rs, sinfo = _lib.spectral_run(dp)                               # the same resident problem serves Spectral
+    dp.free()
+    assert info["converged"] and sinfo["converged"]
+    R_ref = gcw_oracle(mo.Ind, mo.RijMat, S)
+    assert aligned_diff(R, R_ref)[0] < 1e-8
+    assert aligned_diff(Rs, spectral_oracle(mo.Ind, mo.RijMat))[0] < 1e-8
+    R_host = GCW(mo.Ind, mo.AdjMat, mo.RijMat, S)
+    assert aligned_diff(R, R_host)[0] < 1e-10

@@ -54,6 +54,13 @@ def test_no_gpu_fails_loudly(lib):
         lib.Solver(prob, st, 0)
     with pytest.raises(lib.DescError):
         DESC_PGD(mo.Ind, mo.RijMat, dict(iters=3, Gradient=ConstantStepSize(0.01), verbose=False))
+    with pytest.raises(lib.DescError):
+        lib.DeviceProblem(prob, 0)                        # the device-resident problem has no host stand-in either
+    from desc_amd import CEMP, DESC, Spectral
+    for call in (lambda: DESC(mo.Ind, mo.RijMat, dict(iters=3, Gradient=ConstantStepSize(0.01), verbose=False)),
+                 lambda: Spectral(mo.Ind, mo.RijMat), lambda: CEMP(mo.Ind, mo.RijMat, dict(max_iter=2, reweighting=[1.0], nsample=10))):
+        with pytest.raises(lib.DescError):
+            call()
 
 
 @pytest.mark.parametrize("kind,n,p", [("uniform", 35, 0.5), ("uniform", 130, 0.55), ("uniform", 400, 0.1), ("nonuniform", 90, 0.4)])
