@@ -1178,10 +1178,10 @@ __global__ __launch_bounds__(256) void k_midx_rowsum(const int32_t* rowptr, cons
         if (v < n && l16 == 0) rowsum[v] = (uint32_t)acc;
     }
 }
-// moff[t] = rowbase[v] + (entries of the earlier slots of row v); midx filled from the packed words.  16 lanes per row, each
-// walking one contiguous sixteenth of the row's slots (offsets by a 16-lane exclusive scan of the chunk totals)
-__global__ __launch_bounds__(256) void k_midx_fill(const int32_t* rowptr, const int2* adj_seg, const uint32_t* rowbase, const uint32_t* pk,
-                                                   uint32_t* moff, uint16_t* midx, int n) {
+// moff[t] = rowbase[v] + (entries of the earlier slots of row v).  16 lanes per row, each walking one contiguous sixteenth of
+// the row's slots (offsets by a 16-lane exclusive scan of the chunk totals)
+__global__ __launch_bounds__(256) void k_midx_fill(const int32_t* rowptr, const int2* adj_seg, const uint32_t* rowbase,
+                                                   uint32_t* moff, int n) {
     const int l16 = threadIdx.x & 15;
     const int row0 = (blockIdx.x * 256 + threadIdx.x) >> 4, nrows = (gridDim.x * 256) >> 4;
     for (int vb = row0 - (row0 % 4); vb < n; vb += nrows) {      // the 4 rows of a wave advance together (full-wave shuffles)
@@ -1198,19 +1198,24 @@ __global__ __launch_bounds__(256) void k_midx_fill(const int32_t* rowptr, const 
         for (int d = 1; d < 16; d <<= 1) { const int up = __shfl_up(incl, d, 16); if (l16 >= d) incl += up; }
         if (v >= n) continue;
         uint32_t o = rowbase[v] + (uint32_t)(incl - mine);
-        for (int t = t0; t < t1; ++t) {
-            const int2 rec = adj_seg[t];
-            const uint32_t cf = (uint32_t)rec.y;
-            const int n_both = cf & 0x1FFu, n_i = (cf >> 9) & 0x1FFu;
-            const bool v_is_i = cf & 0x80000000u;
-            const int nact = slot_nact(rec);
-            moff[t] = o;
-            for (int q = 0; q < nact; ++q) {
-                const int off = (v_is_i || q < n_both) ? q : n_i + (q - n_both);
-                const uint32_t p = pk[(int64_t)rec.x + off];
-                midx[(size_t)o + q] = (uint16_t)((v_is_i ? p : p >> 16) & 0x7FFFu);
-            }
-            o += (uint32_t)nact;
+        for (int t = t0; t < t1; ++t) { moff[t] = o; o += (uint32_t)slot_nact(adj_seg[t]); }
+    }
+}
+// ... and the entries themselves: 16 lanes per CSR slot, lanes over the slot's contributing cycles (coalesced both ways)
+__global__ __launch_bounds__(256) void k_midx_entries(const int2* adj_seg, const uint32_t* moff, const uint32_t* pk, uint16_t* midx, int64_t nslots) {
+    const int l16 = threadIdx.x & 15;
+    const int64_t g0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4, ng = ((int64_t)gridDim.x * 256) >> 4;
+    for (int64_t t = g0; t < nslots; t += ng) {
+        const int2 rec = adj_seg[t];
+        const uint32_t cf = (uint32_t)rec.y;
+        const int n_both = cf & 0x1FFu, n_i = (cf >> 9) & 0x1FFu;
+        const bool v_is_i = cf & 0x80000000u;
+        const int nact = slot_nact(rec);
+        const uint32_t o = moff[t];
+        for (int q = l16; q < nact; q += 16) {
+            const int off = (v_is_i || q < n_both) ? q : n_i + (q - n_both);
+            const uint32_t p = pk[(int64_t)rec.x + off];
+            midx[(size_t)o + q] = (uint16_t)((v_is_i ? p : p >> 16) & 0x7FFFu);
         }
     }
 }
@@ -2096,8 +2101,9 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         if (tot >= (1ull << 32)) return fail(DESC_ERR_TOO_LARGE, "column-index stream exceeds 2^32 entries");
         if ((rc = dalloc(h, &h->d_midx, (size_t)tot + 8))) return rc;
         if ((rc = upload(h, d_rowbase, rb.data(), (size_t)n))) return rc;
-        hipLaunchKernelGGL(k_midx_fill, dim3(g16), dim3(256), 0, h->stream,
-                           h->d_rowptr, h->d_adj_seg, d_rowbase, h->d_pk, h->d_moff, h->d_midx, (int)n);
+        hipLaunchKernelGGL(k_midx_fill, dim3(g16), dim3(256), 0, h->stream, h->d_rowptr, h->d_adj_seg, d_rowbase, h->d_moff, (int)n);
+        hipLaunchKernelGGL(k_midx_entries, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, (2 * m * 16 + 255) / 256))), dim3(256), 0, h->stream,
+                           h->d_adj_seg, h->d_moff, h->d_pk, h->d_midx, (int64_t)2 * m);
         DESC_HIP(hipStreamSynchronize(h->stream));
         dfree(h, d_rowsum); dfree(h, d_rowbase);
     }
