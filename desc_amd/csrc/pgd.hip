@@ -606,8 +606,9 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
                 if ((okm >> e) & 1u) a.w_new[(int64_t)a0 + r0.qb + r16 + LPS * e] = ws[e];
             if (cnt > 0 && r16 == 0) {
                 chg_acc += fabs(part - c.g.So);                                                      // :232
-                a.S_new[r0.sa] = part; a.S_new[r0.sb] = part;
+                // sharded runs: only the all-gather slice is written; k_unpack_S scatters S of every edge, this rank's included
                 if (a.s_slice) a.s_slice[r0.seg - a.t_seg_lo] = part;
+                else { a.S_new[r0.sa] = part; a.S_new[r0.sb] = part; }
             }
         }
         return o;
@@ -844,8 +845,8 @@ __global__ __launch_bounds__(BAND_THREADS, 1) void k_sweep_band(BandSweepArgs b)
                 }
             if (cnt > 0 && rr == 0) {
                 chg_acc += fabs(part - g.So);                                                            // :232
-                a.S_new[r.sa] = part; a.S_new[r.sb] = part;
-                if (a.s_slice) a.s_slice[r.seg - a.t_seg_lo] = part;
+                if (a.s_slice) a.s_slice[r.seg - a.t_seg_lo] = part;          // sharded: k_unpack_S scatters it (see k_sweep_node)
+                else { a.S_new[r.sa] = part; a.S_new[r.sb] = part; }
             }
         };
 
@@ -2676,8 +2677,8 @@ int desc_pgd_shard_iterate(desc_pgd* h, int32_t n_iters) {
         DESC_HIP(hipEventRecord(h->ev_sw, h->stream));
         DESC_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_sw, 0));
         if ((rc = shard_all_gather(h))) return rc;
-        // one rank: the sweep already wrote S of every edge; only the bookkeeping is left
-        if ((rc = shard_enqueue_unpack(h, h->comm_stream, h->world > 1 ? h->d_S[h->t_done & 1] : nullptr, nullptr, h->t_done, 0, h->last_parts))) return rc;
+        // one rank on the direct path: the sweep already wrote S of every edge; only the bookkeeping is left
+        if ((rc = shard_enqueue_unpack(h, h->comm_stream, shard_direct(h) ? nullptr : h->d_S[h->t_done & 1], nullptr, h->t_done, 0, h->last_parts))) return rc;
         DESC_HIP(hipEventRecord(h->ev_done, h->comm_stream));
     }
     return DESC_OK;
