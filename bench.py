@@ -193,6 +193,7 @@ def measure(lib, name, K, W, seed, convergence, keep_arrays, n_sample_min=30):
     # ---- end to end, really timed: one desc_pgd_solve call = structure build + upload + layout + S0_long +
     #      100 iterations + download (what DESC_PGD() / the MEX shim pay per call in a warm process)
     pe = lib.default_params(); pe.iters = 100; pe.lr = 0.01; pe.seed = seed; pe.patience = (1 << 31) - 1; pe.n_sample_min = n_sample_min
+    lib.trim_memory()                   # the blocks parked by the handle above go back to the driver: this call allocates afresh
     t0 = time.perf_counter()
     e2e = lib.solve(prob, pe)
     t_e2e = time.perf_counter() - t0

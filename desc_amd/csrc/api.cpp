@@ -129,6 +129,8 @@ int desc_structure_sizes(const desc_structure* s, desc_structure_info* info) {
 }
 
 void desc_structure_free(desc_structure* s) { if (s) { structure_free_device(s); delete s; } }
+// (Releasing the host side -- tens of megabytes of index vectors, 10+ ms of page-table work at C4 -- on a background thread was
+//  tried: it contends with the launching thread for the process's memory map and the PGD loop that follows lost what it saved.)
 
 int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* r) {
     if (!p || !r) return fail(DESC_ERR_INVALID, "NULL argument");

@@ -108,10 +108,10 @@ __global__ void k_fill1(double* p, int64_t n, double v) {
 
 struct DevC {
     std::vector<void*> p;
-    ~DevC() { for (void* q : p) if (q) (void)hipFree(q); }
+    ~DevC() { for (void* q : p) dev_free(q); }
     template <class T> int alloc(T** out, size_t count) {
         void* q = nullptr;
-        DESC_HIP(hipMalloc(&q, sizeof(T) * (count ? count : 1)));
+        DESC_HIP(dev_alloc(&q, sizeof(T) * (count ? count : 1)));
         p.push_back(q); *out = (T*)q;
         return DESC_OK;
     }
@@ -146,7 +146,7 @@ extern "C" int desc_cemp_run_dev(const desc_device_problem* dp, const double* be
     // samples: on the device; graphs beyond the device sampler's staging budget fall back to the host sampler
     int64_t mp = 0;
     int32_t *d_pos = nullptr, *d_k = nullptr, *d_ejk = nullptr, *d_eki = nullptr;
-    struct Owned { int32_t **a, **b, **c, **d; ~Owned() { for (int32_t** q : {a, b, c, d}) if (*q) (void)hipFree(*q); } } owned{&d_pos, &d_k, &d_ejk, &d_eki};
+    struct Owned { int32_t **a, **b, **c, **d; ~Owned() { for (int32_t** q : {a, b, c, d}) if (*q) dev_free(*q); } } owned{&d_pos, &d_k, &d_ejk, &d_eki};
     rc = build_cemp_samples_device(dp, nsample, seed, &mp, &d_pos, &d_k, &d_ejk, &d_eki);
     if (rc == DESC_ERR_TOO_LARGE) {
         std::vector<int32_t> pos_edge, kk, e_jk, e_ki;
@@ -156,8 +156,8 @@ extern "C" int desc_cemp_run_dev(const desc_device_problem* dp, const double* be
         const int64_t mch = mp * nsample;
         if (mch >= (1ll << 31)) return fail(DESC_ERR_TOO_LARGE, "m_pos * nsample exceeds 2^31");
         if (mp) {
-            DESC_HIP(hipMalloc((void**)&d_pos, sizeof(int32_t) * mp)); DESC_HIP(hipMalloc((void**)&d_k, sizeof(int32_t) * mch));
-            DESC_HIP(hipMalloc((void**)&d_ejk, sizeof(int32_t) * mch)); DESC_HIP(hipMalloc((void**)&d_eki, sizeof(int32_t) * mch));
+            DESC_HIP(dev_alloc((void**)&d_pos, sizeof(int32_t) * mp)); DESC_HIP(dev_alloc((void**)&d_k, sizeof(int32_t) * mch));
+            DESC_HIP(dev_alloc((void**)&d_ejk, sizeof(int32_t) * mch)); DESC_HIP(dev_alloc((void**)&d_eki, sizeof(int32_t) * mch));
             DESC_HIP(hipMemcpy(d_pos, pos_edge.data(), sizeof(int32_t) * mp, hipMemcpyHostToDevice));
             DESC_HIP(hipMemcpy(d_k, kk.data(), sizeof(int32_t) * mch, hipMemcpyHostToDevice));
             DESC_HIP(hipMemcpy(d_ejk, e_jk.data(), sizeof(int32_t) * mch, hipMemcpyHostToDevice));

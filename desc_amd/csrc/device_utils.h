@@ -15,6 +15,10 @@
 
 namespace desc {
 
+// device memory through the library's block cache (devmem.hip): same contract as hipMalloc / hipFree
+hipError_t dev_alloc(void** out, size_t bytes);
+void dev_free(void* p);
+
 // One DPP-moved copy of a double (two 32-bit v_mov_b32_dpp).  All four controls used
 // here are permutations of the full wave, so every lane is written and no `old` value
 // has to be preserved (mov_dpp leaves it undefined: no extra register copy).

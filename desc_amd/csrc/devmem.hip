@@ -1,0 +1,107 @@
+// Device-memory cache of libdesc_amd.so.  hipFree of the large per-call arrays (sampled cycles, weights, packed words: hundreds of
+// megabytes to gigabytes) costs 5-15 ms per solve in page-table work, hipMalloc of the same sizes again on the next call; a
+// MATLAB / Python session calls DESC_PGD many times on problems of the same shape.  Blocks are therefore parked on release and
+// handed out again (best fit, at most 25 % larger than asked) instead of going back to the driver, up to DESC_CACHE_MB
+// (default 8192) per process; desc_trim_memory() returns everything parked to the driver.
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "device_utils.h"
+
+namespace desc {
+namespace {
+struct Block { void* p; size_t bytes; int dev; };
+std::mutex g_mu;
+std::vector<Block> g_parked;                         // released blocks waiting for reuse
+std::unordered_map<void*, Block> g_live;             // blocks handed out
+size_t g_parked_bytes = 0;
+size_t cache_cap() {
+    static size_t cap = [] { const char* e = std::getenv("DESC_CACHE_MB"); return (size_t)(e ? std::atoll(e) : 8192) << 20; }();
+    return cap;
+}
+}  // namespace
+
+hipError_t dev_alloc(void** out, size_t bytes) {
+    *out = nullptr;
+    if (bytes == 0) bytes = 8;
+    bytes = (bytes + 255) & ~(size_t)255;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        size_t best = (size_t)-1; size_t bi = 0;
+        for (size_t i = 0; i < g_parked.size(); ++i) {
+            const Block& b = g_parked[i];
+            if (b.dev == dev && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 + 4096 && b.bytes < best) { best = b.bytes; bi = i; }
+        }
+        if (best != (size_t)-1) {
+            const Block b = g_parked[bi];
+            g_parked[bi] = g_parked.back(); g_parked.pop_back();
+            g_parked_bytes -= b.bytes;
+            g_live[b.p] = b;
+            *out = b.p;
+            return hipSuccess;
+        }
+    }
+    void* p = nullptr;
+    e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {                            // make room: give the parked blocks back and try once more
+        (void)hipGetLastError();
+        desc_trim_memory();
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_live[p] = Block{p, bytes, dev};
+    *out = p;
+    return hipSuccess;
+}
+
+void dev_free(void* p) {
+    if (!p) return;
+    // hipFree waits for the device before it releases a block; a parked block may be handed out again at once, so the same
+    // guarantee is kept here (idle device: microseconds)
+    (void)hipDeviceSynchronize();
+    Block b{};
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_live.find(p);
+        if (it == g_live.end()) { (void)hipFree(p); return; }         // not ours (should not happen)
+        b = it->second;
+        g_live.erase(it);
+        if (g_parked_bytes + b.bytes <= cache_cap()) {
+            g_parked.push_back(b); g_parked_bytes += b.bytes;
+            return;
+        }
+    }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != b.dev) (void)hipSetDevice(b.dev);
+    (void)hipFree(p);
+    if (cur != b.dev) (void)hipSetDevice(cur);
+}
+
+}  // namespace desc
+
+extern "C" int64_t desc_trim_memory(void) {
+    std::vector<desc::Block> blocks;
+    {
+        std::lock_guard<std::mutex> lk(desc::g_mu);
+        blocks.swap(desc::g_parked);
+        desc::g_parked_bytes = 0;
+    }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    int64_t freed = 0;
+    for (const desc::Block& b : blocks) {
+        (void)hipSetDevice(b.dev);
+        (void)hipFree(b.p);
+        freed += (int64_t)b.bytes;
+    }
+    (void)hipSetDevice(cur);
+    return freed;
+}

@@ -1423,7 +1423,7 @@ template <class T>
 int dalloc(desc_pgd* h, T** p, size_t count) {
     *p = nullptr;
     void* q = nullptr;
-    DESC_HIP(hipMalloc(&q, sizeof(T) * (count > 0 ? count : 1)));
+    DESC_HIP(dev_alloc(&q, sizeof(T) * (count > 0 ? count : 1)));
     h->allocs.push_back(q);
     *p = (T*)q;
     return DESC_OK;
@@ -1431,7 +1431,7 @@ int dalloc(desc_pgd* h, T** p, size_t count) {
 void dfree(desc_pgd* h, void* q) {
     if (!q) return;
     for (auto& x : h->allocs) if (x == q) { x = nullptr; break; }
-    (void)hipFree(q);
+    dev_free(q);
 }
 
 int set_device(const desc_pgd* h) { DESC_HIP(hipSetDevice(h->device)); return DESC_OK; }
@@ -1440,7 +1440,7 @@ int64_t local_cycles(const desc_pgd* h) { return h->variant == VARIANT_NODE ? h-
 void free_all(desc_pgd* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    for (void* q : h->allocs) if (q) (void)hipFree(q);
+    for (void* q : h->allocs) dev_free(q);
     for (hipEvent_t e : {h->ev_col, h->ev_rs, h->ev_sw, h->ev_done}) if (e) (void)hipEventDestroy(e);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     if (h->stream && !h->borrowed_stream) (void)hipStreamDestroy(h->stream);

@@ -27,7 +27,7 @@ int desc_problem_upload(const desc_problem* prob, int32_t device, desc_device_pr
     dp->device = device; dp->n = prob->n; dp->m = prob->m;
     const int64_t n = dp->n, m = dp->m;
     auto bail = [&](int code) { desc_problem_free(dp); return code; };
-    auto A = [&](void** q, size_t bytes) { return hipMalloc(q, bytes ? bytes : 8) == hipSuccess; };
+    auto A = [&](void** q, size_t bytes) { return dev_alloc(q, bytes) == hipSuccess; };
     if (!A((void**)&dp->d_ii, sizeof(int32_t) * m) || !A((void**)&dp->d_jj, sizeof(int32_t) * m) || !A((void**)&dp->d_rowptr, sizeof(int32_t) * (n + 1)) ||
         !A((void**)&dp->d_adj, sizeof(int32_t) * 2 * m) || !A((void**)&dp->d_adj_eid, sizeof(int32_t) * 2 * m) || !A((void**)&dp->d_rij, sizeof(double) * 9 * m))
         return bail(fail(DESC_ERR_HIP, "out of device memory for the problem (m = %lld)", (long long)m));
@@ -63,7 +63,7 @@ void desc_problem_free(desc_device_problem* dp) {
     if (!dp) return;
     (void)hipSetDevice(dp->device);
     for (void* q : {(void*)dp->d_ii, (void*)dp->d_jj, (void*)dp->d_rowptr, (void*)dp->d_adj, (void*)dp->d_adj_eid, (void*)dp->d_rij})
-        if (q) (void)hipFree(q);
+        dev_free(q);
     delete dp;
 }
 

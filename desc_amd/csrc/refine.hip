@@ -323,10 +323,10 @@ int device_quantile(const double* d_x, int64_t m, double p, double* d_mm, unsign
 
 struct DevR {
     std::vector<void*> p;
-    ~DevR() { for (void* q : p) if (q) (void)hipFree(q); }
+    ~DevR() { for (void* q : p) dev_free(q); }
     template <class T> int alloc(T** out, size_t count) {
         void* q = nullptr;
-        DESC_HIP(hipMalloc(&q, sizeof(T) * (count ? count : 1)));
+        DESC_HIP(dev_alloc(&q, sizeof(T) * (count ? count : 1)));
         p.push_back(q); *out = (T*)q;
         return DESC_OK;
     }

@@ -252,10 +252,10 @@ void project_so3(const double* M, double* R) {
 
 struct Dev {
     std::vector<void*> p;
-    ~Dev() { for (void* q : p) if (q) (void)hipFree(q); }
+    ~Dev() { for (void* q : p) dev_free(q); }
     template <class T> int alloc(T** out, size_t count) {
         void* q = nullptr;
-        DESC_HIP(hipMalloc(&q, sizeof(T) * (count ? count : 1)));
+        DESC_HIP(dev_alloc(&q, sizeof(T) * (count ? count : 1)));
         p.push_back(q); *out = (T*)q;
         return DESC_OK;
     }

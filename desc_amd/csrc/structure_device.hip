@@ -264,10 +264,10 @@ __global__ void k_iota(int32_t* p, int64_t n) {
 
 struct DevBuf {
     std::vector<void*> p;
-    ~DevBuf() { for (void* q : p) if (q) (void)hipFree(q); }
+    ~DevBuf() { for (void* q : p) dev_free(q); }
     template <class T> int alloc(T** out, size_t count) {
         void* q = nullptr;
-        DESC_HIP(hipMalloc(&q, sizeof(T) * (count ? count : 1)));
+        DESC_HIP(dev_alloc(&q, sizeof(T) * (count ? count : 1)));
         p.push_back(q); *out = (T*)q;
         return DESC_OK;
     }
@@ -306,7 +306,7 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
     // device arrays that outlive this call are owned by the structure object (structure_free_device)
     auto keep = [&](auto** out, size_t count) -> int {
         void* q = nullptr;
-        DESC_HIP(hipMalloc(&q, sizeof(**out) * (count ? count : 1)));
+        DESC_HIP(dev_alloc(&q, sizeof(**out) * (count ? count : 1)));
         *out = (std::remove_reference_t<decltype(*out)>)q;
         return DESC_OK;
     };
@@ -468,12 +468,12 @@ int build_cemp_samples_device(const desc_device_problem* dp, int32_t nsample, ui
     if (mp == 0) return DESC_OK;
     auto keep = [&](int32_t** out, size_t count) -> int {
         void* q = nullptr;
-        DESC_HIP(hipMalloc(&q, sizeof(int32_t) * (count ? count : 1)));
+        DESC_HIP(dev_alloc(&q, sizeof(int32_t) * (count ? count : 1)));
         *out = (int32_t*)q;
         return DESC_OK;
     };
     if ((rc = keep(o_pos, mp)) || (rc = keep(o_k, mc)) || (rc = keep(o_ejk, mc)) || (rc = keep(o_eki, mc))) {
-        for (int32_t** q : {o_pos, o_k, o_ejk, o_eki}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+        for (int32_t** q : {o_pos, o_k, o_ejk, o_eki}) { if (*q) dev_free(*q); *q = nullptr; }
         return rc;
     }
     if (all_pos) hipLaunchKernelGGL(k_iota, dim3((unsigned)std::min<int64_t>(2048, (mp + 255) / 256)), dim3(256), 0, 0, *o_pos, mp);
@@ -522,7 +522,7 @@ void structure_free_device(desc_structure* s) {
     (void)hipSetDevice(s->dev);
     for (void* q : {(void*)s->d_k, (void*)s->d_tau, (void*)s->d_ktau, (void*)s->d_rowptr, (void*)s->d_adj, (void*)s->d_adj_eid, (void*)s->d_ii,
                     (void*)s->d_jj, (void*)s->d_pos, (void*)s->d_cum, (void*)s->d_poe, (void*)s->d_bits, (void*)s->d_rank})
-        if (q) (void)hipFree(q);
+        dev_free(q);
     s->d_k = nullptr; s->d_tau = nullptr; s->d_ktau = nullptr; s->d_bits = nullptr; s->d_rank = nullptr;
     s->d_rowptr = s->d_adj = s->d_adj_eid = s->d_ii = s->d_jj = s->d_pos = s->d_cum = s->d_poe = nullptr;
     s->dev = -1;

@@ -319,6 +319,11 @@ int desc_refine_run_dev(const desc_device_problem* dp, const double* s_vec, cons
  * uploads, runs, downloads, frees. */
 int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* r);
 
+/* The library parks the device blocks of destroyed handles / structures / problems for reuse by the next call (up to
+ * DESC_CACHE_MB megabytes per process, default 8192: hipFree + hipMalloc of the gigabyte-sized per-cycle arrays cost 10-20 ms
+ * per solve).  desc_trim_memory returns everything parked to the driver; result: bytes released. */
+int64_t desc_trim_memory(void);
+
 /* Binding utilities: synchronous copies between host memory and device memory of the library's own HIP runtime
  * (a binding that implements the collectives itself, e.g. staged through host memory, must not load a second
  * runtime), after draining every stream of `device`. */
