@@ -464,3 +464,17 @@ def test_make_plots_traces(lib):
     assert info["svec_errors"][-1] < info["svec_errors"][0]
     with pytest.raises(ValueError):
         DESC_PGD(mo.Ind, mo.RijMat, dict(base, make_plots=True))          # ErrVec / R_orig are read when plotting (:236-238)
+
+
+def test_device_block_cache(lib, oracle):
+    """The blocks of a destroyed handle / structure are parked for the next call (devmem.hip) and given back by
+    desc_trim_memory; a second solve out of parked blocks gives bitwise the same answer."""
+    mo, nn, ii, jj, rij = make_problem("uniform", n=150, p=0.5, q=0.3, sigma=0.1, seed=8)
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    lib.trim_memory()
+    a = lib.solve(prob, c_params(20, lr=0.01, seed=4))
+    b = lib.solve(prob, c_params(20, lr=0.01, seed=4))             # runs out of the blocks the first call released
+    assert np.array_equal(a["S_vec"], b["S_vec"]) and np.array_equal(a["obj"], b["obj"])
+    assert lib.trim_memory() > 0 and lib.trim_memory() == 0
+    c = lib.solve(prob, c_params(20, lr=0.01, seed=4))
+    assert np.array_equal(a["S_vec"], c["S_vec"])
