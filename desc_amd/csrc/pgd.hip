@@ -674,7 +674,6 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
 #ifndef DESC_BAND_ABLATE            // diagnostic builds only (tools/build_ablate.sh): 1 S({j,k}) from the LDS too, 2 no arithmetic,
 #define DESC_BAND_ABLATE 0          // 4 one threshold pass, 8 no stores, 16 no LDS gathers, 32 no T1/T2 loads, 64 S({j,k}) rows confined to 1 MiB
 #endif
-constexpr int BAND_THREADS = 1024;
 constexpr int BAND_ROW_CAP = 19200;          // doubles of LDS for the band rows (150 KiB of the CU's 160 KiB)
 struct alignas(16) PieceDesc { int32_t row_lo, row_len, seg_lo, seg_hi; };   // CSR slots of the band, device-order segments
 
@@ -698,16 +697,18 @@ __device__ __forceinline__ EdgeInfo uniform_load_einfo(const EdgeInfo* p, int i)
     return EdgeInfo{v.x, v.y, v.z, v.w};
 }
 
-template <int LPS, int E, int STEP>
-__global__ __launch_bounds__(BAND_THREADS, 1) void k_sweep_band(BandSweepArgs b) {
+template <int LPS, int E, int STEP, int NT>
+__global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
     extern __shared__ double s_dyn[];                  // [row_cap] band rows of S_old, then the nv table
     const NodeSweepArgs& a = b.n;
     double* s_rows = s_dyn;
     double* s_nv = s_dyn + b.row_cap;
-    __shared__ double s_part[2][BAND_THREADS / 64];
-    static_assert((LPS == 16 || LPS == 32) && LPS * E <= 64 && STEP != DESC_STEP_HYBRID, "segments of up to 64 cycles; Adam runs on k_sweep_node");
+    __shared__ double s_part[2][NT / 64];
+    // segments of up to 64 cycles: 1024 threads (16 waves, <= 128 VGPRs each); up to 256 cycles (4 cycles per lane: twice the
+    // registers per pipeline stage): 512 threads (8 waves, <= 256 VGPRs).  Adam runs on k_sweep_node.
+    static_assert((LPS == 16 || LPS == 32 || LPS == 64) && LPS * E <= MAX_SEG_CYCLES && STEP != DESC_STEP_HYBRID && (NT == 512 || NT == 1024), "band sweep instances");
     if (a.state->stop) return;
-    constexpr int NW = BAND_THREADS / 64, SPW = 64 / LPS;
+    constexpr int NW = NT / 64, SPW = 64 / LPS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = lane / LPS, rr = lane % LPS;
@@ -858,12 +859,12 @@ __global__ __launch_bounds__(BAND_THREADS, 1) void k_sweep_band(BandSweepArgs b)
         { const RecRaw q = load_raw(2); R2 = land(q); S2 = load_stream(R2); }
         Q = load_raw(3);
         // the band's rows of S_old -> LDS, while the first streams are in flight
-        for (int base = 0; base < pd.row_len; base += 8 * BAND_THREADS) {     // 8 independent loads in flight per thread
+        for (int base = 0; base < pd.row_len; base += 8 * NT) {     // 8 independent loads in flight per thread
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = a.S_old[pd.row_lo + min(base + u * BAND_THREADS + tid, pd.row_len - 1)];
+            for (int u = 0; u < 8; ++u) v[u] = a.S_old[pd.row_lo + min(base + u * NT + tid, pd.row_len - 1)];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (base + u * BAND_THREADS + tid < pd.row_len) s_rows[base + u * BAND_THREADS + tid] = v[u];
+            for (int u = 0; u < 8; ++u) if (base + u * NT + tid < pd.row_len) s_rows[base + u * NT + tid] = v[u];
         }
         __syncthreads();
         G0 = issue_gathers(R0, S0);
@@ -1513,13 +1514,24 @@ void launch_node(desc_pgd* h, const NodeSweepArgs& a) {
     }
 }
 
+const void* band_kernel(const desc_pgd* h) {
+    switch (h->lps * 8 + h->G) {
+        case 16 * 8 + 1: return (const void*)k_sweep_band<16, 1, DESC_STEP_CONSTANT, 1024>;
+        case 16 * 8 + 2: return (const void*)k_sweep_band<16, 2, DESC_STEP_CONSTANT, 1024>;
+        case 32 * 8 + 2: return (const void*)k_sweep_band<32, 2, DESC_STEP_CONSTANT, 1024>;
+        case 32 * 8 + 4: return (const void*)k_sweep_band<32, 4, DESC_STEP_CONSTANT, 512>;
+        default: return (const void*)k_sweep_band<64, 4, DESC_STEP_CONSTANT, 512>;
+    }
+}
 void launch_band(desc_pgd* h, const NodeSweepArgs& a) {
     BandSweepArgs b{a, h->d_pieces, h->d_piece_ptr, h->band_rows};
-    dim3 grid(h->band_grid), block(BAND_THREADS);
+    dim3 grid(h->band_grid);
     switch (h->lps * 8 + h->G) {
-        case 16 * 8 + 1: hipLaunchKernelGGL((k_sweep_band<16, 1, DESC_STEP_CONSTANT>), grid, block, h->band_lds, h->stream, b); break;
-        case 16 * 8 + 2: hipLaunchKernelGGL((k_sweep_band<16, 2, DESC_STEP_CONSTANT>), grid, block, h->band_lds, h->stream, b); break;
-        default: hipLaunchKernelGGL((k_sweep_band<32, 2, DESC_STEP_CONSTANT>), grid, block, h->band_lds, h->stream, b); break;
+        case 16 * 8 + 1: hipLaunchKernelGGL((k_sweep_band<16, 1, DESC_STEP_CONSTANT, 1024>), grid, dim3(1024), h->band_lds, h->stream, b); break;
+        case 16 * 8 + 2: hipLaunchKernelGGL((k_sweep_band<16, 2, DESC_STEP_CONSTANT, 1024>), grid, dim3(1024), h->band_lds, h->stream, b); break;
+        case 32 * 8 + 2: hipLaunchKernelGGL((k_sweep_band<32, 2, DESC_STEP_CONSTANT, 1024>), grid, dim3(1024), h->band_lds, h->stream, b); break;
+        case 32 * 8 + 4: hipLaunchKernelGGL((k_sweep_band<32, 4, DESC_STEP_CONSTANT, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
+        default: hipLaunchKernelGGL((k_sweep_band<64, 4, DESC_STEP_CONSTANT, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
     }
 }
 // workgroups (= partial pairs) of the sweep kernel that serves this step kind
@@ -1825,7 +1837,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     }
     // (tiny problems stay on k_sweep_node: with < 2 M cycles a 1024-thread workgroup per CU is mostly pipeline fill -- C1: 31 vs 20 us)
     const int force_band = env_int("DESC_DEBUG_VARIANT", 0);
-    h->band_ok = force_band != VARIANT_NODE && h->max_cnt <= 64 && h->max_deg <= BAND_ROW_CAP && (h->m_cycle >= (2 << 20) || force_band == 3);
+    h->band_ok = force_band != VARIANT_NODE && h->max_cnt <= MAX_SEG_CYCLES && h->max_deg <= BAND_ROW_CAP && (h->m_cycle >= (2 << 20) || force_band == 3);
     if ((rc = make_node_plan(prob, s, h->max_deg, h->world, h->max_cnt <= 32 ? 32 : h->max_cnt <= 128 ? 16 : 8, h->band_ok ? BAND_ROW_CAP : 0, P))) return rc;   // 8 waves x 64/lps segments
     h->band = P.band;
     lap("plan");
@@ -2046,8 +2058,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     }
     if (h->band_ok) {      // the band rows + the nv table in dynamic LDS: more than the 64 KiB default
         h->band_lds = ((size_t)h->band_rows + MAX_SEG_CYCLES + 1) * sizeof(double);
-        const void* kb = h->lps == 16 ? (h->G == 1 ? (const void*)k_sweep_band<16, 1, DESC_STEP_CONSTANT> : (const void*)k_sweep_band<16, 2, DESC_STEP_CONSTANT>)
-                                      : (const void*)k_sweep_band<32, 2, DESC_STEP_CONSTANT>;
+        const void* kb = band_kernel(h);
         if (hipFuncSetAttribute(kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->band_lds) != hipSuccess) { (void)hipGetLastError(); h->band_ok = false; }
     }
     char nm[64];

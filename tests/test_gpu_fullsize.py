@@ -128,7 +128,7 @@ def test_full_size_properties_large(lib, name, iters):
 def test_full_size_unsampled_c5(lib):
     """BASELINE configs[4] in its unsampled reading: n = 10000, p = 0.1, every triangle swept (n_sample above every
     codegree, DESC_PGD.m:43-45 never samples): ~1.67e8 triangles = 5e8 edge-cycle slots, segments of up to ~150 cycles
-    (k_sweep_node with 32 or 64 lanes x 4 cycles; the band sweep takes segments <= 64).  Properties: every mirror is
+    (the band sweep's 512-thread instance, 64 lanes x 4 cycles).  Properties: every mirror is
     present, weights on the simplex, S in [0,1], objective decreasing, bitwise reproducible, one Jacobi step restated in
     NumPy on random segments, accuracy against the ground truth at the patience exit."""
     mo, nn, ii, jj, rij = bench.generate("C5")
@@ -138,7 +138,7 @@ def test_full_size_unsampled_c5(lib):
     assert sz["m_cycle"] > 4.5e8 and sz["m_cycle"] % 3 == 0 and 64 < sz["max_cnt"] <= 256
     iters = 4
     solver = lib.Solver(prob, st, 0)
-    assert "node" in solver.kernel_name()
+    assert "band<64,4" in solver.kernel_name()
     d = solver.s0()
     node = solver.run(c_params(iters, lr=0.01, seed=0), want_w=True)
     prev = solver.run(c_params(iters - 1, lr=0.01, seed=0), want_w=True)

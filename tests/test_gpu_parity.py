@@ -84,7 +84,7 @@ def test_long_segments(lib, oracle, variant):
     st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=3, iters=25, lr=0.01)
     assert st["n_sample"] > 64
     arrays, s0, out = run_gpu(lib, nn, ii, jj, rij, c_params(25, lr=0.01, seed=3), variant=variant)
-    assert ("node<32,4" in out["kernel"]) if variant != "gather" else ("big" in out["kernel"])    # band sweep: segments <= 64 only
+    assert {"band": "band<32,4", "node": "node<32,4", "gather": "big"}[variant] in out["kernel"]
     check(out, ref, s0, S0)
 
 
@@ -103,16 +103,22 @@ def test_segments_up_to_256_cycles(lib, oracle, n, p, nmin, kind, kern, where):
     assert 64 < mx <= 256
     prob = lib.ProblemArrays(nn, ii, jj, rij)
     dst = lib.Structure.build(prob, nmin, 9, lib.BUILD_DEVICE if where == "device" else lib.BUILD_HOST, 0)
-    solver = lib.Solver(prob, dst, 0)
-    try:
-        assert kern in solver.kernel_name()
-        s0 = solver.s0()
-        out = solver.run(c_params(30, seed=9, **step), want_w=True)
-    finally:
-        solver.destroy()
+    for forced in (None, "3"):                      # default (tiny graph: k_sweep_node) and the band sweep's 512-thread instances
+        if forced:
+            os.environ["DESC_DEBUG_VARIANT"] = forced
+        try:
+            solver = lib.Solver(prob, dst, 0)
+            try:
+                assert (kern.replace("node", "band") if forced and kind != 2 else kern.split("<")[1]) in solver.kernel_name()
+                s0 = solver.s0()
+                out = solver.run(c_params(30, seed=9, **step), want_w=True)
+            finally:
+                solver.destroy()
+        finally:
+            os.environ.pop("DESC_DEBUG_VARIANT", None)
+        check(out, ref, s0, S0, tol=1e-9 if kind == 2 else TOL)
     assert_structure_equal(dst.arrays(), st)
     dst.free()
-    check(out, ref, s0, S0, tol=1e-9 if kind == 2 else TOL)
 
 
 def test_segments_longer_than_256_fall_back(lib, oracle):
