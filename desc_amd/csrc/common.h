@@ -34,6 +34,7 @@ struct desc_structure {
     int32_t n_sample = 0, max_cnt = 0;
     std::vector<int32_t> codeg, pos_edge;
     std::vector<int64_t> cum_ind;
+    std::vector<int32_t> rowptr_host;                // CSR row starts of the graph, when the builder made them (device builder)
     std::vector<int32_t> k, e_jk, e_ki, ikj, jki;   // per-cycle arrays on the host (valid iff host_cycles)
     double ms_build = 0.0;
     // A structure built on the device stays there in a lean form: the sampled third vertices `k`

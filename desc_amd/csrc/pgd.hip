@@ -1666,9 +1666,12 @@ struct NodePlan {
 int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_deg, int world, int max_seg, int row_cap, NodePlan& P) {
     const int64_t mp = s->m_pos, n = prob->n, m = prob->m;
     const int32_t* ii = prob->ind_i; const int32_t* jj = prob->ind_j; const int32_t* pe = s->pos_edge.data();
-    P.rowptr.assign((size_t)n + 1, 0);
-    for (int64_t e = 0; e < m; ++e) { P.rowptr[ii[e] + 1]++; P.rowptr[jj[e] + 1]++; }
-    for (int64_t v = 0; v < n; ++v) P.rowptr[v + 1] += P.rowptr[v];
+    if ((int64_t)s->rowptr_host.size() == n + 1) P.rowptr = s->rowptr_host;      // the device builder already made them
+    else {
+        P.rowptr.assign((size_t)n + 1, 0);
+        for (int64_t e = 0; e < m; ++e) { P.rowptr[ii[e] + 1]++; P.rowptr[jj[e] + 1]++; }
+        for (int64_t v = 0; v < n; ++v) P.rowptr[v + 1] += P.rowptr[v];
+    }
     P.band_lo.clear();
     if (row_cap > 0) {
         P.band = 0;

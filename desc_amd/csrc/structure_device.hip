@@ -328,6 +328,7 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
         DESC_HIP(hipMemcpy(s->d_ii, prob->ind_i, sizeof(int32_t) * m, hipMemcpyHostToDevice));
         DESC_HIP(hipMemcpy(s->d_jj, prob->ind_j, sizeof(int32_t) * m, hipMemcpyHostToDevice));
     }
+    s->rowptr_host = std::move(rowptr);               // the solver's host-side plan needs the row starts again
     lap("alloc+upload");
     DESC_HIP(hipMemset(d_bits, 0, sizeof(unsigned long long) * (size_t)n * words));
     DESC_HIP(hipMemset(d_hist, 0, sizeof(int32_t) * (n + 1)));
