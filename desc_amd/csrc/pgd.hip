@@ -1771,7 +1771,14 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
     } else {
         const int64_t avg_deg = std::max<int64_t>(1, 2 * m / std::max<int64_t>(1, n));
         int64_t JB = env_int("DESC_DEBUG_JBLOCK", 0);
-        if (JB <= 0) JB = std::max<int64_t>(32, (3ll << 19) / (8 * avg_deg));
+        if (JB <= 0) {
+            // rows of a j-block ~1.5 MiB (they share an XCD's 4 MiB L2 with the streams), but wide enough that a unit streams
+            // >= 32 K cycles for the ~150 KB of band rows it loads (sparse graphs with short segments: C5 0.55 -> 0.60), up to 4 MiB
+            const int64_t jb_l2 = std::max<int64_t>(32, (3ll << 19) / (8 * avg_deg));
+            const double cyc_per_pair = (double)mcl / std::max(1.0, 0.5 * (double)nbands * (double)n);     // cycles per (band, j) pair
+            const int64_t jb_amort = (int64_t)(32768.0 / std::max(cyc_per_pair, 1.0));
+            JB = std::min<int64_t>(std::max(jb_l2, jb_amort), std::max<int64_t>(jb_l2, (4ll << 20) / (8 * avg_deg)));
+        }
         const int64_t cap = std::max<int64_t>(16384, mcl / (4 * (int64_t)G));        // cycles per unit at most
         const int64_t nJ = (n + JB - 1) / JB;
         auto j_of = [&](int64_t q) { return (int64_t)prob->ind_j[s->pos_edge[P.order[q]]]; };
