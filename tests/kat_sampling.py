@@ -64,6 +64,18 @@ S2 = np.array([.403, .3, 0, .2, .2, 0])
 OBJ2, AVG2 = 1.9485, 0.013
 TOL = 1e-12           # the only inexact step is acos(cos(x)) for the three non-trivial angles
 
+# First GetStep of HybridGradient (Utils/HybridGradient.m:23-41, strategy 0 = Adam) on the same structure: with m_0 = v_0 = 0,
+#   m_1 = (1-b1) g, v_1 = (1-b2) g.^2, m_1/(1-b1^1) = g, v_1/(1-b2^1) = g.^2  =>  step = -lr * g ./ (|g| + 1e-8),
+# i.e. every cycle moves by lr against the sign of its (mean-removed) gradient, whatever beta_1, beta_2.  From the table above
+# g = -.025 .025 | 0 | .225 -.225 | .35 -.35 | 0 | -.15 .15 ; with lr = 0.1 nothing leaves the simplex:
+ADAM_LR = 0.1
+_G1 = np.array([-.025, .025, 0, .225, -.225, .35, -.35, 0, -.15, .15])
+W1_ADAM = W0 - ADAM_LR * _G1 / (np.abs(_G1) + 1e-8)        # = .6 .4 | 1 | .4 .6 | .4 .6 | 1 | .6 .4  up to 1e-8 / |g| relative
+S1_ADAM = np.array([W1_ADAM[0] * .3 + W1_ADAM[1] * .5, .3, W1_ADAM[3] * .5, W1_ADAM[5] * .3 + W1_ADAM[6] * .2, .2, W1_ADAM[9] * .2])
+ADAM_M1 = 0.1 * _G1                                          # (1 - beta_1) g with beta_1 = 0.9
+ADAM_V1 = 0.001 * _G1 ** 2                                   # (1 - beta_2) g.^2 with beta_2 = 0.999
+assert np.allclose(W1_ADAM, [.6, .4, 1, .4, .6, .4, .6, 1, .6, .4], atol=1e-6) and np.allclose(S1_ADAM, [.38, .3, .2, .24, .2, .08], atol=1e-6)
+
 
 def rotations():
     """RijMat (3,3,6): rotation about z by theta_ij."""

@@ -363,6 +363,13 @@ def test_sampling_regime_known_answer_by_hand(lib, variant):
         assert np.abs(s0 - K.D).max() < K.TOL
         assert np.abs(out["w"] - W).max() < K.TOL and np.abs(out["S_vec"] - S).max() < K.TOL
         assert np.abs(out["obj"] - objs).max() < K.TOL and np.abs(out["avg"] - avgs).max() < K.TOL
+    # first Adam step (HybridGradient.m:23-41): lr against the sign of the gradient, tabulated in kat_sampling.py
+    imp = lib.Structure.from_arrays(4, 6, 30, K.POS_EDGE, K.CUM_IND, K.K, K.E_JK, K.E_KI, K.IKJ, K.JKI)
+    gm = np.zeros(10); gv = np.zeros(10)
+    _, _, out = run_gpu(lib, 4, ii, jj, rij, c_params(1, step_kind=2, lr=K.ADAM_LR, beta1=0.9, beta2=0.999, decay_interval=10), structure=imp,
+                        variant=variant, adam=(gm, gv))
+    assert np.abs(out["w"] - K.W1_ADAM).max() < K.TOL and np.abs(out["S_vec"] - K.S1_ADAM).max() < K.TOL
+    assert np.abs(out["adam_m"] - K.ADAM_M1).max() < K.TOL and np.abs(out["adam_v"] - K.ADAM_V1).max() < K.TOL and out["t_end"] == 1
 
 
 def test_wrapper_keeps_device_structure_on_the_device(lib):

@@ -154,6 +154,17 @@ def test_sampling_regime_known_answer_by_hand(oracle):
     # initial state (:148-157)
     Sv, st = desc_pgd_literal(Ind, K.rotations(), 0, ConstantStepSize(K.LR), return_state=True, forced_lists=K.FORCED)
     assert np.abs(st["wijk"] - K.W0).max() < K.TOL and np.abs(Sv - K.S_INIT).max() < K.TOL
+    # first Adam step (HybridGradient.m:23-41): lr against the sign of the gradient, tabulated in kat_sampling.py
+    from oracle.desc_pgd_literal import HybridGradient
+    H = HybridGradient(K.ADAM_LR, 0.9, 0.999, 10)
+    Sv, st = desc_pgd_literal(Ind, K.rotations(), 1, H, return_state=True, forced_lists=K.FORCED)
+    assert np.abs(st["wijk"] - K.W1_ADAM).max() < K.TOL and np.abs(Sv - K.S1_ADAM).max() < K.TOL
+    assert np.abs(H.m_t - K.ADAM_M1).max() < K.TOL and np.abs(H.v_t - K.ADAM_V1).max() < K.TOL and H.t == 1
+    sd = K.structure_dict()
+    am = np.zeros(10); av = np.zeros(10)
+    res = oracle.pgd_run(sd, K.D, 1, step_kind=2, lr=K.ADAM_LR, beta1=0.9, beta2=0.999, decay_interval=10, adam_m=am, adam_v=av)
+    assert np.abs(res["w"] - K.W1_ADAM).max() < K.TOL and np.abs(res["S_vec"] - K.S1_ADAM).max() < K.TOL
+    assert np.abs(am - K.ADAM_M1).max() < K.TOL and np.abs(av - K.ADAM_V1).max() < K.TOL
 
 
 # ------------------------------------------------------------------ invariants / cross-checks
