@@ -963,7 +963,7 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
     if (st->stop) return;
     extern __shared__ double acc[];                   // [4][stride_cols] doubles, then 3 ints per incident edge
     int* seg_base = (int*)(acc + 4 * stride_cols);
-    int* seg_cf = seg_base + stride_cols;             // n_both | n_i << 9 | n_jonly << 18 | (v is the smaller endpoint) << 31
+    int* seg_cf = seg_base + stride_cols;             // slot_record: {first contributing cycle, their number (| flag)}
     uint32_t* seg_mo = (uint32_t*)(seg_cf + stride_cols);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int v = blockIdx.x; v < n; v += gridDim.x - 1) {
@@ -976,9 +976,10 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
         }
         __syncthreads();
         double* mine = acc + wv * stride_cols;
-        // Inside a segment the cycles are ordered [both mirrors | (ik;j) only | (jk;i) only |
-        // none], so an endpoint reads only the `nact` cycles that contribute to its columns
-        // (~n_sample/codeg of them).  A wave instruction serves 4 segments x 16 lanes; segments
+        // Inside a segment the cycles are ordered [(ik;j) only | both mirrors | (jk;i) only |
+        // none], so either endpoint reads one run: only the `nact` cycles that contribute to its
+        // columns (~n_sample/codeg of them; the smaller endpoint the first two classes, the larger
+        // the middle two).  A wave instruction serves 4 segments x 16 lanes; segments
         // with more than 16 contributing cycles take further passes.  Every load of a batch is
         // issued before any result is touched (a use between loads would make the compiler wait
         // for each one).
@@ -994,17 +995,13 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
                     const int tt = 4 * (g0 + 4 * u) + sub;
                     pv[2 * u] = 0xFFFFu; pv[2 * u + 1] = 0xFFFFu; wvv[2 * u] = 0.0; wvv[2 * u + 1] = 0.0;
                     if (tt < deg) {
-                        const uint32_t cf = (uint32_t)seg_cf[tt];
-                        const int n_both = cf & 0x1FFu, n_i = (cf >> 9) & 0x1FFu, n_jo = (cf >> 18) & 0x1FFu;
-                        const bool v_is_i = cf & 0x80000000u;
-                        const int nact = v_is_i ? n_i : n_both + n_jo;
+                        const int nact = seg_cf[tt] & 0x1FF;
                         more |= nact > 32 * (round + 1);
 #pragma unroll
                         for (int h2 = 0; h2 < 2; ++h2) {
                             const int q = l16 + 16 * (2 * round + h2);
                             if (q < nact) {
-                                const int off = (v_is_i || q < n_both) ? q : n_i + (q - n_both);
-                                const int64_t c = (int64_t)seg_base[tt] + off;
+                                const int64_t c = (int64_t)seg_base[tt] + q;
                                 pv[2 * u + h2] = midx[(size_t)seg_mo[tt] + q];
                                 wvv[2 * u + h2] = w[c];
                             }
@@ -1059,7 +1056,7 @@ __global__ __launch_bounds__(256) void k_layout_node(const int32_t* cum, const i
 // The same for a device-built structure, in place: reads the sampled k (natural order), decides
 // the two mirror-present bits from the selection thresholds of the partner edges -- cycle (ik;j)
 // was sampled iff (key(e_ik, j), j) <= (tau, ktau) of edge {i,k} -- and does the within-segment
-// re-ordering [both mirrors | (ik;j) only | (jk;i) only | none] in the wave (stable: ascending k
+// re-ordering [(ik;j) only | both mirrors | (jk;i) only | none] in the wave (stable: ascending k
 // inside a class, exactly like the host path).  Segments have <= MAX_SEG_CYCLES cycles (pieces of 64).
 template <int NP>                                    // pieces of 64 cycles per segment: 1, 2 or 4
 __global__ __launch_bounds__(256) void k_layout_node_dev(const int32_t* cum, const int32_t* src_start, const int32_t* pos_edge,
@@ -1106,7 +1103,7 @@ __global__ __launch_bounds__(256) void k_layout_node_dev(const int32_t* cum, con
             }
             word[pc] = (uint32_t)xi | (fi ? 1u : 0u) << 15 | (uint32_t)xj << 16 | (fj ? 1u : 0u) << 31;
             eik[pc] = ei2; ejk[pc] = ej2; kk[pc] = k;
-            cls[pc] = !on ? 4 : fi ? (fj ? 0 : 1) : (fj ? 2 : 3);
+            cls[pc] = !on ? 4 : fi ? (fj ? 1 : 0) : (fj ? 2 : 3);
 #pragma unroll
             for (int c = 0; c < 4; ++c) { cm[pc][c] = __ballot(cls[pc] == c); ncls[c] += __popcll(cm[pc][c]); }
         }
@@ -1148,6 +1145,13 @@ __global__ __launch_bounds__(256) void k_edge_slots(const int32_t* ind_i, const 
         einfo[q] = EdgeInfo{rowptr[i], rowptr[j], slot(i, j), slot(j, i)};
     }
 }
+// Record of a CSR slot (v,u) for the column-sum pass: {first cycle of the run of segment {v,u} that contributes to node v's
+// columns, length of the run | (v is the smaller endpoint) << 31}.  counts = n_ionly | n_i << 9 | n_jonly << 18 of the segment
+// (class order [(ik;j) only | both | (jk;i) only | none]): the smaller endpoint reads [0, n_i), the larger [n_ionly, n_i + n_jonly).
+__host__ __device__ inline int2 slot_record(int32_t seg_first, uint32_t counts, bool v_is_i) {
+    const int n_io = counts & 0x1FFu, n_i = (counts >> 9) & 0x1FFu, n_jo = (counts >> 18) & 0x1FFu;
+    return v_is_i ? int2{seg_first, (int)((uint32_t)n_i | 0x80000000u)} : int2{seg_first + n_io, n_i - n_io + n_jo};
+}
 // CSR-aligned segment records for the column-sum pass: 16 lanes per node row
 __global__ __launch_bounds__(256) void k_adj_seg(const int32_t* rowptr, const int32_t* adj, const int32_t* adj_eid, const int32_t* devpos,
                                                  const int32_t* cum, const uint32_t* seg_counts, int seg_lo, int seg_hi, int2* adj_seg, int n) {
@@ -1157,17 +1161,13 @@ __global__ __launch_bounds__(256) void k_adj_seg(const int32_t* rowptr, const in
         for (int t = rowptr[v] + l16; t < rowptr[v + 1]; t += 16) {
             const int q = devpos[adj_eid[t]];
             int2 rec{0, 0};
-            if (q >= seg_lo && q < seg_hi) { rec.x = cum[q]; rec.y = (int)(seg_counts[q] | (v < adj[t] ? 0x80000000u : 0u)); }
+            if (q >= seg_lo && q < seg_hi) rec = slot_record(cum[q], seg_counts[q], v < adj[t]);
             adj_seg[t] = rec;
         }
 }
 
 // ---- the column-index stream of the column-sum pass
-__device__ __forceinline__ int slot_nact(int2 rec) {          // contributing cycles of the segment behind a CSR slot, seen from the row's node
-    const uint32_t cf = (uint32_t)rec.y;
-    const int n_both = cf & 0x1FFu, n_i = (cf >> 9) & 0x1FFu, n_jo = (cf >> 18) & 0x1FFu;
-    return (cf & 0x80000000u) ? n_i : n_both + n_jo;
-}
+__device__ __forceinline__ int slot_nact(int2 rec) { return rec.y & 0x1FF; }         // contributing cycles of the segment behind a CSR slot, seen from the row's node
 // entries per node row (16 lanes per row)
 __global__ __launch_bounds__(256) void k_midx_rowsum(const int32_t* rowptr, const int2* adj_seg, uint32_t* rowsum, int n) {
     const int l16 = threadIdx.x & 15;
@@ -1209,14 +1209,11 @@ __global__ __launch_bounds__(256) void k_midx_entries(const int2* adj_seg, const
     const int64_t g0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4, ng = ((int64_t)gridDim.x * 256) >> 4;
     for (int64_t t = g0; t < nslots; t += ng) {
         const int2 rec = adj_seg[t];
-        const uint32_t cf = (uint32_t)rec.y;
-        const int n_both = cf & 0x1FFu, n_i = (cf >> 9) & 0x1FFu;
-        const bool v_is_i = cf & 0x80000000u;
+        const bool v_is_i = rec.y < 0;
         const int nact = slot_nact(rec);
         const uint32_t o = moff[t];
         for (int q = l16; q < nact; q += 16) {
-            const int off = (v_is_i || q < n_both) ? q : n_i + (q - n_both);
-            const uint32_t p = pk[(int64_t)rec.x + off];
+            const uint32_t p = pk[(int64_t)rec.x + q];
             midx[(size_t)o + q] = (uint16_t)((v_is_i ? p : p >> 16) & 0x7FFFu);
         }
     }
@@ -1379,7 +1376,7 @@ struct desc_pgd {
     uint32_t* d_pk = nullptr;
     uint32_t* d_moff = nullptr;  // per CSR slot: start of its run in d_midx
     uint16_t* d_midx = nullptr;  // column index of every contributing cycle, in the order the column-sum pass reads them
-    int2* d_adj_seg = nullptr;   // per CSR slot: {first cycle of the incident edge's segment, cnt | (row node is the smaller endpoint) << 31}
+    int2* d_adj_seg = nullptr;   // per CSR slot: slot_record() = {first contributing cycle of the incident segment, their number | (row node is the smaller endpoint) << 31}
     int32_t *d_rowptr = nullptr, *d_src_start = nullptr, *d_eslot = nullptr;
     ChunkDesc* d_chunk_desc = nullptr;
     int nchunks = 0;
@@ -1921,15 +1918,15 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     if (!dev_cycles) {
         if ((rc = structure_ensure_host(const_cast<desc_structure*>(s)))) return rc;
     // k with the two mirror-present bits of the owned cycles, device order.  Inside a segment
-    // the cycles are stored [both mirrors sampled | (ik;j) only | (jk;i) only | none] (ascending k
-    // within a class): the column-sum pass then reads only the cycles that contribute
+    // the cycles are stored [(ik;j) only | both mirrors sampled | (jk;i) only | none] (ascending k
+    // within a class): the column-sum pass then reads, for either endpoint, ONE run with the cycles that contribute
     // (a fraction ~n_sample/codeg of them), the per-segment arithmetic is order independent.
-    kf.assign((size_t)mcl, 0u); seg_perm.assign((size_t)mcl, 0); seg_counts.assign((size_t)mp, 0u);   // counts: n_both | n_i << 9 | n_jonly << 18
+    kf.assign((size_t)mcl, 0u); seg_perm.assign((size_t)mcl, 0); seg_counts.assign((size_t)mp, 0u);   // counts: n_ionly | n_i << 9 | n_jonly << 18
     host_parallel(nsl, [&](int64_t a, int64_t b) {
         for (int64_t q = h->seg_lo + a; q < h->seg_lo + b; ++q) {
             const int64_t src = src_start[q], dst = cum_loc[q], cnt = cum2[q + 1] - cum2[q];
-            int n_cls[4] = {0, 0, 0, 0};                      // class 0 both, 1 i-only, 2 j-only, 3 none
-            auto cls = [&](int64_t t) { const bool fi = s->ikj[src + t] >= 0, fj = s->jki[src + t] >= 0; return fi ? (fj ? 0 : 1) : (fj ? 2 : 3); };
+            int n_cls[4] = {0, 0, 0, 0};                      // class 0 i-only, 1 both, 2 j-only, 3 none
+            auto cls = [&](int64_t t) { const bool fi = s->ikj[src + t] >= 0, fj = s->jki[src + t] >= 0; return fi ? (fj ? 1 : 0) : (fj ? 2 : 3); };
             for (int64_t t = 0; t < cnt; ++t) n_cls[cls(t)]++;
             int pos[4] = {0, n_cls[0], n_cls[0] + n_cls[1], n_cls[0] + n_cls[1] + n_cls[2]};
             for (int64_t t = 0; t < cnt; ++t) {
@@ -1947,8 +1944,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
                 const int32_t q = devpos[adj_eid[t]];
                 int2 rec{0, 0};
                 if (q >= h->seg_lo && q < h->seg_hi) {       // only segments this rank owns
-                    rec.x = cum_loc[q];
-                    rec.y = (int)(seg_counts[q] | (v < adj[t] ? 0x80000000u : 0u));
+                    rec = slot_record(cum_loc[q], seg_counts[q], v < adj[t]);
                 }
                 adj_seg[t] = rec;
             }
