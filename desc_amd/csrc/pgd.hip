@@ -672,7 +672,8 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
 // issued in the order gathers -> stream -> arithmetic -> stores: loads and stores retire through one in-order
 // counter on gfx950, so everything an iteration waits for was issued before the previous iteration's stores.
 #ifndef DESC_BAND_ABLATE            // diagnostic builds only (tools/build_ablate.sh): 1 S({j,k}) from the LDS too, 2 no arithmetic,
-#define DESC_BAND_ABLATE 0          // 4 one threshold pass, 8 no stores, 16 no LDS gathers, 32 no T1/T2 loads, 64 S({j,k}) rows confined to 1 MiB
+#define DESC_BAND_ABLATE 0          // 4 one threshold pass, 8 no stores, 16 no LDS gathers, 32 no T1/T2 loads, 64 S({j,k}) rows confined to 1 MiB,
+                                    // 128 / 256 non-temporal stream loads / stores, 2048 gathers issued where they are used (no prefetch)
 #endif
 constexpr int BAND_ROW_CAP = 19200;          // doubles of LDS for the band rows (150 KiB of the CU's 160 KiB)
 struct alignas(16) PieceDesc { int32_t row_lo, row_len, seg_lo, seg_hi; };   // CSR slots of the band, device-order segments
@@ -871,10 +872,11 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
         // one iteration: Ra/Sa/Ga = group g (computed), Rb/Sb = g+1 (gathers issued into Gb), Rd/Sd <- g+3
         auto step = [&](int g, const Rec& Ra, const Str& Sa, const Gat& Ga, const Rec& Rb, const Str& Sb, Gat& Gb, Rec& Rd, Str& Sd) {
             const RecRaw qn = load_raw(g + 4);
-            Gb = issue_gathers(Rb, Sb);
+            if (!(DESC_BAND_ABLATE & 2048)) Gb = issue_gathers(Rb, Sb);
             Rd = land(Q);
             Sd = load_stream(Rd);
-            compute(Ra, Sa, Ga);
+            if (DESC_BAND_ABLATE & 2048) { const Gat gn = issue_gathers(Ra, Sa); compute(Ra, Sa, gn); }    // 2048: gathers not prefetched at all (latency probe)
+            else compute(Ra, Sa, Ga);
             Q = qn;
         };
         for (int g = 0; g < nit; g += 4) {                 // the tail iterations past nit compute nothing (cnt = 0)
