@@ -24,7 +24,7 @@ EXPORTS = [
     "desc_structure_build", "desc_structure_import", "desc_structure_get", "desc_structure_sizes",
     "desc_structure_host_exports", "desc_structure_free",
     "desc_sample_key", "desc_params_default",
-    "desc_pgd_create", "desc_pgd_destroy", "desc_pgd_run", "desc_pgd_reset", "desc_pgd_iterate",
+    "desc_pgd_create", "desc_pgd_destroy", "desc_pgd_run", "desc_pgd_run_traced", "desc_pgd_reset", "desc_pgd_iterate",
     "desc_pgd_iterate_timed", "desc_pgd_sync", "desc_pgd_download", "desc_pgd_get_s0",
     "desc_pgd_sizes", "desc_pgd_kernel_name", "desc_pgd_solve", "desc_selftest_group_sum",
     "desc_pgd_create_shard", "desc_pgd_shard_info", "desc_pgd_shard_bind", "desc_pgd_shard_colsum", "desc_pgd_shard_sweep",
@@ -148,6 +148,7 @@ def load():
     L.desc_pgd_destroy.argtypes = [C.c_void_p]
     L.desc_pgd_destroy.restype = None
     L.desc_pgd_run.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Result)]
+    L.desc_pgd_run_traced.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Params), F64P, C.c_double, C.c_int32, F64P, F64P, C.POINTER(Result)]
     L.desc_pgd_reset.argtypes = [C.c_void_p, C.POINTER(Params)]
     L.desc_pgd_iterate.argtypes = [C.c_void_p, C.c_int32]
     L.desc_pgd_iterate_timed.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -352,6 +353,23 @@ class Solver:
         r, bufs = self._result(params.iters, want_w, adam)
         check(load().desc_pgd_run(self.handle, C.byref(params), C.byref(r)))
         return self._pack(r, bufs)
+
+    def run_traced(self, params: Params, dprob, err_vec, gcw_tol=1e-13, gcw_max_iters=500):
+        """desc_pgd_run_traced (params.make_plots = true, DESC_PGD.m:235-239): the run plus svec_errors and the GCW estimate
+        of every iteration, R_est_all (iters_run, 3, 3, n)."""
+        r, bufs = self._result(params.iters)
+        n = dprob.n
+        ev = np.ascontiguousarray(err_vec, dtype=np.float64).reshape(-1)
+        if ev.size != self.m:
+            raise ValueError("err_vec must have m entries")
+        se = np.zeros(max(params.iters, 1)); Rall = np.zeros(max(params.iters, 1) * 9 * max(n, 1))
+        check(load().desc_pgd_run_traced(self.handle, dprob.handle, C.byref(params), ptr(ev, F64P), gcw_tol, gcw_max_iters,
+                                         ptr(se, F64P), ptr(Rall, F64P), C.byref(r)))
+        out = self._pack(r, bufs)
+        k = out["iters_run"]
+        out["svec_errors"] = se[:k]
+        out["R_est_all"] = Rall[:k * 9 * n].reshape(k, 9 * n).reshape((k, n, 3, 3)).transpose(0, 3, 2, 1)     # (t, r, c, node) from 3 x 3 x n column-major
+        return out
 
     def reset(self, params: Params):
         self._iters_cap = params.iters

@@ -215,26 +215,16 @@ def _run_with_plots(solver, p, params, prob, dprob, perm, verbose):
     R_orig = np.asarray(_get(params, "R_orig"), dtype=np.float64)
     if perm is not None:
         ErrVec = ErrVec[perm]
-    svec_errors, mse_means, mse_medians = [], [], []
     try:
-        solver.reset(p)
-        done = 0
-        while done < p.iters:
-            solver.iterate(1); done += 1
-            mid = solver.download()                                  # also evaluates the objective of this iteration
-            if mid["iters_run"] < done:                              # the patience rule fired at an earlier iteration
-                break
-            S = mid["S_vec"]
-            svec_errors.append(float(np.mean(np.abs(ErrVec - S))))                           # :236
-            R_est, _ = _lib.gcw_run(dprob, S)                                                # :237
-            _, _, mean_e, med_e = Rotation_Alignment(R_est, R_orig)                          # :238
-            mse_means.append(mean_e); mse_medians.append(med_e)
-            if verbose:
-                print("iter %d: average change in S_vec %f, objective value: %f" % (done, mid["avg"][done - 1], mid["obj"][done - 1]), flush=True)
-        out = solver.download()
+        out = solver.run_traced(p, dprob, ErrVec)                     # desc_pgd_run_traced: :236-237 for every iteration
     finally:
         if own is not None:
             own.free()
+    mse_means, mse_medians = [], []
+    for R_est in out.pop("R_est_all"):
+        _, _, mean_e, med_e = Rotation_Alignment(R_est, R_orig)                                  # :238
+        mse_means.append(mean_e); mse_medians.append(med_e)
+    svec_errors = out["svec_errors"]
     k = out["iters_run"]
     out["svec_errors"] = np.array(svec_errors[:k]); out["MSE_means"] = np.array(mse_means[:k]); out["MSE_medians"] = np.array(mse_medians[:k])
     return out

@@ -2441,6 +2441,36 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
     return DESC_OK;
 }
 
+// params.make_plots = true (DESC_PGD.m:235-239) as a composition of device rows: one sweep, one S_vec download and one GCW
+// eigen-solve per iteration.  The alignment against R_orig (:238, GlobalSOdCorrectRight) stays with the caller.
+int desc_pgd_run_traced(desc_pgd* h, const desc_device_problem* dp, const desc_params* p, const double* err_vec, double gcw_tol,
+                        int32_t gcw_max_iters, double* svec_errors, double* R_est_all, desc_result* r) {
+    if (!h || !dp || !p || !r || !err_vec || !svec_errors || !R_est_all) return fail(DESC_ERR_INVALID, "NULL argument");
+    if (!r->s_vec || !r->obj_trace || !r->avg_change_trace) return fail(DESC_ERR_INVALID, "the traced run needs s_vec, obj_trace and avg_change_trace");
+    if (p->step_kind == DESC_STEP_HYBRID && p->hybrid_strategy == 0) return fail(DESC_ERR_INVALID, "the traced run does not carry the Adam moments between its one-iteration pieces");
+    if (dp->m != h->m || dp->n != h->n) return fail(DESC_ERR_INVALID, "device problem and solver handle describe different graphs");
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = desc_pgd_reset(h, p); if (rc) return rc;
+    desc_result mid = *r;                                    // same buffers; w / Adam state only in the final download
+    mid.w = nullptr; mid.adam_m = nullptr; mid.adam_v = nullptr;
+    int done = 0;
+    while (done < p->iters) {
+        if ((rc = desc_pgd_iterate(h, 1))) return rc;
+        ++done;
+        if ((rc = desc_pgd_download(h, &mid))) return rc;    // also evaluates this iteration's objective and stop test
+        if (mid.iters_run < done) break;                     // the patience rule fired at an earlier iteration (:243-246)
+        double acc = 0.0;
+        for (int64_t e = 0; e < h->m; ++e) acc += std::fabs(err_vec[e] - mid.s_vec[e]);
+        svec_errors[done - 1] = h->m > 0 ? acc / (double)h->m : 0.0;                                     // :236
+        if ((rc = desc_gcw_run_dev(dp, mid.s_vec, gcw_tol, gcw_max_iters, R_est_all + (size_t)(done - 1) * 9 * (size_t)h->n, nullptr))) return rc;   // :237
+        if (p->progress) p->progress(p->progress_user, done, mid.avg_change_trace[done - 1], mid.obj_trace[done - 1]);
+        else if (p->verbose) { printf("iter %d: average change in S_vec %f, objective value: %f\n", done, mid.avg_change_trace[done - 1], mid.obj_trace[done - 1]); fflush(stdout); }
+    }
+    rc = desc_pgd_download(h, r);
+    r->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
 int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r) {
     if (!h || !p || !r) return fail(DESC_ERR_INVALID, "NULL argument");
     auto t0 = std::chrono::steady_clock::now();

@@ -184,6 +184,14 @@ int desc_pgd_create_dev(const desc_device_problem* dp, const desc_structure* s, 
 void desc_pgd_destroy(desc_pgd* h);
 /* Full run: init (DESC_PGD.m:148-167) + loop (:182-261) + download. */
 int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r);
+/* params.make_plots = true (DESC_PGD.m:235-239; the figure of DESC.m:315-344 is drawn from these traces): desc_pgd_run with, after
+ * every iteration t, svec_errors[t-1] = mean|err_vec - S_vec| (:236, err_vec = params.ErrVec, m doubles) and the rotation estimate
+ * GCW(S_vec) (:237) in R_est_all[(t-1) * 9n ...] (caller-allocated: iters entries / iters * 9n doubles; 3 x 3 x n column-major per
+ * iteration).  MSE_means / MSE_medians (:238) = the caller's GlobalSOdCorrectRight(R_est, params.R_orig) of each estimate.
+ * dp: the same problem resident on the handle's device.  r->s_vec, obj_trace, avg_change_trace are required.  Entries past
+ * r->iters_run are untouched.  Not for the Adam plugin (its moments are not carried between the one-iteration pieces). */
+int desc_pgd_run_traced(desc_pgd* h, const desc_device_problem* dp, const desc_params* p, const double* err_vec, double gcw_tol,
+                        int32_t gcw_max_iters, double* svec_errors, double* R_est_all, desc_result* r);
 /* Pieces of desc_pgd_run, for benchmarks and the multi-GPU driver.  All work is
  * enqueued on the handle's stream; _sync waits for it. */
 int desc_pgd_reset(desc_pgd* h, const desc_params* p);            /* :148-167                 */

@@ -4,19 +4,27 @@
 %% the GPU once for the three stages (desc_amd_mex('desc', ...): desc_problem_upload).
 function [R_est, R_init, S_vec] = DESC(Ind, RijMat, params)
     G = params.Gradient;
-    if isa(G, 'HybridGradient') && G.strategy == 0
-        % Adam keeps per-cycle state in the handle object: stage by stage
-        S_vec = DESC_PGD(Ind, RijMat, params);
+    make_plots = isfield(params, 'make_plots') && params.make_plots;
+    if make_plots || (isa(G, 'HybridGradient') && G.strategy == 0)
+        % Adam keeps per-cycle state in the handle object, make_plots needs the per-iteration traces: stage by stage
+        [S_vec, traces] = DESC_PGD(Ind, RijMat, params);
         [IndS, perm] = sortrows(double(Ind), [1 2]);
         R_init = desc_amd_mex('gcw', int32(IndS - 1), double(RijMat(:,:,perm)), S_vec(perm));
         disp('Rotation Initialized!')                 % DESC.m:283
         disp('Start DESC refinement ...')             % DESC.m:284
         R_est = desc_amd_mex('refine', int32(IndS - 1), double(RijMat(:,:,perm)), S_vec(perm), R_init);
         disp('DONE!')                                 % DESC.m:313
+        if make_plots                                 % the 2 x 2 convergence figure of DESC.m:315-344
+            names = {'svec_errors', 'obj_vals', 'MSE_means', 'MSE_medians'};
+            labels = {'Average distance to true corruption', 'Value of Objective Function', ...
+                      'Mean Error in R estimate (degrees)', 'Median Error in R estimate (degrees)'};
+            figure;
+            for q = 1:4
+                subplot(2, 2, q); plot(1:numel(traces.(names{q})), traces.(names{q}));
+                xlabel('Iteration number'); ylabel(labels{q});
+            end
+        end
         return
-    end
-    if isfield(params, 'make_plots') && params.make_plots
-        error('desc_amd:make_plots', 'params.make_plots=true is served by the Python host layer only (desc_amd.DESC); set make_plots=false.');
     end
     [IndS, perm] = sortrows(double(Ind), [1 2]);
     opt.iters = double(params.iters); opt.decay_interval = 25; opt.hybrid_strategy = 0; opt.t0 = 0;

@@ -9,10 +9,14 @@
 %%         PiecewiseStepSize / HybridGradient object, DESC_PGD.m:207), .make_plots (:235).
 %%         Optional, not in the reference: .seed (cycle-sampling seed, default 0), .device.
 %% Put this directory BEFORE the reference's Algorithms/ on the MATLAB path.
-function [S_vec] = DESC_PGD(Ind, RijMat, params)
-    if isfield(params, 'make_plots') && params.make_plots
-        error('desc_amd:make_plots', ['params.make_plots=true (per-iteration GCW + alignment, ' ...
-              'DESC_PGD.m:235-239) is outside the accelerated hot path; set make_plots=false.']);
+%% params.make_plots = true (:235-239): the library returns mean|ErrVec - S_vec| and GCW(S_vec) of every iteration
+%% (desc_pgd_run_traced); the alignment of :238 is the reference's own Utils/GlobalSOdCorrectRight, which must be on the path.
+%% The traces the reference keeps in local variables are available as an optional second output:
+%%   [S_vec, traces] = DESC_PGD(...)   traces.svec_errors / .MSE_means / .MSE_medians / .obj_vals
+function [S_vec, traces] = DESC_PGD(Ind, RijMat, params)
+    make_plots = isfield(params, 'make_plots') && params.make_plots;
+    if make_plots && isa(params.Gradient, 'HybridGradient') && params.Gradient.strategy == 0
+        error('desc_amd:make_plots', 'params.make_plots=true is not available with the Adam plugin (strategy 0); use strategy 1 or another plugin.');
     end
     % the reference silently requires Ind sorted as (1,2),(1,3),...,(2,3),... (DESC_PGD.m:5,31-34)
     [IndS, perm] = sortrows(double(Ind), [1 2]);
@@ -35,6 +39,11 @@ function [S_vec] = DESC_PGD(Ind, RijMat, params)
     opt.seed = 0;   if isfield(params, 'seed'),   opt.seed = params.seed;     end
     opt.device = 0; if isfield(params, 'device'), opt.device = params.device; end
     opt.verbose = 1;   % the per-iteration line of DESC_PGD.m:241 is printed by the MEX shim while the loop runs
+    if make_plots
+        opt.make_plots = 1;
+        ErrVec = double(params.ErrVec(:)');               % DESC_PGD.m:236
+        opt.ErrVec = ErrVec(perm);
+    end
 
     disp('compute R cycle')                  % DESC_PGD.m:132
     disp('S0Mat')                            % :145
@@ -48,4 +57,11 @@ function [S_vec] = DESC_PGD(Ind, RijMat, params)
     if isa(G, 'HybridGradient') && G.strategy == 0, G.m_t = info.adam_m; G.v_t = info.adam_v; end
     S_vec = zeros(1, size(Ind,1));
     S_vec(perm) = S_sorted;
+    traces = struct('obj_vals', info.obj_vals(1:info.iters_run), 'svec_errors', [], 'MSE_means', [], 'MSE_medians', []);
+    if make_plots
+        traces.svec_errors = info.svec_errors;
+        for t = 1:size(info.R_est_all, 4)                 % DESC_PGD.m:238
+            [~, traces.MSE_means(end+1), traces.MSE_medians(end+1), ~] = GlobalSOdCorrectRight(info.R_est_all(:,:,:,t), params.R_orig);
+        end
+    end
 end

@@ -5,9 +5,11 @@
  *     RijMat  3 x 3 x m double  -- passed through untouched: MATLAB's column-major layout of a
  *             3x3xm array IS the library's m x 9 layout (element (r,c,l) at 9*l + r + 3*c)
  *     opt     struct: iters, step_kind, lr, beta1, beta2, decay_interval, hybrid_strategy, t0,
- *             seed, device, verbose (1: the reference's per-iteration line, printed while the loop runs)
+ *             seed, device, verbose (1: the reference's per-iteration line, printed while the loop runs),
+ *             make_plots (1: DESC_PGD.m:235-239 -- needs ErrVec, 1 x m in the sorted edge order; not with Adam)
  *     adam_m/adam_v   [] or 1 x m_cycle (HybridGradient.m_t / v_t carried between calls)
- *   info: iters_run, t_end, obj_vals, avg_change, adam_m, adam_v, ms_structure, ms_pgd, ms_total
+ *   info: iters_run, t_end, obj_vals, avg_change, adam_m, adam_v, ms_structure, ms_pgd, ms_total; with make_plots also
+ *         svec_errors (1 x iters_run) and R_est_all (3 x 3 x n x iters_run: GCW(S_vec) after every iteration)
  *
  * Build (on a machine with MATLAB + ROCm; NOT possible in the build container: no mex.h):
  *   mex -I../include desc_pgd_mex.c -L../desc_amd -ldesc_amd
@@ -99,16 +101,43 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     r.avg_change_trace = mxGetPr(avg);
     if (p.step_kind == DESC_STEP_HYBRID && p.hybrid_strategy == 0) { r.adam_m = mxGetPr(am); r.adam_v = mxGetPr(av); }
 
+    const int make_plots = field_or(prhs[2], "make_plots", 0) != 0;
+    mxArray *se = NULL, *rall = NULL;
     desc_pgd* h = NULL;
-    rc = desc_pgd_create(&prob, st, p.device, &h);
-    desc_structure_free(st);
-    if (rc == DESC_OK) rc = desc_pgd_run(h, &p, &r);
+    if (!make_plots) {
+        rc = desc_pgd_create(&prob, st, p.device, &h);
+        desc_structure_free(st);
+        if (rc == DESC_OK) rc = desc_pgd_run(h, &p, &r);
+    } else {                                   /* DESC_PGD.m:235-239: svec_errors and GCW(S_vec) after every iteration */
+        const mxArray* ev = mxGetField(prhs[2], 0, "ErrVec");
+        if (!ev || !mxIsDouble(ev) || mxGetNumberOfElements(ev) != m) {
+            desc_structure_free(st);
+            mexErrMsgIdAndTxt("desc_amd:make_plots", "opt.make_plots needs opt.ErrVec with one entry per edge");
+        }
+        const mwSize it = p.iters > 0 ? p.iters : 1;
+        mwSize rd[4]; rd[0] = 3; rd[1] = 3; rd[2] = (mwSize)prob.n; rd[3] = it;
+        se = mxCreateDoubleMatrix(1, it, mxREAL);
+        rall = mxCreateNumericArray(4, rd, mxDOUBLE_CLASS, mxREAL);
+        desc_device_problem* dp = NULL;
+        rc = desc_problem_upload(&prob, p.device, &dp);
+        if (rc == DESC_OK) rc = desc_pgd_create_dev(dp, st, 0, 1, &h);
+        desc_structure_free(st);
+        if (rc == DESC_OK) rc = desc_pgd_run_traced(h, dp, &p, mxGetPr(ev), 1e-13, 500, mxGetPr(se), mxGetPr(rall), &r);
+        if (dp) desc_problem_free(dp);
+        if (rc == DESC_OK && (mwSize)r.iters_run < it) {          /* early stop: trim to the iterations that ran */
+            mxSetN(se, (mwSize)r.iters_run);
+            rd[3] = (mwSize)r.iters_run;
+            mxSetDimensions(rall, rd, 4);
+        }
+    }
     if (h) desc_pgd_destroy(h);
     if (rc != DESC_OK) mexErrMsgIdAndTxt("desc_amd:run", "%s", desc_last_error());
 
     if (nlhs > 1) {
-        const char* names[] = {"iters_run", "t_end", "obj_vals", "avg_change", "adam_m", "adam_v", "ms_structure", "ms_pgd", "ms_total"};
-        plhs[1] = mxCreateStructMatrix(1, 1, 9, names);
+        const char* names[] = {"iters_run", "t_end", "obj_vals", "avg_change", "adam_m", "adam_v", "ms_structure", "ms_pgd", "ms_total",
+                               "svec_errors", "R_est_all"};
+        plhs[1] = mxCreateStructMatrix(1, 1, make_plots ? 11 : 9, names);
+        if (make_plots) { mxSetField(plhs[1], 0, "svec_errors", se); mxSetField(plhs[1], 0, "R_est_all", rall); }
         mxSetField(plhs[1], 0, "iters_run", mxCreateDoubleScalar(r.iters_run));
         mxSetField(plhs[1], 0, "t_end", mxCreateDoubleScalar(r.t_end));
         mxSetField(plhs[1], 0, "obj_vals", obj);

@@ -32,6 +32,8 @@ mxArray* mxCreateDoubleMatrix(mwSize, mwSize, mxComplexity);
 mxArray* mxCreateDoubleScalar(double);
 mxArray* mxCreateNumericArray(mwSize, const mwSize*, mxClassID, mxComplexity);
 mxArray* mxCreateStructMatrix(mwSize, mwSize, int, const char**);
+void mxSetN(mxArray*, mwSize);
+int mxSetDimensions(mxArray*, const mwSize*, mwSize);
 void mexErrMsgIdAndTxt(const char*, const char*, ...);
 int mexPrintf(const char*, ...);
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]);

@@ -475,6 +475,26 @@ def test_make_plots_traces(lib):
     _, _, mean_e, med_e = Rotation_Alignment(GCW(mo.Ind, mo.AdjMat, mo.RijMat, S), mo.R_orig)
     assert abs(info["MSE_means"][-1] - mean_e) < 1e-6 and abs(info["MSE_medians"][-1] - med_e) < 1e-6
     assert info["svec_errors"][-1] < info["svec_errors"][0]
+    S7 = DESC_PGD(mo.Ind, mo.RijMat, dict(base, iters=7, make_plots=False))      # entry t of the traces = the state after t iterations
+    assert abs(info["svec_errors"][6] - np.mean(np.abs(mo.ErrVec - S7))) < 1e-15
+    _, _, mean7, _ = Rotation_Alignment(GCW(mo.Ind, mo.AdjMat, mo.RijMat, S7), mo.R_orig)
+    assert abs(info["MSE_means"][6] - mean7) < 1e-6
+    # early stop (:243-246): the traces end with the run (library level: the wrapper keeps the reference's patience 30 / 1e-5)
+    mo2, n2, i2, j2, r2 = make_problem("uniform", n=40, p=0.5, q=0.1, sigma=0.0, seed=10)
+    prob = lib.ProblemArrays(n2, i2, j2, r2)
+    pr = c_params(400, lr=1.0, seed=1, patience=5, stop_tol=1e-3)
+    plain = lib.solve(prob, pr)
+    dp = lib.DeviceProblem(prob, 0)
+    st = lib.Structure.build(prob, pr.n_sample_min, pr.seed, lib.BUILD_DEVICE, 0)
+    sol = lib.Solver(dp, st, 0)
+    st.free()
+    tr = sol.run_traced(pr, dp, mo2.ErrVec)
+    assert plain["iters_run"] < 400 and tr["iters_run"] == plain["iters_run"]
+    assert np.array_equal(tr["S_vec"], plain["S_vec"]) and np.array_equal(tr["obj"], plain["obj"])
+    assert len(tr["svec_errors"]) == tr["iters_run"] and tr["R_est_all"].shape == (tr["iters_run"], 3, 3, n2)
+    Rg, _ = lib.gcw_run(dp, tr["S_vec"])
+    assert np.abs(tr["R_est_all"][-1] - Rg).max() < 1e-9           # same S_vec, same solver: the last estimate is GCW of the result
+    sol.destroy(); dp.free()
     with pytest.raises(ValueError):
         DESC_PGD(mo.Ind, mo.RijMat, dict(base, make_plots=True))          # ErrVec / R_orig are read when plotting (:236-238)
 
