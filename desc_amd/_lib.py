@@ -354,10 +354,10 @@ class Solver:
         check(load().desc_pgd_run(self.handle, C.byref(params), C.byref(r)))
         return self._pack(r, bufs)
 
-    def run_traced(self, params: Params, dprob, err_vec, gcw_tol=1e-13, gcw_max_iters=500):
+    def run_traced(self, params: Params, dprob, err_vec, gcw_tol=1e-13, gcw_max_iters=500, adam=None):
         """desc_pgd_run_traced (params.make_plots = true, DESC_PGD.m:235-239): the run plus svec_errors and the GCW estimate
         of every iteration, R_est_all (iters_run, 3, 3, n)."""
-        r, bufs = self._result(params.iters)
+        r, bufs = self._result(params.iters, adam=adam)
         n = dprob.n
         ev = np.ascontiguousarray(err_vec, dtype=np.float64).reshape(-1)
         if ev.size != self.m:

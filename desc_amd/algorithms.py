@@ -135,8 +135,6 @@ def DESC_PGD(Ind, RijMat, params, return_info=False, _marshalled=None):
     make_plots = bool(_get(params, "make_plots", False))
     if make_plots and (_get(params, "ErrVec") is None or _get(params, "R_orig") is None):
         raise ValueError("params.make_plots=true reads params.ErrVec and params.R_orig (DESC_PGD.m:236-238)")
-    if make_plots and isinstance(G, HybridGradient) and G.strategy == 0:
-        raise NotImplementedError("make_plots with the Adam plugin: the per-iteration path does not carry m_t / v_t")
     if _marshalled is None:
         n, ii, jj, rij, perm = marshal_edges(Ind, RijMat)
         if ii.shape[0] == 0:
@@ -182,7 +180,7 @@ def DESC_PGD(Ind, RijMat, params, return_info=False, _marshalled=None):
         if not make_plots:
             out = solver.run(p, adam=adam)
         else:
-            out = _run_with_plots(solver, p, params, prob, dprob, perm, verbose)
+            out = _run_with_plots(solver, p, params, prob, dprob, perm, verbose, adam)
     finally:
         solver.destroy()
     # plugin state after the run (handle-object semantics)
@@ -204,7 +202,7 @@ def DESC_PGD(Ind, RijMat, params, return_info=False, _marshalled=None):
     return S_vec
 
 
-def _run_with_plots(solver, p, params, prob, dprob, perm, verbose):
+def _run_with_plots(solver, p, params, prob, dprob, perm, verbose, adam=None):
     """params.make_plots = true (DESC_PGD.m:235-239): after every iteration the error of S_vec against params.ErrVec and
     the rotation error of GCW(S_vec) against params.R_orig (GlobalSOdCorrectRight = the alignment of Rotation_Alignment).
     A composition of device rows: one sweep, one S_vec download and one GCW eigen-solve per iteration."""
@@ -216,7 +214,7 @@ def _run_with_plots(solver, p, params, prob, dprob, perm, verbose):
     if perm is not None:
         ErrVec = ErrVec[perm]
     try:
-        out = solver.run_traced(p, dprob, ErrVec)                     # desc_pgd_run_traced: :236-237 for every iteration
+        out = solver.run_traced(p, dprob, ErrVec, adam=adam)                     # desc_pgd_run_traced: :236-237 for every iteration
     finally:
         if own is not None:
             own.free()

@@ -2441,16 +2441,28 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
     return DESC_OK;
 }
 
+// HybridGradient keeps m_t / v_t between calls (handle object): after desc_pgd_reset, the caller's moments of a run that
+// continues (t0 > 0) go to the parity sweep 1 reads
+static int upload_adam_state(desc_pgd* h, const desc_params* p, const desc_result* r) {
+    if (!(p->step_kind == DESC_STEP_HYBRID && p->hybrid_strategy == 0 && p->t0 > 0 && r->adam_m && r->adam_v && h->m_cycle > 0)) return DESC_OK;
+    int rc = ensure_scratch(h); if (rc) return rc;
+    rc = cycles_to_device(h, r->adam_m, h->d_adam_m[0]); if (rc) return rc;
+    DESC_HIP(hipStreamSynchronize(h->stream));
+    rc = cycles_to_device(h, r->adam_v, h->d_adam_v[0]); if (rc) return rc;
+    DESC_HIP(hipStreamSynchronize(h->stream));
+    return DESC_OK;
+}
+
 // params.make_plots = true (DESC_PGD.m:235-239) as a composition of device rows: one sweep, one S_vec download and one GCW
 // eigen-solve per iteration.  The alignment against R_orig (:238, GlobalSOdCorrectRight) stays with the caller.
 int desc_pgd_run_traced(desc_pgd* h, const desc_device_problem* dp, const desc_params* p, const double* err_vec, double gcw_tol,
                         int32_t gcw_max_iters, double* svec_errors, double* R_est_all, desc_result* r) {
     if (!h || !dp || !p || !r || !err_vec || !svec_errors || !R_est_all) return fail(DESC_ERR_INVALID, "NULL argument");
     if (!r->s_vec || !r->obj_trace || !r->avg_change_trace) return fail(DESC_ERR_INVALID, "the traced run needs s_vec, obj_trace and avg_change_trace");
-    if (p->step_kind == DESC_STEP_HYBRID && p->hybrid_strategy == 0) return fail(DESC_ERR_INVALID, "the traced run does not carry the Adam moments between its one-iteration pieces");
     if (dp->m != h->m || dp->n != h->n) return fail(DESC_ERR_INVALID, "device problem and solver handle describe different graphs");
     auto t0 = std::chrono::steady_clock::now();
     int rc = desc_pgd_reset(h, p); if (rc) return rc;
+    if ((rc = upload_adam_state(h, p, r))) return rc;        // the moments stay on the device between the one-iteration pieces
     desc_result mid = *r;                                    // same buffers; w / Adam state only in the final download
     mid.w = nullptr; mid.adam_m = nullptr; mid.adam_v = nullptr;
     int done = 0;
@@ -2475,14 +2487,7 @@ int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r) {
     if (!h || !p || !r) return fail(DESC_ERR_INVALID, "NULL argument");
     auto t0 = std::chrono::steady_clock::now();
     int rc = desc_pgd_reset(h, p); if (rc) return rc;
-    if (p->step_kind == DESC_STEP_HYBRID && p->hybrid_strategy == 0 && p->t0 > 0 && r->adam_m && r->adam_v && h->m_cycle > 0) {
-        // HybridGradient keeps m_t / v_t between calls (handle object)
-        rc = ensure_scratch(h); if (rc) return rc;
-        rc = cycles_to_device(h, r->adam_m, h->d_adam_m[0]); if (rc) return rc;      // sweep 1 reads parity 0
-        DESC_HIP(hipStreamSynchronize(h->stream));
-        rc = cycles_to_device(h, r->adam_v, h->d_adam_v[0]); if (rc) return rc;
-        DESC_HIP(hipStreamSynchronize(h->stream));
-    }
+    if ((rc = upload_adam_state(h, p, r))) return rc;
     // progress lines (DESC_PGD.m:241) are streamed while the loop runs: at every poll of the stop flag the traces of the
     // iterations that became final since the last poll are fetched and handed to the callback (or printed)
     const bool stream_lines = (p->progress != nullptr || p->verbose) && h->m_pos > 0;

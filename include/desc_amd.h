@@ -189,7 +189,7 @@ int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r);
  * GCW(S_vec) (:237) in R_est_all[(t-1) * 9n ...] (caller-allocated: iters entries / iters * 9n doubles; 3 x 3 x n column-major per
  * iteration).  MSE_means / MSE_medians (:238) = the caller's GlobalSOdCorrectRight(R_est, params.R_orig) of each estimate.
  * dp: the same problem resident on the handle's device.  r->s_vec, obj_trace, avg_change_trace are required.  Entries past
- * r->iters_run are untouched.  Not for the Adam plugin (its moments are not carried between the one-iteration pieces). */
+ * r->iters_run are untouched.  r->adam_m / adam_v as in desc_pgd_run. */
 int desc_pgd_run_traced(desc_pgd* h, const desc_device_problem* dp, const desc_params* p, const double* err_vec, double gcw_tol,
                         int32_t gcw_max_iters, double* svec_errors, double* R_est_all, desc_result* r);
 /* Pieces of desc_pgd_run, for benchmarks and the multi-GPU driver.  All work is

@@ -15,9 +15,6 @@
 %%   [S_vec, traces] = DESC_PGD(...)   traces.svec_errors / .MSE_means / .MSE_medians / .obj_vals
 function [S_vec, traces] = DESC_PGD(Ind, RijMat, params)
     make_plots = isfield(params, 'make_plots') && params.make_plots;
-    if make_plots && isa(params.Gradient, 'HybridGradient') && params.Gradient.strategy == 0
-        error('desc_amd:make_plots', 'params.make_plots=true is not available with the Adam plugin (strategy 0); use strategy 1 or another plugin.');
-    end
     % the reference silently requires Ind sorted as (1,2),(1,3),...,(2,3),... (DESC_PGD.m:5,31-34)
     [IndS, perm] = sortrows(double(Ind), [1 2]);
     if ~isequal(perm(:)', 1:size(Ind,1)), RijMat = RijMat(:,:,perm); end

@@ -6,7 +6,7 @@
  *             3x3xm array IS the library's m x 9 layout (element (r,c,l) at 9*l + r + 3*c)
  *     opt     struct: iters, step_kind, lr, beta1, beta2, decay_interval, hybrid_strategy, t0,
  *             seed, device, verbose (1: the reference's per-iteration line, printed while the loop runs),
- *             make_plots (1: DESC_PGD.m:235-239 -- needs ErrVec, 1 x m in the sorted edge order; not with Adam)
+ *             make_plots (1: DESC_PGD.m:235-239 -- needs ErrVec, 1 x m in the sorted edge order)
  *     adam_m/adam_v   [] or 1 x m_cycle (HybridGradient.m_t / v_t carried between calls)
  *   info: iters_run, t_end, obj_vals, avg_change, adam_m, adam_v, ms_structure, ms_pgd, ms_total; with make_plots also
  *         svec_errors (1 x iters_run) and R_est_all (3 x 3 x n x iters_run: GCW(S_vec) after every iteration)

@@ -495,6 +495,12 @@ def test_make_plots_traces(lib):
     Rg, _ = lib.gcw_run(dp, tr["S_vec"])
     assert np.abs(tr["R_est_all"][-1] - Rg).max() < 1e-9           # same S_vec, same solver: the last estimate is GCW of the result
     sol.destroy(); dp.free()
+    # the Adam plugin: moments stay on the device between the one-iteration pieces, and leave in the handle object as in a plain run
+    from desc_amd import HybridGradient
+    Ga, Gb = HybridGradient(0.01, 0.9, 0.999, 25), HybridGradient(0.01, 0.9, 0.999, 25)
+    Sa = DESC_PGD(mo.Ind, mo.RijMat, dict(iters=9, Gradient=Ga, seed=2, verbose=False, make_plots=False))
+    Sb, ib = DESC_PGD(mo.Ind, mo.RijMat, dict(iters=9, Gradient=Gb, seed=2, verbose=False, make_plots=True, ErrVec=mo.ErrVec, R_orig=mo.R_orig), return_info=True)
+    assert np.array_equal(Sa, Sb) and Ga.t == Gb.t == 9 and np.array_equal(Ga.m_t, Gb.m_t) and np.array_equal(Ga.v_t, Gb.v_t) and len(ib["MSE_means"]) == 9
     with pytest.raises(ValueError):
         DESC_PGD(mo.Ind, mo.RijMat, dict(base, make_plots=True))          # ErrVec / R_orig are read when plotting (:236-238)
 
