@@ -706,8 +706,10 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
     double* s_nv = s_dyn + b.row_cap;
     __shared__ double s_part[2][NT / 64];
     // segments of up to 64 cycles: 1024 threads (16 waves, <= 128 VGPRs each); up to 256 cycles (4 cycles per lane: twice the
-    // registers per pipeline stage): 512 threads (8 waves, <= 256 VGPRs).  Adam runs on k_sweep_node.
-    static_assert((LPS == 16 || LPS == 32 || LPS == 64) && LPS * E <= MAX_SEG_CYCLES && STEP != DESC_STEP_HYBRID && (NT == 512 || NT == 1024), "band sweep instances");
+    // registers per pipeline stage) and the Adam plugin (its two moments are two more streams in and out): 512 threads (8 waves, <= 256 VGPRs).
+    static_assert((LPS == 16 || LPS == 32 || LPS == 64) && LPS * E <= MAX_SEG_CYCLES && (NT == 512 || NT == 1024) && (STEP != DESC_STEP_HYBRID || NT == 512), "band sweep instances");
+    constexpr bool ADAM = STEP == DESC_STEP_HYBRID;
+    constexpr int EA = ADAM ? E : 1;
     if (a.state->stop) return;
     constexpr int NW = NT / 64, SPW = 64 / LPS;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
 
     struct RecRaw { int c0[SPW], c1[SPW]; EdgeInfo ei[SPW]; int t0; };      // wave-uniform (SGPRs)
     struct Rec { int c0, cnt, rbi, rbj, sa, sb, seg; };                   // this lane group's segment
-    struct Str { uint32_t pk[E]; double w[E], d[E]; };
+    struct Str { uint32_t pk[E]; double w[E], d[E], am[EA], av[EA]; };     // am / av: HybridGradient.m_t / v_t (Adam only)
     struct Gat { double sj[E], si[E], T1, T2, So; };
 
     const int p0 = uniform_load(b.piece_ptr, blockIdx.x), p1 = uniform_load(b.piece_ptr, blockIdx.x + 1);
@@ -757,6 +759,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
                 if (DESC_BAND_ABLATE & 128) {       // streamed once: non-temporal, so that the j-rows of S keep their place in the L2
                     x.pk[e] = __builtin_nontemporal_load(&a.pk[c]); x.w[e] = __builtin_nontemporal_load(&a.w_old[c]); x.d[e] = __builtin_nontemporal_load(&a.S0[c]);
                 } else { x.pk[e] = a.pk[c]; x.w[e] = a.w_old[c]; x.d[e] = a.S0[c]; }
+                if (ADAM) { x.am[e % EA] = a.st.adam_m[c]; x.av[e % EA] = a.st.adam_v[c]; }
             }
             return x;
         };
@@ -778,7 +781,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
         // arithmetic + stores of one segment group (DESC_PGD.m:193-233), everything in registers
         auto compute = [&](const Rec& r, const Str& x, const Gat& g) {
             const int cnt = r.cnt;
-            double ws[E];
+            double ws[E], mo[EA], vo[EA];
             uint32_t okm = 0;
             double part = 0.0;
             if (DESC_BAND_ABLATE & 2) {
@@ -804,6 +807,13 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     const double gr = ws[e] - dot * nv;
+                    if (ADAM) {                            // HybridGradient.m:28-35 (strategy 0): apply_step with the moments in registers
+                        const double mt = (a.st.beta1 * x.am[e % EA]) + (1.0 - a.st.beta1) * gr;
+                        const double vt = (a.st.beta2 * x.av[e % EA]) + (1.0 - a.st.beta2) * (gr * gr);
+                        mo[e % EA] = mt; vo[e % EA] = vt;
+                        const double cm = mt / a.st.bc1, cv = vt / a.st.bc2;
+                        ws[e] = ((okm >> e) & 1u) ? x.w[e] + (-a.st.lr * cm / (sqrt(cv) + 1e-8)) : 0.0;
+                    } else
                     ws[e] = ((okm >> e) & 1u) ? apply_step<STEP>(a.st, x.w[e], gr, 0) : 0.0;             // :207
                 }
                 uint32_t act = okm;                        // simplex threshold (:215-223), Michelot fixed point
@@ -844,6 +854,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
                 if ((okm >> e) & 1u) {
                     if (DESC_BAND_ABLATE & 256) __builtin_nontemporal_store(ws[e], &a.w_new[(int64_t)r.c0 + rr + LPS * e]);
                     else a.w_new[(int64_t)r.c0 + rr + LPS * e] = ws[e];
+                    if (ADAM) { a.st.adam_m_out[(int64_t)r.c0 + rr + LPS * e] = mo[e % EA]; a.st.adam_v_out[(int64_t)r.c0 + rr + LPS * e] = vo[e % EA]; }
                 }
             if (cnt > 0 && rr == 0) {
                 chg_acc += fabs(part - g.So);                                                            // :232
@@ -1514,28 +1525,47 @@ void launch_node(desc_pgd* h, const NodeSweepArgs& a) {
     }
 }
 
+template <int STEP>
 const void* band_kernel(const desc_pgd* h) {
+    constexpr int NT = STEP == DESC_STEP_HYBRID ? 512 : 1024;      // Adam: 8 waves, twice the registers (two more streams each way)
     switch (h->lps * 8 + h->G) {
-        case 16 * 8 + 1: return (const void*)k_sweep_band<16, 1, DESC_STEP_CONSTANT, 1024>;
-        case 16 * 8 + 2: return (const void*)k_sweep_band<16, 2, DESC_STEP_CONSTANT, 1024>;
-        case 32 * 8 + 2: return (const void*)k_sweep_band<32, 2, DESC_STEP_CONSTANT, 1024>;
-        case 32 * 8 + 4: return (const void*)k_sweep_band<32, 4, DESC_STEP_CONSTANT, 512>;
-        default: return (const void*)k_sweep_band<64, 4, DESC_STEP_CONSTANT, 512>;
+        case 16 * 8 + 1: return (const void*)k_sweep_band<16, 1, STEP, NT>;
+        case 16 * 8 + 2: return (const void*)k_sweep_band<16, 2, STEP, NT>;
+        case 32 * 8 + 2: return (const void*)k_sweep_band<32, 2, STEP, NT>;
+        default: break;
     }
+    if constexpr (STEP != DESC_STEP_HYBRID) {      // 4 cycles per lane + the Adam moments do not fit the registers: band_adam_ok()
+        if (h->lps == 32) return (const void*)k_sweep_band<32, 4, STEP, 512>;
+        return (const void*)k_sweep_band<64, 4, STEP, 512>;
+    }
+    return nullptr;
 }
+bool band_adam_ok(const desc_pgd* h) { return h->band_ok && h->G <= 2; }
+template <int STEP>
 void launch_band(desc_pgd* h, const NodeSweepArgs& a) {
+    constexpr int NT = STEP == DESC_STEP_HYBRID ? 512 : 1024;
     BandSweepArgs b{a, h->d_pieces, h->d_piece_ptr, h->band_rows};
     dim3 grid(h->band_grid);
     switch (h->lps * 8 + h->G) {
-        case 16 * 8 + 1: hipLaunchKernelGGL((k_sweep_band<16, 1, DESC_STEP_CONSTANT, 1024>), grid, dim3(1024), h->band_lds, h->stream, b); break;
-        case 16 * 8 + 2: hipLaunchKernelGGL((k_sweep_band<16, 2, DESC_STEP_CONSTANT, 1024>), grid, dim3(1024), h->band_lds, h->stream, b); break;
-        case 32 * 8 + 2: hipLaunchKernelGGL((k_sweep_band<32, 2, DESC_STEP_CONSTANT, 1024>), grid, dim3(1024), h->band_lds, h->stream, b); break;
-        case 32 * 8 + 4: hipLaunchKernelGGL((k_sweep_band<32, 4, DESC_STEP_CONSTANT, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
-        default: hipLaunchKernelGGL((k_sweep_band<64, 4, DESC_STEP_CONSTANT, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
+        case 16 * 8 + 1: hipLaunchKernelGGL((k_sweep_band<16, 1, STEP, NT>), grid, dim3(NT), h->band_lds, h->stream, b); break;
+        case 16 * 8 + 2: hipLaunchKernelGGL((k_sweep_band<16, 2, STEP, NT>), grid, dim3(NT), h->band_lds, h->stream, b); break;
+        case 32 * 8 + 2: hipLaunchKernelGGL((k_sweep_band<32, 2, STEP, NT>), grid, dim3(NT), h->band_lds, h->stream, b); break;
+        default:
+            if constexpr (STEP != DESC_STEP_HYBRID) {
+                if (h->lps == 32) hipLaunchKernelGGL((k_sweep_band<32, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b);
+                else hipLaunchKernelGGL((k_sweep_band<64, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b);
+            }
+            break;
     }
 }
+void launch_sweep_node_layout(desc_pgd* h, const NodeSweepArgs& a, bool adam) {
+    if (h->band_ok && !adam) launch_band<DESC_STEP_CONSTANT>(h, a);
+    else if (adam && band_adam_ok(h)) launch_band<DESC_STEP_HYBRID>(h, a);
+    else if (adam) launch_node<DESC_STEP_HYBRID>(h, a);
+    else launch_node<DESC_STEP_CONSTANT>(h, a);
+}
 // workgroups (= partial pairs) of the sweep kernel that serves this step kind
-int sweep_parts(const desc_pgd* h, bool adam) { return h->variant == VARIANT_NODE && h->band_ok && !adam ? h->band_grid : h->grid; }
+int sweep_parts(const desc_pgd* h, bool adam) { return h->variant == VARIANT_NODE && (adam ? band_adam_ok(h) : h->band_ok) ? h->band_grid : h->grid; }
 
 FinArgs fin_args(const desc_pgd* h, const double* partials, int nparts, int t, int last_only) {
     return FinArgs{partials, h->d_state, h->d_obj, h->d_avg, h->m, h->p.stop_tol, nparts, t, h->p.patience, last_only, 0, 1};
@@ -1562,7 +1592,7 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
         a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
         a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->d_T; a.t_seg_lo = -1; a.nv_tab = h->d_nv; a.partials = h->d_partials;
         a.state = h->d_state; a.st = st; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks; a.max_cnt = h->max_cnt; a.ablate = h->ablate;
-        if (adam) launch_node<DESC_STEP_HYBRID>(h, a); else if (h->band_ok) launch_band(h, a); else launch_node<DESC_STEP_CONSTANT>(h, a);
+        launch_sweep_node_layout(h, a, adam);
     } else {
         SweepArgs a{};
         a.cum = h->d_cum; a.pos_edge = h->d_pos_edge; a.e_jk = h->d_ejk; a.e_ki = h->d_eki; a.ikj = h->d_ikj; a.jki = h->d_jki;
@@ -2067,8 +2097,8 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     }
     if (h->band_ok) {      // the band rows + the nv table in dynamic LDS: more than the 64 KiB default
         h->band_lds = ((size_t)h->band_rows + MAX_SEG_CYCLES + 1) * sizeof(double);
-        const void* kb = band_kernel(h);
-        if (hipFuncSetAttribute(kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->band_lds) != hipSuccess) { (void)hipGetLastError(); h->band_ok = false; }
+        for (const void* kb : {band_kernel<DESC_STEP_CONSTANT>(h), band_kernel<DESC_STEP_HYBRID>(h)})
+            if (kb && hipFuncSetAttribute(kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->band_lds) != hipSuccess) { (void)hipGetLastError(); h->band_ok = false; }
     }
     char nm[64];
     if (h->band_ok) snprintf(nm, sizeof nm, "k_sweep_band<%d,%d,", h->lps, h->G);
@@ -2598,7 +2628,7 @@ int shard_enqueue_sweep(desc_pgd* h, hipStream_t st) {
     a.state = h->d_state; a.st = sa; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks;
     a.max_cnt = h->max_cnt; a.ablate = 0;
     const hipStream_t keep = h->stream; h->stream = st;
-    if (adam) launch_node<DESC_STEP_HYBRID>(h, a); else if (h->band_ok) launch_band(h, a); else launch_node<DESC_STEP_CONSTANT>(h, a);
+    launch_sweep_node_layout(h, a, adam);
     h->stream = keep;
     h->last_parts = sweep_parts(h, adam);
     DESC_HIP(hipGetLastError());
