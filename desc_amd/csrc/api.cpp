@@ -3,6 +3,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 
 #include "common.h"
@@ -130,7 +131,8 @@ int desc_structure_sizes(const desc_structure* s, desc_structure_info* info) {
 
 void desc_structure_free(desc_structure* s) { if (s) { structure_free_device(s); delete s; } }
 // (Releasing the host side -- tens of megabytes of index vectors, 10+ ms of page-table work at C4 -- on a background thread was
-//  tried: it contends with the launching thread for the process's memory map and the PGD loop that follows lost what it saved.)
+//  tried: it contends with the launching thread for the process's memory map and the PGD loop that follows lost what it saved.
+//  desc_pgd_solve does it on the calling thread while the device runs the first iterations: pgd_set_idle_hook.)
 
 int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* r) {
     if (!p || !r) return fail(DESC_ERR_INVALID, "NULL argument");
@@ -157,9 +159,14 @@ int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* 
     desc_pgd* h = nullptr;
     rc = desc_pgd_create(prob, s, p->device, &h);
     lap("create");
-    desc_structure_free(s);
+    structure_free_device(s);                 // parks the blocks: microseconds
+    if (rc) { delete s; return rc; }
+    {   // the host side of the structure (tens of megabytes of index vectors: 4-12 ms of page-table work at C4 / C5) is released by
+        // this thread while the device runs the first iterations
+        std::shared_ptr<desc_structure> sp(s, [](desc_structure* q) { delete q; });
+        pgd_set_idle_hook(h, [sp]() mutable { sp.reset(); });
+    }
     lap("structure free");
-    if (rc) return rc;
     rc = desc_pgd_run(h, p, r);
     lap("run + download");
     desc_pgd_destroy(h);

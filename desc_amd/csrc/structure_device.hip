@@ -336,8 +336,9 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
         hipLaunchKernelGGL(k_bitmaps, dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, 0, s->d_rowptr, s->d_adj, d_bits, (int)n, (int)words);
         hipLaunchKernelGGL(k_rank, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_bits, s->d_rank, (int)n, (int)words);
     }
-    if (m > 0)
-        hipLaunchKernelGGL(k_codeg, dim3((unsigned)std::min<int64_t>(2048, (m + 3) / 4)), dim3(256), 0, 0, s->d_ii, s->d_jj, d_bits, d_codeg, d_hist, m, (int)words, (int)(n + 1));
+    if (m > 0)      // a codegree is at most the smaller degree: max_deg + 1 bins (in LDS up to 8192; n + 1 would push n > 8191 onto global atomics -- 30 ms at n = 10000)
+        hipLaunchKernelGGL(k_codeg, dim3((unsigned)std::min<int64_t>(2048, (m + 3) / 4)), dim3(256), 0, 0, s->d_ii, s->d_jj, d_bits, d_codeg, d_hist, m, (int)words,
+                           (int)std::min<int64_t>(n + 1, (int64_t)s->max_deg + 1));
     DESC_HIP(hipGetLastError());
     s->codeg.assign((size_t)m, 0);
     std::vector<int32_t> hist((size_t)n + 1, 0);
