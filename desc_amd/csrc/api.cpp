@@ -3,7 +3,6 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
-#include <memory>
 #include <new>
 
 #include "common.h"
@@ -132,7 +131,8 @@ int desc_structure_sizes(const desc_structure* s, desc_structure_info* info) {
 void desc_structure_free(desc_structure* s) { if (s) { structure_free_device(s); delete s; } }
 // (Releasing the host side -- tens of megabytes of index vectors, 10+ ms of page-table work at C4 -- on a background thread was
 //  tried: it contends with the launching thread for the process's memory map and the PGD loop that follows lost what it saved.
-//  desc_pgd_solve does it on the calling thread while the device runs the first iterations: pgd_set_idle_hook.)
+//  Doing it on the calling thread while the device runs the first iterations was tried too: the unmapping stalls the kernel that is
+//  running -- one sweep of 16-26 ms instead of 1.2 ms in the rocprofv3 trace at C4 -- for as long as it takes.)
 
 int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* r) {
     if (!p || !r) return fail(DESC_ERR_INVALID, "NULL argument");
@@ -159,14 +159,9 @@ int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* 
     desc_pgd* h = nullptr;
     rc = desc_pgd_create(prob, s, p->device, &h);
     lap("create");
-    structure_free_device(s);                 // parks the blocks: microseconds
-    if (rc) { delete s; return rc; }
-    {   // the host side of the structure (tens of megabytes of index vectors: 4-12 ms of page-table work at C4 / C5) is released by
-        // this thread while the device runs the first iterations
-        std::shared_ptr<desc_structure> sp(s, [](desc_structure* q) { delete q; });
-        pgd_set_idle_hook(h, [sp]() mutable { sp.reset(); });
-    }
+    desc_structure_free(s);
     lap("structure free");
+    if (rc) return rc;
     rc = desc_pgd_run(h, p, r);
     lap("run + download");
     desc_pgd_destroy(h);

@@ -3,7 +3,6 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
-#include <functional>
 #include <string>
 #include <vector>
 
@@ -93,7 +92,4 @@ int build_cemp_samples_device(const desc_device_problem* dp, int32_t nsample, ui
 inline desc_problem host_view(const desc_device_problem* dp) { return desc_problem{dp->n, dp->m, dp->ii.data(), dp->jj.data(), nullptr}; }
 int build_cemp_samples_host(const desc_problem* prob, int32_t nsample, uint64_t seed, std::vector<int32_t>& pos_edge,
                             std::vector<int32_t>& kk, std::vector<int32_t>& e_jk, std::vector<int32_t>& e_ki);
-// One-shot hook run by the solver's next desc_pgd_iterate* call after it has enqueued its sweeps and before it waits for them: host
-// work that nothing depends on (desc_pgd_solve: releasing the structure's host arrays) then overlaps the device's first iterations.
-void pgd_set_idle_hook(desc_pgd* h, std::function<void()> f);
 }  // namespace desc

@@ -1360,7 +1360,6 @@ using namespace desc;
 enum { VARIANT_GATHER = 1, VARIANT_NODE = 2 };
 
 struct desc_pgd {
-    std::function<void()> idle_hook;      // pgd_set_idle_hook
     int device = 0;
     hipStream_t stream = nullptr;
     int64_t n = 0, m = 0, m_pos = 0, m_cycle = 0;
@@ -2197,10 +2196,6 @@ int ensure_scratch(desc_pgd* h) {
 
 }  // namespace
 
-namespace desc {
-void pgd_set_idle_hook(desc_pgd* h, std::function<void()> f) { if (h) h->idle_hook = std::move(f); }
-}  // namespace desc
-
 extern "C" {
 
 int desc_device_count(void) {
@@ -2390,7 +2385,6 @@ int desc_pgd_iterate_timed(desc_pgd* h, int32_t n_iters, float* ms_total, float*
         }
     else { h->t_done += n_iters; h->t_plugin += n_iters; }
     DESC_HIP(hipEventRecord(e1, h->stream));
-    if (h->idle_hook) { auto f = std::move(h->idle_hook); h->idle_hook = nullptr; f(); }      // the device is busy with the sweeps just enqueued
     DESC_HIP(hipStreamSynchronize(h->stream));
     float ms = 0; DESC_HIP(hipEventElapsedTime(&ms, e0, e1));
     if (ms_total) *ms_total = ms;
