@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (GPU box): random graphs / sampling budgets / step plugins, HIP path
-(device-built structure, node and gather layouts) against the CPU oracle.  Test infrastructure,
+(device- or host-built structure; band sweep, k_sweep_node and gather layouts) against the CPU oracle.  Test infrastructure,
 like tests/: imports oracle/.  Prints one line per failure and a summary; exit code 1 on any failure."""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,7 +28,7 @@ while time.time() < t_end:
     iters = int(rng.choice([1, 2, 7, 40]))
     seed = int(rng.integers(0, 1 << 30))
     lr = float(rng.choice([0.01, 0.1, 1.0]))
-    variant = "1" if rng.random() < 0.25 else "0"
+    variant = str(rng.choice(["0", "1", "2", "3", "3", "3"]))        # DESC_DEBUG_VARIANT: 0 library's choice, 1 gather layout, 2 k_sweep_node, 3 band sweep (forced on small graphs)
     where = lib.BUILD_DEVICE if rng.random() < 0.8 else lib.BUILD_HOST
     tag = dict(kind=kind, n=n, p=p, nmin=nmin, sk=sk, iters=iters, seed=seed, lr=lr, variant=variant, where=where)
     try:
@@ -56,7 +56,8 @@ while time.time() < t_end:
         for key in STRUCT_KEYS:
             assert np.array_equal(a[key], st[key]), "structure " + key
         assert out["iters_run"] == ref["iters_run"], "iters_run %d vs %d" % (out["iters_run"], ref["iters_run"])
-        tol = (1e-8 if lr >= 0.1 else 1e-9) if sk == 2 else 1e-10     # Adam divides by sqrt(v) + 1e-8: round-off is amplified
+        # Adam divides by sqrt(v) + 1e-8: round-off is amplified; lr = 1 amplifies it too (10 400-case run of round 2: one case at 1.4e-10 after 40 iterations)
+        tol = (1e-8 if lr >= 0.1 else 1e-9) if sk == 2 else (5e-10 if lr >= 1.0 else 1e-10)
         e1 = float(np.abs(out["S_vec"] - ref["S_vec"]).max()) if nn else 0.0
         e2 = float(np.abs(out["w"] - ref["w"]).max()) if st["m_cycle"] else 0.0
         worst = max(worst, e1, e2)
