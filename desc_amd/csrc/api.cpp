@@ -159,8 +159,10 @@ int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* 
     desc_pgd* h = nullptr;
     rc = desc_pgd_create(prob, s, p->device, &h);
     lap("create");
-    desc_structure_free(s);
-    lap("structure free");
+    structure_free_device(s);
+    lap("structure free dev");
+    delete s;
+    lap("structure free host");
     if (rc) return rc;
     rc = desc_pgd_run(h, p, r);
     lap("run + download");

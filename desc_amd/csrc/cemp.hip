@@ -107,7 +107,7 @@ __global__ void k_fill1(double* p, int64_t n, double v) {
 }
 
 struct DevC {
-    std::vector<void*> p;
+    hvec<void*> p;
     ~DevC() { for (void* q : p) dev_free(q); }
     template <class T> int alloc(T** out, size_t count) {
         void* q = nullptr;
@@ -149,7 +149,7 @@ extern "C" int desc_cemp_run_dev(const desc_device_problem* dp, const double* be
     struct Owned { int32_t **a, **b, **c, **d; ~Owned() { for (int32_t** q : {a, b, c, d}) if (*q) dev_free(*q); } } owned{&d_pos, &d_k, &d_ejk, &d_eki};
     rc = build_cemp_samples_device(dp, nsample, seed, &mp, &d_pos, &d_k, &d_ejk, &d_eki);
     if (rc == DESC_ERR_TOO_LARGE) {
-        std::vector<int32_t> pos_edge, kk, e_jk, e_ki;
+        hvec<int32_t> pos_edge, kk, e_jk, e_ki;
         const desc_problem hv = host_view(dp);
         if ((rc = build_cemp_samples_host(&hv, nsample, seed, pos_edge, kk, e_jk, e_ki))) return rc;
         mp = (int64_t)pos_edge.size();

@@ -7,6 +7,8 @@
 #include <vector>
 
 #include "desc_amd.h"
+#include "hostmem.h"
+using desc::hvec;      // every host vector of the library: pooled large blocks (hostmem.h)
 
 namespace desc {
 
@@ -32,10 +34,10 @@ inline uint64_t sample_key(uint64_t seed, uint64_t edge, uint64_t k) {
 struct desc_structure {
     int64_t n = 0, m = 0, m_pos = 0, m_cycle = 0;
     int32_t n_sample = 0, max_cnt = 0;
-    std::vector<int32_t> codeg, pos_edge;
-    std::vector<int64_t> cum_ind;
-    std::vector<int32_t> rowptr_host;                // CSR row starts of the graph, when the builder made them (device builder)
-    std::vector<int32_t> k, e_jk, e_ki, ikj, jki;   // per-cycle arrays on the host (valid iff host_cycles)
+    hvec<int32_t> codeg, pos_edge;
+    hvec<int64_t> cum_ind;
+    hvec<int32_t> rowptr_host;                // CSR row starts of the graph, when the builder made them (device builder)
+    hvec<int32_t> k, e_jk, e_ki, ikj, jki;   // per-cycle arrays on the host (valid iff host_cycles)
     double ms_build = 0.0;
     // A structure built on the device stays there in a lean form: the sampled third vertices `k`
     // (natural order), per edge-with-cycles the selection threshold (largest selected key and its k;
@@ -63,7 +65,7 @@ struct desc_structure {
 struct desc_device_problem {
     int device = 0;
     int64_t n = 0, m = 0;
-    std::vector<int32_t> ii, jj, rowptr;      // host copies of the index data (O(m) host passes: degrees, validation)
+    hvec<int32_t> ii, jj, rowptr;      // host copies of the index data (O(m) host passes: degrees, validation)
     int32_t *d_ii = nullptr, *d_jj = nullptr, *d_rowptr = nullptr, *d_adj = nullptr, *d_adj_eid = nullptr;
     double* d_rij = nullptr;
     double ms_upload = 0.0;
@@ -79,8 +81,8 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
 int validate_problem(const desc_problem* prob, bool need_rij);
 // CSR adjacency of the undirected graph (neighbours ascending, edge id per slot); Ind must be sorted by (i,j).
 // Multithreaded for large m; the result does not depend on the thread count.
-void build_csr(int64_t n, int64_t m, const int32_t* ii, const int32_t* jj, std::vector<int32_t>& rowptr, std::vector<int32_t>& adj,
-               std::vector<int32_t>& adj_eid);
+void build_csr(int64_t n, int64_t m, const int32_t* ii, const int32_t* jj, hvec<int32_t>& rowptr, hvec<int32_t>& adj,
+               hvec<int32_t>& adj_eid);
 // device-resident structures (structure_device.hip)
 int structure_ensure_host(desc_structure* s);      // copy the per-cycle arrays to the host if they live on the device
 void structure_free_device(desc_structure* s);
@@ -90,6 +92,6 @@ int build_cemp_samples_device(const desc_device_problem* dp, int32_t nsample, ui
                               int32_t** d_pos, int32_t** d_k, int32_t** d_ejk, int32_t** d_eki);
 // the desc_problem view of a device problem's host index copies (rij = NULL)
 inline desc_problem host_view(const desc_device_problem* dp) { return desc_problem{dp->n, dp->m, dp->ii.data(), dp->jj.data(), nullptr}; }
-int build_cemp_samples_host(const desc_problem* prob, int32_t nsample, uint64_t seed, std::vector<int32_t>& pos_edge,
-                            std::vector<int32_t>& kk, std::vector<int32_t>& e_jk, std::vector<int32_t>& e_ki);
+int build_cemp_samples_host(const desc_problem* prob, int32_t nsample, uint64_t seed, hvec<int32_t>& pos_edge,
+                            hvec<int32_t>& kk, hvec<int32_t>& e_jk, hvec<int32_t>& e_ki);
 }  // namespace desc

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "device_utils.h"
+#include "hostmem.h"
 
 namespace desc {
 namespace {
@@ -85,9 +86,73 @@ void dev_free(void* p) {
     if (cur != b.dev) (void)hipSetDevice(cur);
 }
 
+
+// ---- host blocks (hostmem.h)
+namespace {
+constexpr size_t HOST_POOL_MIN = 256 << 10;
+struct HBlock { void* p; size_t bytes; };
+std::mutex g_hmu;
+std::vector<HBlock> g_hparked;
+std::unordered_map<void*, size_t> g_hlive;            // pooled blocks handed out -> their real size
+size_t g_hparked_bytes = 0;
+size_t host_cache_cap() {
+    static size_t cap = [] { const char* e = std::getenv("DESC_HOST_CACHE_MB"); return (size_t)(e ? std::atoll(e) : 1024) << 20; }();
+    return cap;
+}
+}  // namespace
+
+void* host_block_alloc(size_t bytes) {
+    if (bytes < HOST_POOL_MIN) return ::operator new(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_hmu);
+        size_t best = (size_t)-1, bi = 0;
+        for (size_t i = 0; i < g_hparked.size(); ++i) {
+            const HBlock& b = g_hparked[i];
+            if (b.bytes >= bytes && b.bytes <= bytes + bytes / 4 && b.bytes < best) { best = b.bytes; bi = i; }
+        }
+        if (best != (size_t)-1) {
+            const HBlock b = g_hparked[bi];
+            g_hparked[bi] = g_hparked.back(); g_hparked.pop_back();
+            g_hparked_bytes -= b.bytes;
+            g_hlive[b.p] = b.bytes;
+            return b.p;
+        }
+    }
+    void* p = ::operator new(bytes);
+    std::lock_guard<std::mutex> lk(g_hmu);
+    g_hlive[p] = bytes;
+    return p;
+}
+void host_block_free(void* p, size_t bytes) {
+    if (!p) return;
+    if (bytes < HOST_POOL_MIN) { ::operator delete(p); return; }
+    {
+        std::lock_guard<std::mutex> lk(g_hmu);
+        auto it = g_hlive.find(p);
+        if (it != g_hlive.end()) {
+            const size_t real = it->second;
+            g_hlive.erase(it);
+            if (g_hparked_bytes + real <= host_cache_cap()) { g_hparked.push_back(HBlock{p, real}); g_hparked_bytes += real; return; }
+        }
+    }
+    ::operator delete(p);
+}
+size_t host_block_trim() {
+    std::vector<HBlock> blocks;
+    {
+        std::lock_guard<std::mutex> lk(g_hmu);
+        blocks.swap(g_hparked);
+        g_hparked_bytes = 0;
+    }
+    size_t freed = 0;
+    for (const HBlock& b : blocks) { ::operator delete(b.p); freed += b.bytes; }
+    return freed;
+}
+
 }  // namespace desc
 
 extern "C" int64_t desc_trim_memory(void) {
+    (void)desc::host_block_trim();
     std::vector<desc::Block> blocks;
     {
         std::lock_guard<std::mutex> lk(desc::g_mu);

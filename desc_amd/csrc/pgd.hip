@@ -1376,7 +1376,7 @@ struct desc_pgd {
     size_t band_lds = 0;
     PieceDesc* d_pieces = nullptr;
     int32_t* d_piece_ptr = nullptr;
-    std::vector<void*> allocs;
+    hvec<void*> allocs;
     // common
     int32_t* d_cum = nullptr;
     double *d_S0 = nullptr, *d_w[2] = {nullptr, nullptr}, *d_S[2] = {nullptr, nullptr};
@@ -1407,7 +1407,7 @@ struct desc_pgd {
     hipStream_t comm_stream = nullptr;  // second stream: exchange + unpack overlap the next column-sum pass
     hipEvent_t ev_col = nullptr, ev_rs = nullptr, ev_sw = nullptr, ev_done = nullptr;
     bool own_xbuf = false, force_coll = false;
-    std::vector<int64_t> rank_seg;      // world+1 segment boundaries
+    hvec<int64_t> rank_seg;      // world+1 segment boundaries
     double* x_T = nullptr;              // caller-bound exchange buffers (device): owner-sorted partial mirror sums (send)
     double* x_Trecv = nullptr;          // reduce-scattered mirror sums of the owned segments
     int32_t* d_xpos = nullptr;          // 2m: CSR slot -> position in x_T
@@ -1475,7 +1475,7 @@ void host_parallel(int64_t count, F&& body, int64_t grain = 65536) {
     unsigned hw = std::thread::hardware_concurrency();
     int nt = (int)std::min<int64_t>(std::max(1u, std::min(hw, 16u)), std::max<int64_t>(1, count / grain));
     if (nt <= 1) { body(0, count); return; }
-    std::vector<std::thread> th;
+    hvec<std::thread> th;
     for (int t = 0; t < nt; ++t) th.emplace_back([=, &body]() { body(count * t / nt, count * (t + 1) / nt); });
     for (auto& x : th) x.join();
 }
@@ -1637,7 +1637,7 @@ int setup_gather(desc_pgd* h, const desc_problem* prob, const desc_structure* s,
     h->kname = nm;
 
     auto t0 = std::chrono::steady_clock::now();
-    std::vector<int32_t> cum32((size_t)mp + 1);
+    hvec<int32_t> cum32((size_t)mp + 1);
     for (int64_t l = 0; l <= mp; ++l) cum32[l] = (int32_t)s->cum_ind[l];
     int32_t *d_k = nullptr, *d_ii = nullptr, *d_jj = nullptr; double* d_rij = nullptr;
     if ((rc = dalloc(h, &d_k, mc))) return rc;
@@ -1682,13 +1682,13 @@ int setup_gather(desc_pgd* h, const desc_problem* prob, const desc_structure* s,
 // and the chunk ranges of the `world` ranks (contiguous, equal numbers of chunks).
 struct NodePlan {
     int band = 0;                     // nodes per band (fixed-size bands), 0: LDS-sized bands
-    std::vector<int32_t> band_lo;     // nbands+1: first node of every band
-    std::vector<int64_t> bstart;      // nbands+1: first device position (= position in pos_edge) of every band
-    std::vector<int32_t> rowptr;      // n+1: CSR row starts (degrees prefix-summed)
-    std::vector<int32_t> order;       // device position -> index into s->pos_edge
-    std::vector<int32_t> cum2;        // m_pos+1, device order, global cycle numbering
-    std::vector<int32_t> chunk_seg;   // nchunks+1
-    std::vector<int64_t> rank_chunk;  // world+1
+    hvec<int32_t> band_lo;     // nbands+1: first node of every band
+    hvec<int64_t> bstart;      // nbands+1: first device position (= position in pos_edge) of every band
+    hvec<int32_t> rowptr;      // n+1: CSR row starts (degrees prefix-summed)
+    hvec<int32_t> order;       // device position -> index into s->pos_edge
+    hvec<int32_t> cum2;        // m_pos+1, device order, global cycle numbering
+    hvec<int32_t> chunk_seg;   // nchunks+1
+    hvec<int64_t> rank_chunk;  // world+1
 };
 
 // row_cap > 0: bands = maximal runs of consecutive nodes whose CSR rows hold <= row_cap entries together (the band
@@ -1733,7 +1733,7 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
         }
     }
     host_parallel(nb, [&](int64_t b0, int64_t b1) {
-        std::vector<int32_t> cnt((size_t)n + 1);
+        hvec<int32_t> cnt((size_t)n + 1);
         for (int64_t b = b0; b < b1; ++b) {
             const int64_t lo = P.bstart[b], hi = P.bstart[b + 1];
             if (lo == hi) continue;
@@ -1771,12 +1771,12 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
 //    that at any moment all workgroups gather from the same block of rows.
 // Host only: no device call (also reachable through desc_debug_band_plan, which the CPU tests and sanitizer builds use).
 void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const NodePlan& P, int64_t seg_lo, int64_t seg_hi, int64_t cyc_lo, int64_t mcl,
-                      int G, std::vector<PieceDesc>& pieces, std::vector<int32_t>& piece_ptr, int& band_rows, bool& jmajor_out) {
-    const std::vector<int32_t>& cum2 = P.cum2;
+                      int G, hvec<PieceDesc>& pieces, hvec<int32_t>& piece_ptr, int& band_rows, bool& jmajor_out) {
+    const hvec<int32_t>& cum2 = P.cum2;
     const int64_t n = prob->n, m = prob->m;
     band_rows = 0;
     const int64_t nbands = (int64_t)P.band_lo.size() - 1;
-    std::vector<std::vector<PieceDesc>> per_wg((size_t)G);
+    hvec<hvec<PieceDesc>> per_wg((size_t)G);
     auto piece_of = [&](int64_t bd, int64_t q0, int64_t q1) {
         const int32_t row_lo = P.rowptr[P.band_lo[bd]], row_len = P.rowptr[P.band_lo[bd + 1]] - row_lo;
         band_rows = std::max(band_rows, (int)row_len);
@@ -1813,13 +1813,13 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
         const int64_t nJ = (n + JB - 1) / JB;
         auto j_of = [&](int64_t q) { return (int64_t)prob->ind_j[s->pos_edge[P.order[q]]]; };
         // position of the first segment of band bd with j >= jlim, inside the rank's range
-        std::vector<int64_t> cur((size_t)nbands), bend((size_t)nbands);
+        hvec<int64_t> cur((size_t)nbands), bend((size_t)nbands);
         for (int64_t bd = 0; bd < nbands; ++bd) {
             cur[bd] = std::min(std::max(P.bstart[bd], seg_lo), seg_hi);
             bend[bd] = std::min(std::max(P.bstart[bd + 1], seg_lo), seg_hi);
         }
         // min-heap over (load, wg): the next unit goes to the workgroup that would be free first
-        std::vector<std::pair<int64_t, int>> heap; heap.reserve((size_t)G);
+        hvec<std::pair<int64_t, int>> heap; heap.reserve((size_t)G);
         for (int b = 0; b < G; ++b) heap.push_back({0, b});
         auto cmp = [](const std::pair<int64_t, int>& x, const std::pair<int64_t, int>& y) { return x > y; };
         std::make_heap(heap.begin(), heap.end(), cmp);
@@ -1881,7 +1881,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     if ((rc = make_node_plan(prob, s, h->max_deg, h->world, h->max_cnt <= 32 ? 32 : h->max_cnt <= 128 ? 16 : 8, h->band_ok ? BAND_ROW_CAP : 0, P))) return rc;   // 8 waves x 64/lps segments
     h->band = P.band;
     lap("plan");
-    const std::vector<int32_t>& cum2 = P.cum2;
+    const hvec<int32_t>& cum2 = P.cum2;
     const int64_t nch_all = (int64_t)P.chunk_seg.size() - 1;
     const int64_t ch_a = P.rank_chunk[h->rank], ch_b = P.rank_chunk[h->rank + 1];
     h->ch_lo = (int)ch_a; h->nchunks = (int)(ch_b - ch_a);
@@ -1897,7 +1897,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     const int64_t mcl = h->cyc_hi - h->cyc_lo;            // local cycles
     const int64_t nsl = h->seg_hi - h->seg_lo;            // local segments
     // band sweep: the work of every workgroup as a list of pieces (plan_band_pieces)
-    std::vector<PieceDesc> pieces; std::vector<int32_t> piece_ptr;
+    hvec<PieceDesc> pieces; hvec<int32_t> piece_ptr;
     if (h->band_ok) {
         h->band_grid = ncu;
         bool jmajor = false;
@@ -1910,14 +1910,14 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     // per-edge tables and the cycle layout are then made by kernels and the host only plans.
     const bool dev_cycles = s->dev == h->device && s->d_k != nullptr;
     // CSR adjacency (neighbours ascending; single pass because Ind is sorted by (i,j))
-    std::vector<int32_t> rowptr, adj, adj_eid, eslot, eslot_b;
+    hvec<int32_t> rowptr, adj, adj_eid, eslot, eslot_b;
     if (!dev_cycles) {
         rowptr.assign((size_t)n + 1, 0); adj.resize((size_t)2 * m); adj_eid.resize((size_t)2 * m);
         for (int64_t e = 0; e < m; ++e) { rowptr[prob->ind_i[e] + 1]++; rowptr[prob->ind_j[e] + 1]++; }
         for (int64_t v = 0; v < n; ++v) rowptr[v + 1] += rowptr[v];
         // slot of every edge in its two endpoint rows (eslot: smaller endpoint, for S_vec extraction)
         eslot.resize((size_t)m); eslot_b.resize((size_t)m);
-        std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
+        hvec<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
         for (int64_t e = 0; e < m; ++e) {
             const int32_t i = prob->ind_i[e], j = prob->ind_j[e];
             eslot[e] = fill[i]; eslot_b[e] = fill[j];
@@ -1926,8 +1926,8 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         }
     }
     lap("csr+eslot");
-    std::vector<int32_t> cum_loc((size_t)mp + 1), src_start((size_t)mp), pos_edge2((size_t)mp), devpos((size_t)m, -1);
-    std::vector<EdgeInfo> einfo;
+    hvec<int32_t> cum_loc((size_t)mp + 1), src_start((size_t)mp), pos_edge2((size_t)mp), devpos((size_t)m, -1);
+    hvec<EdgeInfo> einfo;
     cum_loc[mp] = cum2[mp] - (int32_t)h->cyc_lo;
     host_parallel(mp, [&](int64_t a, int64_t b) {
         for (int64_t q = a; q < b; ++q) {
@@ -1947,7 +1947,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         });
     }
     lap("einfo");
-    std::vector<uint32_t> kf; std::vector<uint8_t> seg_perm; std::vector<uint32_t> seg_counts; std::vector<int2> adj_seg;
+    hvec<uint32_t> kf; hvec<uint8_t> seg_perm; hvec<uint32_t> seg_counts; hvec<int2> adj_seg;
     if (!dev_cycles) {
         if ((rc = structure_ensure_host(const_cast<desc_structure*>(s)))) return rc;
     // k with the two mirror-present bits of the owned cycles, device order.  Inside a segment
@@ -1983,7 +1983,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
             }
     });
     }
-    std::vector<int32_t> xpos;                          // host path: exchange positions of the CSR slots (k_xpos on the device path)
+    hvec<int32_t> xpos;                          // host path: exchange positions of the CSR slots (k_xpos on the device path)
     if (!dev_cycles) {
         xpos.resize((size_t)2 * m);
         host_parallel(n, [&](int64_t a, int64_t b) {
@@ -2002,7 +2002,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     }
     lap("host pack");
     // chunk tables: all chunks, local cycle numbering
-    std::vector<ChunkDesc> chunk_desc((size_t)std::max<int64_t>(nch_all, 1));
+    hvec<ChunkDesc> chunk_desc((size_t)std::max<int64_t>(nch_all, 1));
     for (int64_t t = 0; t < nch_all; ++t)
         chunk_desc[t] = ChunkDesc{cum_loc[P.chunk_seg[t]], cum_loc[P.chunk_seg[t + 1]], P.chunk_seg[t], P.chunk_seg[t + 1]};
 
@@ -2042,7 +2042,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     if ((rc = dalloc(h, &d_pos_edge2, mp))) return rc;
     if (shared_rij) d_rij = const_cast<double*>(shared_rij);          // the device problem's copy: no 72-B-per-edge upload
     else if ((rc = dalloc(h, &d_rij, 9 * (size_t)m))) return rc;
-    std::vector<int32_t> rank_seg32(h->rank_seg.begin(), h->rank_seg.end());
+    hvec<int32_t> rank_seg32(h->rank_seg.begin(), h->rank_seg.end());
     if ((rc = upload(h, h->d_cum, cum_loc.data(), (size_t)mp + 1))) return rc;
     if ((rc = upload(h, h->d_src_start, src_start.data(), (size_t)mp))) return rc;
     if ((rc = upload(h, h->d_chunk_desc, chunk_desc.data(), chunk_desc.size()))) return rc;
@@ -2144,7 +2144,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         if ((rc = dalloc(h, &d_rowsum, n)) || (rc = dalloc(h, &d_rowbase, n)) || (rc = dalloc(h, &h->d_moff, 2 * m))) return rc;
         const unsigned g16 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256));
         hipLaunchKernelGGL(k_midx_rowsum, dim3(g16), dim3(256), 0, h->stream, h->d_rowptr, h->d_adj_seg, d_rowsum, (int)n);
-        std::vector<uint32_t> rs((size_t)n), rb((size_t)n);
+        hvec<uint32_t> rs((size_t)n), rb((size_t)n);
         DESC_HIP(hipMemcpyAsync(rs.data(), d_rowsum, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, h->stream));
         DESC_HIP(hipStreamSynchronize(h->stream));
         uint64_t tot = 0;
@@ -2242,7 +2242,7 @@ static int create_impl(const desc_problem* prob, const double* shared_rij, const
     h->n = prob->n; h->m = s->m; h->m_pos = s->m_pos; h->m_cycle = s->m_cycle; h->max_cnt = s->max_cnt; h->n_sample = s->n_sample;
     if (s->max_deg > 0) h->max_deg = s->max_deg;          // device-built structures carry it
     else {
-        std::vector<int32_t> deg((size_t)h->n, 0);
+        hvec<int32_t> deg((size_t)h->n, 0);
         for (int64_t e = 0; e < h->m; ++e) { deg[prob->ind_i[e]]++; deg[prob->ind_j[e]]++; }
         for (int32_t d : deg) h->max_deg = std::max(h->max_deg, d);
     }
@@ -2267,7 +2267,7 @@ static int create_impl(const desc_problem* prob, const double* shared_rij, const
     A(dalloc(h, &h->d_nv, (size_t)h->max_cnt + 1));
     A(dalloc(h, &h->d_state, 1));
     if (!rc) {
-        std::vector<double> nv((size_t)h->max_cnt + 1, 0.0);
+        hvec<double> nv((size_t)h->max_cnt + 1, 0.0);
         for (int c = 1; c <= h->max_cnt; ++c) nv[c] = 1.0 / std::pow((double)c, 0.5);   // ones/(nsample^0.5), DESC_PGD.m:199
         rc = upload(h, h->d_nv, nv.data(), nv.size());
         if (!rc) { hipError_t e = hipStreamSynchronize(h->stream); if (e != hipSuccess) rc = fail(DESC_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
@@ -2375,7 +2375,7 @@ int desc_pgd_iterate_timed(desc_pgd* h, int32_t n_iters, float* ms_total, float*
     int rc = set_device(h); if (rc) return rc;
     hipEvent_t e0, e1;
     DESC_HIP(hipEventCreate(&e0)); DESC_HIP(hipEventCreate(&e1));
-    std::vector<hipEvent_t> ev;
+    hvec<hipEvent_t> ev;
     if (ms_main_kernel_avg) { ev.resize(2 * (size_t)n_iters); for (auto& e : ev) DESC_HIP(hipEventCreate(&e)); }
     DESC_HIP(hipEventRecord(e0, h->stream));
     if (h->m_pos > 0)
@@ -2525,7 +2525,7 @@ int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r) {
     int chunk = p->check_every > 0 ? p->check_every : 32;
     if (stream_lines && p->check_every <= 0) chunk = 10;
     int reported = 0;
-    std::vector<double> lo, la;
+    hvec<double> lo, la;
     auto emit = [&](int it, double avg, double obj) {
         if (p->progress) p->progress(p->progress_user, it, avg, obj);
         else { printf("iter %d: average change in S_vec %f, objective value: %f\n", it, avg, obj); fflush(stdout); }
@@ -2833,7 +2833,7 @@ int desc_debug_band_plan(const desc_problem* prob, const desc_structure* s, int3
     if (s->m_pos == 0) return fail(DESC_ERR_INVALID, "no edge with cycles");
     int32_t max_deg = 0;
     {
-        std::vector<int32_t> deg((size_t)prob->n, 0);
+        hvec<int32_t> deg((size_t)prob->n, 0);
         for (int64_t e = 0; e < prob->m; ++e) { deg[prob->ind_i[e]]++; deg[prob->ind_j[e]]++; }
         for (int32_t d : deg) max_deg = std::max(max_deg, d);
     }
@@ -2843,10 +2843,10 @@ int desc_debug_band_plan(const desc_problem* prob, const desc_structure* s, int3
     if (rc) return rc;
     const int64_t seg_lo = P.chunk_seg[P.rank_chunk[rank]], seg_hi = P.chunk_seg[P.rank_chunk[rank + 1]];
     const int64_t cyc_lo = P.cum2[seg_lo], mcl = P.cum2[seg_hi] - cyc_lo;
-    std::vector<PieceDesc> pieces; std::vector<int32_t> piece_ptr; int band_rows = 0; bool jmajor = false;
+    hvec<PieceDesc> pieces; hvec<int32_t> piece_ptr; int band_rows = 0; bool jmajor = false;
     plan_band_pieces(prob, s, P, seg_lo, seg_hi, cyc_lo, mcl, grid, pieces, piece_ptr, band_rows, jmajor);
     const int64_t nbands = (int64_t)P.band_lo.size() - 1;
-    std::vector<uint8_t> seen((size_t)(seg_hi - seg_lo), 0);
+    hvec<uint8_t> seen((size_t)(seg_hi - seg_lo), 0);
     int64_t wmax = 0, wmin = INT64_MAX;
     for (int b = 0; b < grid; ++b) {
         int64_t cyc = 0;

@@ -33,7 +33,7 @@ int desc_problem_upload(const desc_problem* prob, int32_t device, desc_device_pr
         return bail(fail(DESC_ERR_HIP, "out of device memory for the problem (m = %lld)", (long long)m));
     // the big copy (72 B per edge; synchronous copies from pageable memory run at ~12 GB/s, asynchronous ones at ~3 GB/s
     // on this runtime) overlaps the host-side CSR pass, which runs on a helper thread
-    std::vector<int32_t> adj, adj_eid;
+    hvec<int32_t> adj, adj_eid;
     std::thread csr([&]() {
         dp->ii.assign(prob->ind_i, prob->ind_i + m); dp->jj.assign(prob->ind_j, prob->ind_j + m);
         build_csr(n, m, prob->ind_i, prob->ind_j, dp->rowptr, adj, adj_eid);

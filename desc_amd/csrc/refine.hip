@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_qcollect(const double* x, int64_t m, do
 }
 
 // MATLAB quantile(x, p): Hazen plotting positions (k-0.5)/n, linear interpolation, clamped
-double matlab_quantile(std::vector<double>& x, double p) {
+double matlab_quantile(hvec<double>& x, double p) {
     const size_t n = x.size();
     if (n == 0) return NAN;
     double pos = p * (double)n + 0.5;                    // 1-based fractional index
@@ -294,7 +294,7 @@ int device_quantile(const double* d_x, int64_t m, double p, double* d_mm, unsign
     const double scale = (double)QBINS / (hi - lo) * (1.0 - 1e-12);
     DESC_HIP(hipMemset(d_hist, 0, sizeof(unsigned) * (QBINS + 1)));
     hipLaunchKernelGGL(k_qhist, dim3(g), dim3(256), 0, 0, d_x, m, lo, scale, d_hist);
-    std::vector<unsigned> hist(QBINS);
+    hvec<unsigned> hist(QBINS);
     DESC_HIP(hipMemcpy(hist.data(), d_hist, sizeof(unsigned) * QBINS, hipMemcpyDeviceToHost));
     int64_t acc = 0; int b0 = -1, b1 = -1; int64_t base0 = 0;
     for (int b = 0; b < QBINS; ++b) {
@@ -305,13 +305,13 @@ int device_quantile(const double* d_x, int64_t m, double p, double* d_mm, unsign
     if (b0 < 0 || b1 < 0) return fail(DESC_ERR_STATE, "quantile histogram inconsistent");
     const uint64_t need = (uint64_t)hist[b0] + (b1 != b0 ? hist[b1] : 0);
     if (need > cap) {                                       // a bin too full to collect (heavily tied data): exact host path
-        std::vector<double> all((size_t)m);
+        hvec<double> all((size_t)m);
         DESC_HIP(hipMemcpy(all.data(), d_x, sizeof(double) * m, hipMemcpyDeviceToHost));
         *result = matlab_quantile(all, p);
         return DESC_OK;
     }
     hipLaunchKernelGGL(k_qcollect, dim3(g), dim3(256), 0, 0, d_x, m, lo, scale, b0, b1, d_cand, d_hist + QBINS, cap);
-    std::vector<double> cand((size_t)need);
+    hvec<double> cand((size_t)need);
     DESC_HIP(hipMemcpy(cand.data(), d_cand, sizeof(double) * need, hipMemcpyDeviceToHost));
     std::sort(cand.begin(), cand.end());
     // cand = bin b0 (ranks base0 ...) followed, if different, by bin b1 (which starts at rank >= k0 + 1)
@@ -322,7 +322,7 @@ int device_quantile(const double* d_x, int64_t m, double p, double* d_mm, unsign
 }
 
 struct DevR {
-    std::vector<void*> p;
+    hvec<void*> p;
     ~DevR() { for (void* q : p) dev_free(q); }
     template <class T> int alloc(T** out, size_t count) {
         void* q = nullptr;
@@ -405,7 +405,7 @@ extern "C" int desc_refine_run_dev(const desc_device_problem* dp, const double* 
     const double quant_ratio_min = 0.8;
     int Iteration = 1, cg_total = 0, cg_unconverged = 0;
     double cg_worst = 0.0;
-    std::vector<double> part(sgrid);
+    hvec<double> part(sgrid);
     constexpr unsigned QCAP = 1u << 20;
     double *d_mm, *d_cand; unsigned* d_qh;
     if ((rc = D.alloc(&d_mm, 128)) || (rc = D.alloc(&d_cand, QCAP)) || (rc = D.alloc(&d_qh, QBINS + 1))) return rc;

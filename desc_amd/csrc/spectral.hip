@@ -251,7 +251,7 @@ void project_so3(const double* M, double* R) {
 }
 
 struct Dev {
-    std::vector<void*> p;
+    hvec<void*> p;
     ~Dev() { for (void* q : p) dev_free(q); }
     template <class T> int alloc(T** out, size_t count) {
         void* q = nullptr;
@@ -307,7 +307,7 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
 
     // block CSR: every edge in both endpoint rows; the index part lives with the device problem, the 2m blocks are
     // assembled on the device ((i,j) slot = R, (j,i) slot = R')
-    std::vector<double> deg((size_t)n, 0.0);
+    hvec<double> deg((size_t)n, 0.0);
     Dev W;                                                  // edge weights on the device (NULL: all ones)
     double* d_w = nullptr;
     if (gcw_svec) {                                         // weights and weighted degrees entirely on the device
@@ -332,7 +332,7 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
         }
     }
     double sigma = 0.0;
-    std::vector<double> dinv((size_t)n, 1.0);               // D^-1/2
+    hvec<double> dinv((size_t)n, 1.0);               // D^-1/2
     if (normalize_rows) {
         for (int64_t v = 0; v < n; ++v) dinv[v] = deg[v] > 0 ? 1.0 / std::sqrt(deg[v]) : 0.0;
         sigma = 1.0;                                        // spectrum of D^-1/2 A D^-1/2 lies in [-1,1]
@@ -341,7 +341,7 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
     }
     const int64_t rows = 3 * n;
     // deterministic start: hashed pseudo-random entries in [-1,1)
-    std::vector<double> X0((size_t)rows * BW);
+    hvec<double> X0((size_t)rows * BW);
     for (size_t t = 0; t < X0.size(); ++t) X0[t] = (double)(int64_t)(mix64(0xC0FFEEull + t) >> 11) / 4503599627370496.0 - 1.0;
 
     Dev D;
@@ -361,7 +361,7 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
     }
     DESC_HIP(hipMemcpy(d_Y, X0.data(), sizeof(double) * rows * BW, hipMemcpyHostToDevice));
 
-    std::vector<double> part((size_t)ggrid * 2 * BW * BW);
+    hvec<double> part((size_t)ggrid * 2 * BW * BW);
     double G1[BW * BW], G2[BW * BW];
     auto grams = [&](const double* A, const double* B) -> int {
         hipLaunchKernelGGL(k_gram, dim3(ggrid), dim3(256), 0, 0, A, B, rows, d_part);
@@ -466,11 +466,11 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
     SmallMat CZ; std::memcpy(CZ.c, Z, sizeof Z);
     hipLaunchKernelGGL(k_combine, dim3(512), dim3(256), 0, 0, d_X, d_Y, rows, CZ);
     DESC_HIP(hipGetLastError());
-    std::vector<double> Vh((size_t)rows * BW);
+    hvec<double> Vh((size_t)rows * BW);
     DESC_HIP(hipMemcpy(Vh.data(), d_Y, sizeof(double) * rows * BW, hipMemcpyDeviceToHost));
 
     // back to the eigenvectors of D^-1 A, unit 2-norm columns (what eigs returns)   (GCW.m:21,27)
-    std::vector<double> V((size_t)rows * 3);
+    hvec<double> V((size_t)rows * 3);
     double nrm[3] = {0, 0, 0};
     for (int64_t v = 0; v < n; ++v) for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
         const double x = Vh[((size_t)3 * v + r) * BW + c] * (normalize_rows ? dinv[v] : 1.0);

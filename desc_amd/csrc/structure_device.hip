@@ -263,7 +263,7 @@ __global__ void k_iota(int32_t* p, int64_t n) {
 }
 
 struct DevBuf {
-    std::vector<void*> p;
+    hvec<void*> p;
     ~DevBuf() { for (void* q : p) dev_free(q); }
     template <class T> int alloc(T** out, size_t count) {
         void* q = nullptr;
@@ -298,7 +298,7 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
     s->n = n; s->m = m; s->dev = device; s->seed = seed;
 
     // CSR on the host (one pass; Ind is sorted by (i,j), so rows come out ascending)
-    std::vector<int32_t> rowptr, adj, adj_eid;
+    hvec<int32_t> rowptr, adj, adj_eid;
     build_csr(n, m, prob->ind_i, prob->ind_j, rowptr, adj, adj_eid);
     s->max_deg = 0;
     for (int64_t v = 0; v < n; ++v) s->max_deg = std::max(s->max_deg, rowptr[v + 1] - rowptr[v]);
@@ -341,7 +341,7 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
                            (int)std::min<int64_t>(n + 1, (int64_t)s->max_deg + 1));
     DESC_HIP(hipGetLastError());
     s->codeg.assign((size_t)m, 0);
-    std::vector<int32_t> hist((size_t)n + 1, 0);
+    hvec<int32_t> hist((size_t)n + 1, 0);
     if (m) DESC_HIP(hipMemcpy(s->codeg.data(), d_codeg, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
     DESC_HIP(hipMemcpy(hist.data(), d_hist, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost));
     lap("bitmaps+codeg+d2h");
@@ -366,14 +366,14 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
     s->pos_edge.resize((size_t)mp);
     s->cum_ind.assign((size_t)mp + 1, 0);
     s->max_cnt = std::min(max_codeg, n_sample);
-    std::vector<int32_t> cum32((size_t)mp + 1, 0), pos_of_edge((size_t)std::max<int64_t>(m, 1), -1);
+    hvec<int32_t> cum32((size_t)mp + 1, 0), pos_of_edge((size_t)std::max<int64_t>(m, 1), -1);
     {   // compaction of the edges with cycles + prefix sum of their cycle counts, in chunks (threads for large m)
         unsigned hw = std::thread::hardware_concurrency();
         const int T = m >= (1 << 20) ? (int)std::max(1u, std::min(hw, 16u)) : 1;
-        std::vector<int64_t> c_pos((size_t)T + 1, 0), c_cyc((size_t)T + 1, 0);
+        hvec<int64_t> c_pos((size_t)T + 1, 0), c_cyc((size_t)T + 1, 0);
         auto run = [&](auto&& body) {
             if (T == 1) { body(0, (int64_t)0, m); return; }
-            std::vector<std::thread> th;
+            hvec<std::thread> th;
             for (int t = 0; t < T; ++t) th.emplace_back([=, &body]() { body(t, m * t / T, m * (t + 1) / T); });
             for (auto& x : th) x.join();
         };
@@ -453,13 +453,13 @@ int build_cemp_samples_device(const desc_device_problem* dp, int32_t nsample, ui
     DESC_HIP(hipGetLastError());
     // edges with cycles: the codegree histogram says how many have none.  Usually (dense measurement graphs) every edge lies
     // on a triangle and pos_edge is the identity: filled on the device, no O(m) round trip through the host.
-    std::vector<int32_t> hist((size_t)n + 1), pos_edge;
+    hvec<int32_t> hist((size_t)n + 1), pos_edge;
     DESC_HIP(hipMemcpy(hist.data(), d_hist, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost));
     int32_t max_codeg = 0;
     for (int64_t c = 1; c <= n; ++c) if (hist[c]) max_codeg = (int32_t)c;
     const bool all_pos = m > 0 && hist[0] == 0;
     if (!all_pos) {
-        std::vector<int32_t> codeg((size_t)m);
+        hvec<int32_t> codeg((size_t)m);
         if (m) DESC_HIP(hipMemcpy(codeg.data(), d_codeg, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
         for (int64_t e = 0; e < m; ++e) if (codeg[e] > 0) pos_edge.push_back((int32_t)e);
     }

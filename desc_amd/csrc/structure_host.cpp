@@ -26,12 +26,12 @@ struct Graph {
     int64_t n, m;
     const int32_t* ii;
     const int32_t* jj;
-    std::vector<int64_t> rowptr;     // n+1
-    std::vector<int32_t> col, eid;   // 2m, neighbours ascending per row
+    hvec<int64_t> rowptr;     // n+1
+    hvec<int32_t> col, eid;   // 2m, neighbours ascending per row
     bool use_bits = false;
     int64_t words = 0;
-    std::vector<uint64_t> bits;      // n*words
-    std::vector<uint32_t> rank;      // n*words: neighbours of the row before this word
+    hvec<uint64_t> bits;      // n*words
+    hvec<uint32_t> rank;      // n*words: neighbours of the row before this word
 };
 
 template <class F>
@@ -39,7 +39,7 @@ void parallel_for(int64_t count, F&& body) {
     unsigned hw = std::thread::hardware_concurrency();
     int nt = (int)std::min<int64_t>(std::max(1u, std::min(hw, 32u)), std::max<int64_t>(1, count / 2048));
     if (nt <= 1) { body(0, count, 0); return; }
-    std::vector<std::thread> th;
+    hvec<std::thread> th;
     // interleaved blocks: low-numbered edges have larger neighbour lists on average
     int64_t chunk = 1024;
     for (int t = 0; t < nt; ++t)
@@ -56,7 +56,7 @@ void build_graph(Graph& g) {
     for (int64_t e = 0; e < m; ++e) { g.rowptr[g.ii[e] + 1]++; g.rowptr[g.jj[e] + 1]++; }
     for (int64_t v = 0; v < n; ++v) g.rowptr[v + 1] += g.rowptr[v];
     g.col.resize(2 * m); g.eid.resize(2 * m);
-    std::vector<int64_t> fill(g.rowptr.begin(), g.rowptr.end() - 1);
+    hvec<int64_t> fill(g.rowptr.begin(), g.rowptr.end() - 1);
     // Edges are sorted by (i,j): a row receives its smaller neighbours (from edges
     // (x,v), x<v) before its larger ones (edges (v,x)), each run ascending.
     for (int64_t e = 0; e < m; ++e) {
@@ -101,7 +101,7 @@ inline int32_t codeg_of(const Graph& g, int32_t i, int32_t j) {
 struct Tri { int32_t k, ejk, eki; };
 
 // ascending common neighbours of (i,j) with the ids of edges {j,k} and {k,i}
-inline void common_of(const Graph& g, int32_t i, int32_t j, std::vector<Tri>& out) {
+inline void common_of(const Graph& g, int32_t i, int32_t j, hvec<Tri>& out) {
     out.clear();
     if (g.use_bits) {
         const uint64_t* a = &g.bits[(size_t)i * g.words];
@@ -133,18 +133,18 @@ inline void common_of(const Graph& g, int32_t i, int32_t j, std::vector<Tri>& ou
 
 // CEMP's cycle sample (Algorithms/CEMP.m:44-65): nsample third vertices per edge-with-cycles,
 // drawn WITH replacement; datasample's RNG is replaced by  CoInd[sample_key(seed, edge, t) mod codeg].
-int build_cemp_samples_host(const desc_problem* prob, int32_t nsample, uint64_t seed, std::vector<int32_t>& pos_edge,
-                            std::vector<int32_t>& kk, std::vector<int32_t>& e_jk, std::vector<int32_t>& e_ki) {
+int build_cemp_samples_host(const desc_problem* prob, int32_t nsample, uint64_t seed, hvec<int32_t>& pos_edge,
+                            hvec<int32_t>& kk, hvec<int32_t>& e_jk, hvec<int32_t>& e_ki) {
     Graph g; g.n = prob->n; g.m = prob->m; g.ii = prob->ind_i; g.jj = prob->ind_j;
     build_graph(g);
-    std::vector<int32_t> cd((size_t)g.m);
+    hvec<int32_t> cd((size_t)g.m);
     parallel_for(g.m, [&](int64_t a, int64_t b, int) { for (int64_t e = a; e < b; ++e) cd[e] = codeg_of(g, g.ii[e], g.jj[e]); });
     pos_edge.clear();
     for (int64_t e = 0; e < g.m; ++e) if (cd[e] > 0) pos_edge.push_back((int32_t)e);
     const int64_t mp = (int64_t)pos_edge.size();
     kk.assign((size_t)mp * nsample, 0); e_jk.assign((size_t)mp * nsample, 0); e_ki.assign((size_t)mp * nsample, 0);
     parallel_for(mp, [&](int64_t a, int64_t b, int) {
-        std::vector<Tri> tri;
+        hvec<Tri> tri;
         for (int64_t l = a; l < b; ++l) {
             const int32_t e = pos_edge[l];
             common_of(g, g.ii[e], g.jj[e], tri);
@@ -157,8 +157,8 @@ int build_cemp_samples_host(const desc_problem* prob, int32_t nsample, uint64_t 
     return DESC_OK;
 }
 
-void build_csr(int64_t n, int64_t m, const int32_t* ii, const int32_t* jj, std::vector<int32_t>& rowptr, std::vector<int32_t>& adj,
-               std::vector<int32_t>& adj_eid) {
+void build_csr(int64_t n, int64_t m, const int32_t* ii, const int32_t* jj, hvec<int32_t>& rowptr, hvec<int32_t>& adj,
+               hvec<int32_t>& adj_eid) {
     rowptr.assign((size_t)n + 1, 0); adj.resize((size_t)2 * m); adj_eid.resize((size_t)2 * m);
     unsigned hw = std::thread::hardware_concurrency();
     int T = (int)std::min<int64_t>(std::max(1u, std::min(hw, 16u)), std::max<int64_t>(1, (int64_t)(16 << 20) / std::max<int64_t>(n, 1)));
@@ -168,7 +168,7 @@ void build_csr(int64_t n, int64_t m, const int32_t* ii, const int32_t* jj, std::
         // before its larger ones (edges (v,x)), each run ascending.
         for (int64_t e = 0; e < m; ++e) { rowptr[ii[e] + 1]++; rowptr[jj[e] + 1]++; }
         for (int64_t v = 0; v < n; ++v) rowptr[v + 1] += rowptr[v];
-        std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
+        hvec<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
         for (int64_t e = 0; e < m; ++e) {
             const int32_t i = ii[e], j = jj[e];
             adj[fill[i]] = j; adj_eid[fill[i]++] = (int32_t)e;
@@ -179,9 +179,9 @@ void build_csr(int64_t n, int64_t m, const int32_t* ii, const int32_t* jj, std::
     // T contiguous chunks of edges; per chunk the number of edges ending (lo) / starting (up) at every node,
     // turned into per-chunk start offsets inside the lower / upper part of each row: the same slots as the
     // serial pass, whatever T is
-    std::vector<int32_t> lo((size_t)T * n, 0), up((size_t)T * n, 0), lowtot((size_t)n);
+    hvec<int32_t> lo((size_t)T * n, 0), up((size_t)T * n, 0), lowtot((size_t)n);
     auto run = [&](auto&& body) {
-        std::vector<std::thread> th;
+        hvec<std::thread> th;
         for (int t = 0; t < T; ++t) th.emplace_back([=, &body]() { body(t, m * t / T, m * (t + 1) / T); });
         for (auto& x : th) x.join();
     };
@@ -244,7 +244,7 @@ int build_structure_host(const desc_problem* prob, int32_t n_sample_min, uint64_
 
     // edges with cycles, median of their codegree (DESC_PGD.m:36-43)
     s->pos_edge.clear();
-    std::vector<int32_t> pos_cd;
+    hvec<int32_t> pos_cd;
     for (int64_t e = 0; e < m; ++e) if (s->codeg[e] > 0) { s->pos_edge.push_back((int32_t)e); pos_cd.push_back(s->codeg[e]); }
     s->m_pos = (int64_t)s->pos_edge.size();
     int32_t n_sample = n_sample_min;            // median([]) = NaN, max(NaN,30) = 30
@@ -273,8 +273,8 @@ int build_structure_host(const desc_problem* prob, int32_t n_sample_min, uint64_
 
     // cycle lists (DESC_PGD.m:79-96)
     parallel_for(s->m_pos, [&](int64_t a, int64_t b, int) {
-        std::vector<Tri> tri;
-        std::vector<std::pair<uint64_t, int32_t>> keyed;
+        hvec<Tri> tri;
+        hvec<std::pair<uint64_t, int32_t>> keyed;
         for (int64_t l = a; l < b; ++l) {
             int32_t e = s->pos_edge[l];
             common_of(g, g.ii[e], g.jj[e], tri);
@@ -299,7 +299,7 @@ int build_structure_host(const desc_problem* prob, int32_t n_sample_min, uint64_
 
     // mirror maps (DESC_PGD.m:103-127): binary search of j in the sampled list of
     // edge {i,k}, and of i in the sampled list of edge {j,k}
-    std::vector<int32_t> pos_of_edge(m, -1);                             // CoDeg_pos_ind_long (:53-54)
+    hvec<int32_t> pos_of_edge(m, -1);                             // CoDeg_pos_ind_long (:53-54)
     for (int64_t l = 0; l < s->m_pos; ++l) pos_of_edge[s->pos_edge[l]] = (int32_t)l;
     parallel_for(s->m_pos, [&](int64_t a, int64_t b, int) {
         for (int64_t l = a; l < b; ++l) {

@@ -329,7 +329,9 @@ int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* 
 
 /* The library parks the device blocks of destroyed handles / structures / problems for reuse by the next call (up to
  * DESC_CACHE_MB megabytes per process, default 8192: hipFree + hipMalloc of the gigabyte-sized per-cycle arrays cost 10-20 ms
- * per solve).  desc_trim_memory returns everything parked to the driver; result: bytes released. */
+ * per solve), and likewise the large host-side index vectors of its setup (up to DESC_HOST_CACHE_MB, default 1024: first-touch
+ * page faults and munmap of ~200 MB cost 40 ms per solve at n = 5000).  desc_trim_memory returns everything parked to the
+ * driver / the C++ runtime; result: device bytes released. */
 int64_t desc_trim_memory(void);
 
 /* Binding utilities: synchronous copies between host memory and device memory of the library's own HIP runtime
