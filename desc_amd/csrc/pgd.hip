@@ -1143,6 +1143,18 @@ __global__ __launch_bounds__(256) void k_layout_node_dev(const int32_t* cum, con
         }
     }
 }
+// Device-order segment tables from the plan's permutation (device-built structures): segment q of the device order is the
+// structure's edge-with-cycles number order[q]
+__global__ __launch_bounds__(256) void k_seg_tables(const int32_t* order, const int32_t* nat_pos_edge, const int32_t* nat_cum, int32_t* cum,
+                                                    int32_t cyc_lo, int32_t* src_start, int32_t* pos_edge2, int32_t* devpos, int64_t m_pos) {
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q <= m_pos; q += (int64_t)gridDim.x * 256) {
+        cum[q] -= cyc_lo;                                  // local cycle numbering (meaningful for owned segments)
+        if (q == m_pos) break;
+        const int32_t l = order[q], e = nat_pos_edge[l];
+        src_start[q] = nat_cum[l];
+        pos_edge2[q] = e; devpos[e] = (int32_t)q;
+    }
+}
 // per-edge slots of the CSR-aligned arrays, on the device (device-built structures): eslot[e] = this
 // edge's slot in its smaller endpoint's row; einfo of the edges with cycles in device order
 __global__ __launch_bounds__(256) void k_edge_slots(const int32_t* ind_i, const int32_t* ind_j, const int32_t* rowptr, const int32_t* adj,
@@ -1926,8 +1938,12 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         }
     }
     lap("csr+eslot");
-    hvec<int32_t> cum_loc((size_t)mp + 1), src_start((size_t)mp), pos_edge2((size_t)mp), devpos((size_t)m, -1);
+    // device-order tables of the segments: local cycle starts, start in the structure's natural cycle order, edge id; position of
+    // every edge.  Device-built structures: k_seg_tables makes them from the plan's permutation (no host pass, two uploads instead of four)
+    hvec<int32_t> cum_loc, src_start, pos_edge2, devpos;
     hvec<EdgeInfo> einfo;
+    if (!dev_cycles) {
+    cum_loc.resize((size_t)mp + 1); src_start.resize((size_t)mp); pos_edge2.resize((size_t)mp); devpos.assign((size_t)m, -1);
     cum_loc[mp] = cum2[mp] - (int32_t)h->cyc_lo;
     host_parallel(mp, [&](int64_t a, int64_t b) {
         for (int64_t q = a; q < b; ++q) {
@@ -1937,6 +1953,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
             pos_edge2[q] = e; devpos[e] = (int32_t)q;
         }
     });
+    }
     if (!dev_cycles) {
         einfo.resize((size_t)mp);
         host_parallel(mp, [&](int64_t a, int64_t b) {
@@ -2004,7 +2021,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     // chunk tables: all chunks, local cycle numbering
     hvec<ChunkDesc> chunk_desc((size_t)std::max<int64_t>(nch_all, 1));
     for (int64_t t = 0; t < nch_all; ++t)
-        chunk_desc[t] = ChunkDesc{cum_loc[P.chunk_seg[t]], cum_loc[P.chunk_seg[t + 1]], P.chunk_seg[t], P.chunk_seg[t + 1]};
+        chunk_desc[t] = ChunkDesc{cum2[P.chunk_seg[t]] - (int32_t)h->cyc_lo, cum2[P.chunk_seg[t + 1]] - (int32_t)h->cyc_lo, P.chunk_seg[t], P.chunk_seg[t + 1]};
 
     if ((rc = dalloc(h, &h->d_S0, mcl + 8))) return rc;   // +8: 16-byte tail reads
     if ((rc = dalloc(h, &h->d_w[0], mcl + 8))) return rc;
@@ -2043,11 +2060,23 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     if (shared_rij) d_rij = const_cast<double*>(shared_rij);          // the device problem's copy: no 72-B-per-edge upload
     else if ((rc = dalloc(h, &d_rij, 9 * (size_t)m))) return rc;
     hvec<int32_t> rank_seg32(h->rank_seg.begin(), h->rank_seg.end());
+    int32_t* d_devpos = nullptr;
+    if (dev_cycles) {
+        int32_t* d_order = nullptr;
+        if ((rc = dalloc(h, &d_devpos, m)) || (rc = dalloc(h, &d_order, mp))) return rc;
+        if ((rc = upload(h, h->d_cum, cum2.data(), (size_t)mp + 1)) || (rc = upload(h, d_order, P.order.data(), (size_t)mp))) return rc;
+        DESC_HIP(hipMemsetAsync(d_devpos, 0xFF, sizeof(int32_t) * std::max<int64_t>(1, m), h->stream));
+        hipLaunchKernelGGL(k_seg_tables, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (mp + 256) / 256))), dim3(256), 0, h->stream,
+                           d_order, s->d_pos, s->d_cum, h->d_cum, (int32_t)h->cyc_lo, h->d_src_start, d_pos_edge2, d_devpos, mp);
+        DESC_HIP(hipStreamSynchronize(h->stream));       // d_order, the host sources of the copies
+        dfree(h, d_order);
+    } else {
     if ((rc = upload(h, h->d_cum, cum_loc.data(), (size_t)mp + 1))) return rc;
     if ((rc = upload(h, h->d_src_start, src_start.data(), (size_t)mp))) return rc;
+    if ((rc = upload(h, d_pos_edge2, pos_edge2.data(), (size_t)mp))) return rc;
+    }
     if ((rc = upload(h, h->d_chunk_desc, chunk_desc.data(), chunk_desc.size()))) return rc;
     if ((rc = upload(h, h->d_rank_seg, rank_seg32.data(), rank_seg32.size()))) return rc;
-    if ((rc = upload(h, d_pos_edge2, pos_edge2.data(), (size_t)mp))) return rc;
     // (a synchronous copy from pageable memory runs 2-3x faster than an asynchronous one on this runtime)
     if (!shared_rij && m) DESC_HIP(hipMemcpy(d_rij, prob->rij, sizeof(double) * 9 * (size_t)m, hipMemcpyHostToDevice));
     if (h->band_ok) {
@@ -2115,10 +2144,8 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
                            d_kf, h->d_rowptr, d_adj, d_adj_eid, d_rij, h->d_pk, h->d_S0, (int)nsl);
     } else if (dev_cycles) {
         // the structure's per-cycle arrays never left the device: lay them out in place
-        int32_t* d_devpos = nullptr; uint32_t* d_counts = nullptr;
-        if ((rc = dalloc(h, &d_devpos, m))) return rc;
+        uint32_t* d_counts = nullptr;
         if ((rc = dalloc(h, &d_counts, mp))) return rc;
-        if ((rc = upload(h, d_devpos, devpos.data(), (size_t)m))) return rc;
         DESC_HIP(hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * std::max<int64_t>(1, mp), h->stream));
         if (nsl > 0) {
             int g = (int)std::min<int64_t>(4096, (nsl + 3) / 4);
