@@ -198,9 +198,13 @@ def measure(lib, name, K, W, seed, convergence, keep_arrays, n_sample_min=30):
     e2e = lib.solve(prob, pe)
     t_e2e = time.perf_counter() - t0
     # ... and the same call again: device and host blocks parked by the first one are reused (every later call of a session)
-    t0 = time.perf_counter()
-    e2e_again = lib.solve(prob, pe)
-    t_e2e_again = time.perf_counter() - t0
+    t_e2e_again = None
+    for _ in range(2):                  # best of two: single calls scatter by +-10 % on a shared host
+        t0 = time.perf_counter()
+        x = lib.solve(prob, pe)
+        dt_x = time.perf_counter() - t0
+        if t_e2e_again is None or dt_x < t_e2e_again:
+            t_e2e_again, e2e_again = dt_x, x
 
     bytes_per_launch = 72.0 * m_cycle + 12.0 * m_pos
     achieved = bytes_per_launch / (ms_kernel * 1e-3) / 1e9 if ms_kernel else 0.0
@@ -216,7 +220,7 @@ def measure(lib, name, K, W, seed, convergence, keep_arrays, n_sample_min=30):
         end_to_end={"ms": t_e2e * 1e3, "what": "one timed desc_pgd_solve call: host arrays in -> S_vec out, 100 iterations, warm HIP context, every block allocated afresh",
                     "ms_structure": e2e["ms_structure"], "ms_upload": e2e["ms_upload"], "ms_layout_cycle_d": e2e["ms_cycle_d"],
                     "ms_pgd": e2e["ms_pgd"], "ms_total_in_library": e2e["ms_total"],
-                    "repeat_ms": t_e2e_again * 1e3, "repeat_what": "the same call again: the blocks the first call released are reused (devmem.hip / hostmem.h)",
+                    "repeat_ms": t_e2e_again * 1e3, "repeat_what": "the same call again (best of two): the blocks the first call released are reused (devmem.hip / hostmem.h)",
                     "repeat_ms_structure": e2e_again["ms_structure"], "repeat_ms_pgd": e2e_again["ms_pgd"]},
         conv=None if conv is None else
         {"iters_run": int(conv["iters_run"]), "ms_iterations": conv["t"] * 1e3,
