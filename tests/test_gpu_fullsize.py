@@ -176,3 +176,34 @@ def test_full_size_unsampled_c5(lib):
         wn = np.maximum(v - css[rho] / (rho + 1), 0)
         assert np.abs(wn - w[lo:hi]).max() < 1e-13
         assert abs(wn @ d[lo:hi] - S[a["pos_edge"][l]]) < 1e-13
+
+
+@pytest.mark.parametrize("name,iters", [("C2", 8), ("C4", 5)])
+def test_full_size_adam_band_equals_node(lib, name, iters):
+    """HybridGradient strategy 0 (Adam) at full size: the 512-thread band instances against k_sweep_node -- the same
+    arithmetic in the same order, so weights, S_vec and both moments agree bitwise (the objective to round-off); weights stay on the simplex."""
+    mo, nn, ii, jj, rij = bench.generate(name)
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    st = lib.Structure.build(prob, 30, 0, lib.BUILD_DEVICE, 0)
+    p = c_params(iters, step_kind=2, lr=0.01, seed=0)
+    outs = {}
+    for variant in ("band", "node"):
+        os.environ["DESC_DEBUG_VARIANT"] = {"band": "3", "node": "2"}[variant]
+        try:
+            solver = lib.Solver(prob, st, 0)
+            mc = solver.m_cycle
+            outs[variant] = solver.run(p, want_w=True, adam=(np.zeros(mc), np.zeros(mc)))
+            outs[variant]["kernel"] = solver.kernel_name()
+            solver.destroy()
+        finally:
+            os.environ.pop("DESC_DEBUG_VARIANT", None)
+    cum = st.arrays()["cum_ind"]
+    st.free()
+    b, n = outs["band"], outs["node"]
+    assert "band" in b["kernel"] and "node" in n["kernel"]
+    for key in ("S_vec", "w", "adam_m", "adam_v"):
+        assert np.array_equal(b[key], n[key]), key
+    assert np.allclose(b["obj"], n["obj"], rtol=1e-12, atol=0)      # workgroup partials of different grids: another summation order
+    sums = np.add.reduceat(b["w"], cum[:-1])
+    assert np.abs(sums - 1.0).max() < 1e-12 and b["w"].min() >= 0.0
+    assert np.all(np.diff(b["obj"]) < 0)
