@@ -1537,37 +1537,57 @@ void launch_node(desc_pgd* h, const NodeSweepArgs& a) {
     }
 }
 
+// Band sweep instances by the longest segment: lanes per segment x cycles per lane, threads per workgroup.
+//   <= 16 cycles: 16 x 1, 1024     <= 32: 16 x 2, 1024     <= 64: 16 x 4, 512     <= 128: 32 x 4, 512     <= 256: 64 x 4, 512
+// (33..64 cycles: 8 waves with 4 cycles per lane beat 16 waves of 32 x 2 by 5 % at C2 and C4 -- the DPP reductions are shared by four
+//  segments per wave instead of two; 8 lanes x 4 cycles for <= 32 was slower: eight segment records per wave spill the SGPRs.)
+// The Adam plugin: 512-thread instances (the moments ride in the stream sets) up to 64 cycles: 16 x 1, 16 x 2, 32 x 2.
+struct BandShape { int lps, E; };
+BandShape band_shape(const desc_pgd* h, bool adam) {
+    const int c = h->max_cnt;
+    if (adam) return c <= 16 ? BandShape{16, 1} : c <= 32 ? BandShape{16, 2} : BandShape{32, 2};
+    return c <= 16 ? BandShape{16, 1} : c <= 32 ? BandShape{16, 2} : c <= 64 ? BandShape{16, 4} : c <= 128 ? BandShape{32, 4} : BandShape{64, 4};
+}
+bool band_adam_ok(const desc_pgd* h) { return h->band_ok && h->max_cnt <= 64; }
 template <int STEP>
 const void* band_kernel(const desc_pgd* h) {
-    constexpr int NT = STEP == DESC_STEP_HYBRID ? 512 : 1024;      // Adam: 8 waves, twice the registers (two more streams each way)
-    switch (h->lps * 8 + h->G) {
-        case 16 * 8 + 1: return (const void*)k_sweep_band<16, 1, STEP, NT>;
-        case 16 * 8 + 2: return (const void*)k_sweep_band<16, 2, STEP, NT>;
-        case 32 * 8 + 2: return (const void*)k_sweep_band<32, 2, STEP, NT>;
-        default: break;
+    const BandShape sh = band_shape(h, STEP == DESC_STEP_HYBRID);
+    if constexpr (STEP == DESC_STEP_HYBRID) {
+        if (h->max_cnt > 64) return nullptr;           // 4 cycles per lane + the moments do not fit the registers: k_sweep_node (band_adam_ok)
+        switch (sh.lps * 8 + sh.E) {
+            case 16 * 8 + 1: return (const void*)k_sweep_band<16, 1, STEP, 512>;
+            case 16 * 8 + 2: return (const void*)k_sweep_band<16, 2, STEP, 512>;
+            default: return (const void*)k_sweep_band<32, 2, STEP, 512>;
+        }
+    } else {
+        switch (sh.lps * 8 + sh.E) {
+            case 16 * 8 + 1: return (const void*)k_sweep_band<16, 1, STEP, 1024>;
+            case 16 * 8 + 2: return (const void*)k_sweep_band<16, 2, STEP, 1024>;
+            case 16 * 8 + 4: return (const void*)k_sweep_band<16, 4, STEP, 512>;
+            case 32 * 8 + 4: return (const void*)k_sweep_band<32, 4, STEP, 512>;
+            default: return (const void*)k_sweep_band<64, 4, STEP, 512>;
+        }
     }
-    if constexpr (STEP != DESC_STEP_HYBRID) {      // 4 cycles per lane + the Adam moments do not fit the registers: band_adam_ok()
-        if (h->lps == 32) return (const void*)k_sweep_band<32, 4, STEP, 512>;
-        return (const void*)k_sweep_band<64, 4, STEP, 512>;
-    }
-    return nullptr;
 }
-bool band_adam_ok(const desc_pgd* h) { return h->band_ok && h->G <= 2; }
 template <int STEP>
 void launch_band(desc_pgd* h, const NodeSweepArgs& a) {
-    constexpr int NT = STEP == DESC_STEP_HYBRID ? 512 : 1024;
+    const BandShape sh = band_shape(h, STEP == DESC_STEP_HYBRID);
     BandSweepArgs b{a, h->d_pieces, h->d_piece_ptr, h->band_rows};
     dim3 grid(h->band_grid);
-    switch (h->lps * 8 + h->G) {
-        case 16 * 8 + 1: hipLaunchKernelGGL((k_sweep_band<16, 1, STEP, NT>), grid, dim3(NT), h->band_lds, h->stream, b); break;
-        case 16 * 8 + 2: hipLaunchKernelGGL((k_sweep_band<16, 2, STEP, NT>), grid, dim3(NT), h->band_lds, h->stream, b); break;
-        case 32 * 8 + 2: hipLaunchKernelGGL((k_sweep_band<32, 2, STEP, NT>), grid, dim3(NT), h->band_lds, h->stream, b); break;
-        default:
-            if constexpr (STEP != DESC_STEP_HYBRID) {
-                if (h->lps == 32) hipLaunchKernelGGL((k_sweep_band<32, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b);
-                else hipLaunchKernelGGL((k_sweep_band<64, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b);
-            }
-            break;
+    if constexpr (STEP == DESC_STEP_HYBRID) {
+        switch (sh.lps * 8 + sh.E) {
+            case 16 * 8 + 1: hipLaunchKernelGGL((k_sweep_band<16, 1, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
+            case 16 * 8 + 2: hipLaunchKernelGGL((k_sweep_band<16, 2, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
+            default: hipLaunchKernelGGL((k_sweep_band<32, 2, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
+        }
+    } else {
+        switch (sh.lps * 8 + sh.E) {
+            case 16 * 8 + 1: hipLaunchKernelGGL((k_sweep_band<16, 1, STEP, 1024>), grid, dim3(1024), h->band_lds, h->stream, b); break;
+            case 16 * 8 + 2: hipLaunchKernelGGL((k_sweep_band<16, 2, STEP, 1024>), grid, dim3(1024), h->band_lds, h->stream, b); break;
+            case 16 * 8 + 4: hipLaunchKernelGGL((k_sweep_band<16, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
+            case 32 * 8 + 4: hipLaunchKernelGGL((k_sweep_band<32, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
+            default: hipLaunchKernelGGL((k_sweep_band<64, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
+        }
     }
 }
 void launch_sweep_node_layout(desc_pgd* h, const NodeSweepArgs& a, bool adam) {
@@ -2130,7 +2150,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
             if (kb && hipFuncSetAttribute(kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->band_lds) != hipSuccess) { (void)hipGetLastError(); h->band_ok = false; }
     }
     char nm[64];
-    if (h->band_ok) snprintf(nm, sizeof nm, "k_sweep_band<%d,%d,", h->lps, h->G);
+    if (h->band_ok) { const BandShape sh = band_shape(h, false); snprintf(nm, sizeof nm, "k_sweep_band<%d,%d,", sh.lps, sh.E); }
     else snprintf(nm, sizeof nm, "k_sweep_node<%d,%d,", h->lps, h->G);
     h->kname = nm;
 
