@@ -82,11 +82,11 @@ __device__ __forceinline__ double swap32_sum_f64(double v) {
 // receives its group's total.  Fixed butterfly order -> bitwise reproducible.
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
-    static_assert(G == 16 || G == 32 || G == 64, "group width");
+    static_assert(G == 8 || G == 16 || G == 32 || G == 64, "group width");
     v += dpp_mov_f64<0xB1>(v);    // quad_perm:[1,0,3,2]
     v += dpp_mov_f64<0x4E>(v);    // quad_perm:[2,3,0,1]
     v += dpp_mov_f64<0x141>(v);   // row_half_mirror
-    v += dpp_mov_f64<0x140>(v);   // row_mirror
+    if (G >= 16) v += dpp_mov_f64<0x140>(v);   // row_mirror
     if (G >= 32) v = swap16_sum_f64(v);
     if (G >= 64) v = swap32_sum_f64(v);
     return v;

@@ -707,7 +707,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
     __shared__ double s_part[2][NT / 64];
     // segments of up to 64 cycles: 1024 threads (16 waves, <= 128 VGPRs each); up to 256 cycles (4 cycles per lane: twice the
     // registers per pipeline stage) and the Adam plugin (its two moments are two more streams in and out): 512 threads (8 waves, <= 256 VGPRs).
-    static_assert((LPS == 16 || LPS == 32 || LPS == 64) && LPS * E <= MAX_SEG_CYCLES && (NT == 512 || NT == 1024) && (STEP != DESC_STEP_HYBRID || NT == 512), "band sweep instances");
+    static_assert((LPS == 8 || LPS == 16 || LPS == 32 || LPS == 64) && LPS * E <= MAX_SEG_CYCLES && (NT == 512 || NT == 1024) && (STEP != DESC_STEP_HYBRID || NT == 512), "band sweep instances");
     constexpr bool ADAM = STEP == DESC_STEP_HYBRID;
     constexpr int EA = ADAM ? E : 1;
     if (a.state->stop) return;
@@ -718,7 +718,8 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
     if (tid <= MAX_SEG_CYCLES) s_nv[tid] = tid <= a.max_cnt ? a.nv_tab[tid] : 0.0;
     double obj_acc = 0.0, chg_acc = 0.0;
 
-    struct RecRaw { int c0[SPW], c1[SPW]; EdgeInfo ei[SPW]; int t0; };      // wave-uniform (SGPRs)
+    constexpr bool VREC = SPW > 4;         // eight segments per wave: their records would not fit the SGPRs -- per-lane vector loads instead
+    struct RecRaw { int c0[VREC ? 1 : SPW], c1[VREC ? 1 : SPW]; EdgeInfo ei[VREC ? 1 : SPW]; int t0; };      // wave-uniform (SGPRs); VREC: this lane group's record (VGPRs)
     struct Rec { int c0, cnt, rbi, rbj, sa, sb, seg; };                   // this lane group's segment
     struct Str { uint32_t pk[E]; double w[E], d[E], am[EA], av[EA]; };     // am / av: HybridGradient.m_t / v_t (Adam only)
     struct Gat { double sj[E], si[E], T1, T2, So; };
@@ -732,6 +733,11 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
         auto load_raw = [&](int it) -> RecRaw {            // past the end: the piece's last segment, cnt = 0
             RecRaw q;
             q.t0 = pd.seg_lo + (it * NW + wv) * SPW;
+            if constexpr (VREC) {
+                const int t = min(q.t0 + grp, pd.seg_hi - 1);
+                q.c0[0] = a.cum[t]; q.c1[0] = a.cum[t + 1]; q.ei[0] = a.einfo[t];
+                return q;
+            }
 #pragma unroll
             for (int s2 = 0; s2 < SPW; ++s2) {
                 const int t = min(q.t0 + s2, pd.seg_hi - 1);
@@ -742,6 +748,12 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
         };
         auto land = [&](const RecRaw& q) -> Rec {
             Rec r{};
+            if constexpr (VREC) {
+                r.c0 = q.c0[0]; r.cnt = q.t0 + grp < pd.seg_hi ? q.c1[0] - q.c0[0] : 0;
+                r.rbi = q.ei[0].rb_i - pd.row_lo; r.rbj = q.ei[0].rb_j; r.sa = q.ei[0].slot_a; r.sb = q.ei[0].slot_b;
+                r.seg = min(q.t0 + grp, pd.seg_hi - 1);
+                return r;
+            }
 #pragma unroll
             for (int s2 = 0; s2 < SPW; ++s2)
                 if (grp == s2) {
@@ -823,7 +835,8 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
 #pragma unroll
                     for (int e = 0; e < E; ++e) sp += ((act >> e) & 1u) ? ws[e] : 0.0;
                     s1v = group_sum<LPS>(sp) - 1.0;
-                    if (LPS == 16) na = max(group16_sum((int)__popc(act)), 1);
+                    if (LPS == 8) na = max(group8_sum((int)__popc(act)), 1);
+                    else if (LPS == 16) na = max(group16_sum((int)__popc(act)), 1);
                     else {
                         na = 0;
 #pragma unroll
@@ -1379,6 +1392,7 @@ struct desc_pgd {
     int variant = VARIANT_GATHER;
     int G = 64;                 // gather variant: lanes per segment (0 = big fallback); node variant: cycles per lane
     int lps = 16;               // node variant: lanes per segment
+    bool band_jmajor = false;   // band sweep: j-block-major units (large graphs) instead of contiguous ranges
     int grid = 0;               // sweep grid (multiple of 8)
     int obj_grid = 0;
     int colsum_grid = 0, colsum_stride = 0;
@@ -1538,14 +1552,16 @@ void launch_node(desc_pgd* h, const NodeSweepArgs& a) {
 }
 
 // Band sweep instances by the longest segment: lanes per segment x cycles per lane, threads per workgroup.
-//   <= 16 cycles: 16 x 1, 1024     <= 32: 16 x 2, 1024     <= 64: 16 x 4, 512     <= 128: 32 x 4, 512     <= 256: 64 x 4, 512
+//   <= 16 cycles: 16 x 1, 1024     <= 32: 16 x 2, 1024 (8 x 4, 512 on small graphs)     <= 64: 16 x 4, 512     <= 128: 32 x 4, 512     <= 256: 64 x 4, 512
 // (33..64 cycles: 8 waves with 4 cycles per lane beat 16 waves of 32 x 2 by 5 % at C2 and C4 -- the DPP reductions are shared by four
-//  segments per wave instead of two; 8 lanes x 4 cycles for <= 32 was slower: eight segment records per wave spill the SGPRs.)
+//  segments per wave instead of two.  17..32 cycles: 8 lanes x 4 cycles, eight segments per wave with their records in per-lane vector
+//  loads (they would spill the SGPRs), gains 4-5 % where S stays in the L2 (C3) and loses 1-2 % at C5, where the gathers need the waves.)
 // The Adam plugin: 512-thread instances (the moments ride in the stream sets) up to 64 cycles: 16 x 1, 16 x 2, 32 x 2.
 struct BandShape { int lps, E; };
 BandShape band_shape(const desc_pgd* h, bool adam) {
     const int c = h->max_cnt;
     if (adam) return c <= 16 ? BandShape{16, 1} : c <= 32 ? BandShape{16, 2} : BandShape{32, 2};
+    if (c > 16 && c <= 32 && !h->band_jmajor) return BandShape{8, 4};      // graphs whose S stays in the L2 (contiguous ranges)
     return c <= 16 ? BandShape{16, 1} : c <= 32 ? BandShape{16, 2} : c <= 64 ? BandShape{16, 4} : c <= 128 ? BandShape{32, 4} : BandShape{64, 4};
 }
 bool band_adam_ok(const desc_pgd* h) { return h->band_ok && h->max_cnt <= 64; }
@@ -1564,6 +1580,7 @@ const void* band_kernel(const desc_pgd* h) {
             case 16 * 8 + 1: return (const void*)k_sweep_band<16, 1, STEP, 1024>;
             case 16 * 8 + 2: return (const void*)k_sweep_band<16, 2, STEP, 1024>;
             case 16 * 8 + 4: return (const void*)k_sweep_band<16, 4, STEP, 512>;
+            case 8 * 8 + 4: return (const void*)k_sweep_band<8, 4, STEP, 512>;
             case 32 * 8 + 4: return (const void*)k_sweep_band<32, 4, STEP, 512>;
             default: return (const void*)k_sweep_band<64, 4, STEP, 512>;
         }
@@ -1585,6 +1602,7 @@ void launch_band(desc_pgd* h, const NodeSweepArgs& a) {
             case 16 * 8 + 1: hipLaunchKernelGGL((k_sweep_band<16, 1, STEP, 1024>), grid, dim3(1024), h->band_lds, h->stream, b); break;
             case 16 * 8 + 2: hipLaunchKernelGGL((k_sweep_band<16, 2, STEP, 1024>), grid, dim3(1024), h->band_lds, h->stream, b); break;
             case 16 * 8 + 4: hipLaunchKernelGGL((k_sweep_band<16, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
+            case 8 * 8 + 4: hipLaunchKernelGGL((k_sweep_band<8, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
             case 32 * 8 + 4: hipLaunchKernelGGL((k_sweep_band<32, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
             default: hipLaunchKernelGGL((k_sweep_band<64, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
         }
@@ -1934,6 +1952,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         h->band_grid = ncu;
         bool jmajor = false;
         plan_band_pieces(prob, s, P, h->seg_lo, h->seg_hi, h->cyc_lo, mcl, h->band_grid, pieces, piece_ptr, h->band_rows, jmajor);
+        h->band_jmajor = jmajor;
         if (timing) fprintf(stderr, "[desc_amd] band sweep: %zu bands, %zu pieces over %d workgroups, %s, rows <= %d\n", P.band_lo.size() - 1, pieces.size(),
                             h->band_grid, jmajor ? "j-block-major units" : "contiguous ranges", h->band_rows);
     }
