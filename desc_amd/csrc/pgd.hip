@@ -1552,10 +1552,12 @@ void launch_node(desc_pgd* h, const NodeSweepArgs& a) {
 }
 
 // Band sweep instances by the longest segment: lanes per segment x cycles per lane, threads per workgroup.
-//   <= 16 cycles: 16 x 1, 1024     <= 32: 16 x 2, 1024 (8 x 4, 512 on small graphs)     <= 64: 16 x 4, 512     <= 128: 32 x 4, 512     <= 256: 64 x 4, 512
+//   <= 16 cycles: 16 x 1, 1024     <= 32: 16 x 2, 512 (8 x 4, 512 on small graphs)     <= 64: 16 x 4, 512     <= 128: 32 x 4, 512     <= 256: 64 x 4, 512
 // (33..64 cycles: 8 waves with 4 cycles per lane beat 16 waves of 32 x 2 by 5 % at C2 and C4 -- the DPP reductions are shared by four
 //  segments per wave instead of two.  17..32 cycles: 8 lanes x 4 cycles, eight segments per wave with their records in per-lane vector
-//  loads (they would spill the SGPRs), gains 4-5 % where S stays in the L2 (C3) and loses 1-2 % at C5, where the gathers need the waves.)
+//  loads (they would spill the SGPRs), gains 4-5 % where S stays in the L2 (C3) and loses 1-2 % at C5; there 16 x 2 on 8 waves beats
+//  the same shape on 16 waves by 2-4 % (12 waves: 1 %; 4 waves lose 7-22 % everywhere): fewer waves keep more of the j rows in the caches --
+//  the PMC traffic of the C4 sweep fell from 6.2 to 5.6 GB with the 8-wave shape.)
 // The Adam plugin: 512-thread instances (the moments ride in the stream sets) up to 64 cycles: 16 x 1, 16 x 2, 32 x 2.
 struct BandShape { int lps, E; };
 BandShape band_shape(const desc_pgd* h, bool adam) {
@@ -1578,7 +1580,7 @@ const void* band_kernel(const desc_pgd* h) {
     } else {
         switch (sh.lps * 8 + sh.E) {
             case 16 * 8 + 1: return (const void*)k_sweep_band<16, 1, STEP, 1024>;
-            case 16 * 8 + 2: return (const void*)k_sweep_band<16, 2, STEP, 1024>;
+            case 16 * 8 + 2: return (const void*)k_sweep_band<16, 2, STEP, 512>;
             case 16 * 8 + 4: return (const void*)k_sweep_band<16, 4, STEP, 512>;
             case 8 * 8 + 4: return (const void*)k_sweep_band<8, 4, STEP, 512>;
             case 32 * 8 + 4: return (const void*)k_sweep_band<32, 4, STEP, 512>;
@@ -1600,7 +1602,7 @@ void launch_band(desc_pgd* h, const NodeSweepArgs& a) {
     } else {
         switch (sh.lps * 8 + sh.E) {
             case 16 * 8 + 1: hipLaunchKernelGGL((k_sweep_band<16, 1, STEP, 1024>), grid, dim3(1024), h->band_lds, h->stream, b); break;
-            case 16 * 8 + 2: hipLaunchKernelGGL((k_sweep_band<16, 2, STEP, 1024>), grid, dim3(1024), h->band_lds, h->stream, b); break;
+            case 16 * 8 + 2: hipLaunchKernelGGL((k_sweep_band<16, 2, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
             case 16 * 8 + 4: hipLaunchKernelGGL((k_sweep_band<16, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
             case 8 * 8 + 4: hipLaunchKernelGGL((k_sweep_band<8, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
             case 32 * 8 + 4: hipLaunchKernelGGL((k_sweep_band<32, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
