@@ -884,13 +884,16 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
         { const RecRaw q = load_raw(2); R2 = land(q); S2 = load_stream(R2); }
         Q = load_raw(3);
         // the band's rows of S_old -> LDS, while the first streams are in flight
-        {   // every load of the rows in flight at once (one memory latency per piece instead of three)
-            constexpr int RL = (BAND_ROW_CAP + NT - 1) / NT;
-            double v[RL];
+        {
+            // up to 19 loads in flight per thread: one batch for 1024 threads, two for 512 (38 at once cost the 64 x 4 instance 3.5 %)
+            constexpr int RL = (BAND_ROW_CAP + 1023) / 1024;
+            for (int base = 0; base < pd.row_len; base += RL * NT) {
+                double v[RL];
 #pragma unroll
-            for (int u = 0; u < RL; ++u) v[u] = a.S_old[pd.row_lo + min(u * NT + tid, pd.row_len - 1)];
+                for (int u = 0; u < RL; ++u) v[u] = a.S_old[pd.row_lo + min(base + u * NT + tid, pd.row_len - 1)];
 #pragma unroll
-            for (int u = 0; u < RL; ++u) if (u * NT + tid < pd.row_len) s_rows[u * NT + tid] = v[u];
+                for (int u = 0; u < RL; ++u) if (base + u * NT + tid < pd.row_len) s_rows[base + u * NT + tid] = v[u];
+            }
         }
         __syncthreads();
         G0 = issue_gathers(R0, S0);
