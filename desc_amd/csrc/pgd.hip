@@ -26,13 +26,14 @@
 //    HBM traffic per cycle and iteration: sweep 28 B (w r/w 16, S0 8, packed word 4)
 //    + column sums (w 8 + a 2-byte column index for the mirrored cycles only), plus the row
 //    gathers of S served by L1/L2.
-//    Two sweeps run on this layout.  k_sweep_band (default since round 2, segments <= 64 cycles): bands sized so that their
-//    CSR rows fit the LDS of a CU, one 1024-thread workgroup per CU, S({k,i}) from the LDS, register-pipelined waves, work
-//    dealt in j-block-major units so that the rows of S({j,k}) stay in the L2s.  k_sweep_node (round 1; long segments, tiny
-//    graphs, the Adam plugin): L2-sized bands, 512-thread workgroups, chunks staged through the LDS.
+//    Two sweeps run on this layout.  k_sweep_band (default since round 2, segments <= 256 cycles): bands sized so that their
+//    CSR rows fit the LDS of a CU, one workgroup per CU (8 waves; shapes: band_shape()), S({k,i}) from the LDS,
+//    register-pipelined waves, work dealt in j-block-major units so that the rows of S({j,k}) stay in the L2s; the Adam plugin on
+//    its own instances up to 64 cycles.  k_sweep_node (round 1; tiny graphs, rows beyond the LDS, Adam on longer segments):
+//    L2-sized bands, 512-thread workgroups, chunks staged through the LDS.
 //
 //  GATHER (fallback: max degree >= 32768, more LDS than a workgroup may hold, or
-//  segments longer than 64 cycles).  Natural edge order; per cycle e_jk, e_ki, ikj, jki
+//  segments longer than 256 cycles).  Natural edge order; per cycle e_jk, e_ki, ikj, jki
 //  and element-granular gathers S[e_jk], S[e_ki], w[ikj], w[jki]  (72 B per cycle as
 //  SURVEY.md 8d counts them).
 //
