@@ -19,7 +19,10 @@ rng = np.random.default_rng(args.seed)
 t_end = time.time() + args.seconds
 n_cases = n_fail = 0
 worst = 0.0
+t_note = time.time()
 while time.time() < t_end:
+    if time.time() - t_note > 60:          # a progress line per minute (a silent GPU run is taken to be hung)
+        print("... %d cases, %d failures so far" % (n_cases, n_fail), flush=True); t_note = time.time()
     kind = "uniform" if rng.random() < 0.7 else "nonuniform"
     n = int(rng.choice([5, 8, 13, 21, 34, 55, 89, 144, 233, 300]))
     p = float(rng.choice([0.08, 0.15, 0.3, 0.5, 0.7, 0.95]))
