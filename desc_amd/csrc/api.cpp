@@ -71,6 +71,7 @@ int desc_structure_import(int64_t n, int64_t m, int64_t m_pos, int32_t n_sample,
                           const int32_t* pos_edge, const int64_t* cum_ind,
                           const int32_t* k, const int32_t* e_jk, const int32_t* e_ki,
                           const int32_t* ikj, const int32_t* jki, desc_structure** out) {
+    return no_throw("desc_structure_import", [&]() -> int {
     if (!out) return fail(DESC_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (n < 0 || m < 0 || m_pos < 0 || m_pos > m) return fail(DESC_ERR_INVALID, "bad sizes");
@@ -103,6 +104,7 @@ int desc_structure_import(int64_t n, int64_t m, int64_t m_pos, int32_t n_sample,
     s->ikj.assign(ikj, ikj + mc); s->jki.assign(jki, jki + mc);
     *out = s;
     return DESC_OK;
+    });
 }
 
 int desc_structure_get(const desc_structure* cs, desc_structure_view* v) {
@@ -135,6 +137,7 @@ void desc_structure_free(desc_structure* s) { if (s) { structure_free_device(s);
 //  running -- one sweep of 16-26 ms instead of 1.2 ms in the rocprofv3 trace at C4 -- for as long as it takes.)
 
 int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* r) {
+    return no_throw("desc_pgd_solve", [&]() -> int {
     if (!p || !r) return fail(DESC_ERR_INVALID, "NULL argument");
     auto t0 = std::chrono::steady_clock::now();
     auto t_lap = t0;
@@ -171,6 +174,7 @@ int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* 
     r->ms_structure = ms_structure;
     r->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
+    });
 }
 
 }  // extern "C"

@@ -137,6 +137,7 @@ extern "C" int desc_cemp_run(const desc_problem* prob, const double* beta, int32
 
 extern "C" int desc_cemp_run_dev(const desc_device_problem* dp, const double* beta, int32_t n_beta, int32_t max_iter, int32_t nsample,
                                  uint64_t seed, double* s_vec, double* ms_total) {
+    return no_throw("desc_cemp_run_dev", [&]() -> int {
     if (!dp || !s_vec || !beta) return fail(DESC_ERR_INVALID, "NULL argument");
     if (n_beta < 1 || max_iter < 0 || nsample < 1) return fail(DESC_ERR_INVALID, "need n_beta >= 1, max_iter >= 0, nsample >= 1");
     int rc = DESC_OK;
@@ -188,4 +189,5 @@ extern "C" int desc_cemp_run_dev(const desc_device_problem* dp, const double* be
     if (m) DESC_HIP(hipMemcpy(s_vec, d_S[cur], sizeof(double) * m, hipMemcpyDeviceToHost));
     if (ms_total) *ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return DESC_OK;
+    });
 }

@@ -3,6 +3,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -94,4 +96,13 @@ int build_cemp_samples_device(const desc_device_problem* dp, int32_t nsample, ui
 inline desc_problem host_view(const desc_device_problem* dp) { return desc_problem{dp->n, dp->m, dp->ii.data(), dp->jj.data(), nullptr}; }
 int build_cemp_samples_host(const desc_problem* prob, int32_t nsample, uint64_t seed, hvec<int32_t>& pos_edge,
                             hvec<int32_t>& kk, hvec<int32_t>& e_jk, hvec<int32_t>& e_ki);
+// No C++ exception may cross the C ABI (a MATLAB or Python host would be aborted): the entry points that allocate host memory run
+// their bodies through this guard.
+template <class F>
+int no_throw(const char* what, F&& f) noexcept {
+    try { return f(); }
+    catch (const std::bad_alloc&) { return fail(DESC_ERR_INVALID, "%s: out of host memory", what); }
+    catch (const std::exception& e) { return fail(DESC_ERR_INVALID, "%s: %s", what, e.what()); }
+    catch (...) { return fail(DESC_ERR_INVALID, "%s: unknown C++ exception", what); }
+}
 }  // namespace desc

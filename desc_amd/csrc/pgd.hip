@@ -2285,13 +2285,17 @@ static int create_impl(const desc_problem* prob, const double* shared_rij, const
 
 int desc_pgd_create_shard(const desc_problem* prob, const desc_structure* s, int32_t device, int32_t rank, int32_t world,
                           desc_pgd** out) {
+    return no_throw("desc_pgd_create_shard", [&]() -> int {
     return create_impl(prob, nullptr, s, device, rank, world, out);
+    });
 }
 // the same with the problem already resident in HBM (desc_problem_upload): nothing but O(m_pos) plan tables is uploaded
 int desc_pgd_create_dev(const desc_device_problem* dp, const desc_structure* s, int32_t rank, int32_t world, desc_pgd** out) {
+    return no_throw("desc_pgd_create_dev", [&]() -> int {
     if (!dp) return fail(DESC_ERR_INVALID, "NULL argument");
     const desc_problem hv = host_view(dp);
     return create_impl(&hv, dp->d_rij, s, dp->device, rank, world, out);
+    });
 }
 
 static int create_impl(const desc_problem* prob, const double* shared_rij, const desc_structure* s, int32_t device, int32_t rank, int32_t world,
@@ -2560,6 +2564,7 @@ static int upload_adam_state(desc_pgd* h, const desc_params* p, const desc_resul
 // eigen-solve per iteration.  The alignment against R_orig (:238, GlobalSOdCorrectRight) stays with the caller.
 int desc_pgd_run_traced(desc_pgd* h, const desc_device_problem* dp, const desc_params* p, const double* err_vec, double gcw_tol,
                         int32_t gcw_max_iters, double* svec_errors, double* R_est_all, desc_result* r) {
+    return no_throw("desc_pgd_run_traced", [&]() -> int {
     if (!h || !dp || !p || !r || !err_vec || !svec_errors || !R_est_all) return fail(DESC_ERR_INVALID, "NULL argument");
     if (!r->s_vec || !r->obj_trace || !r->avg_change_trace) return fail(DESC_ERR_INVALID, "the traced run needs s_vec, obj_trace and avg_change_trace");
     if (dp->m != h->m || dp->n != h->n) return fail(DESC_ERR_INVALID, "device problem and solver handle describe different graphs");
@@ -2584,9 +2589,11 @@ int desc_pgd_run_traced(desc_pgd* h, const desc_device_problem* dp, const desc_p
     rc = desc_pgd_download(h, r);
     r->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
+    });
 }
 
 int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r) {
+    return no_throw("desc_pgd_run", [&]() -> int {
     if (!h || !p || !r) return fail(DESC_ERR_INVALID, "NULL argument");
     auto t0 = std::chrono::steady_clock::now();
     int rc = desc_pgd_reset(h, p); if (rc) return rc;
@@ -2633,6 +2640,7 @@ int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r) {
         for (int it = 1; it <= r->iters_run; ++it) emit(it, r->avg_change_trace[it - 1], r->obj_trace[it - 1]);
     r->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return DESC_OK;
+    });
 }
 
 // ------------------------------------------------------------- multi-GPU pieces --

@@ -361,6 +361,7 @@ extern "C" int desc_refine_run(const desc_problem* prob, const double* s_vec, co
 
 extern "C" int desc_refine_run_dev(const desc_device_problem* dp, const double* s_vec, const double* R_init, double stop_threshold,
                                    int32_t max_iters, double* R_out, desc_refine_info* info) {
+    return no_throw("desc_refine_run_dev", [&]() -> int {
     if (!dp || !s_vec || !R_init || !R_out) return fail(DESC_ERR_INVALID, "NULL argument");
     int rc = DESC_OK;
     const int64_t n = dp->n, m = dp->m;
@@ -468,4 +469,5 @@ extern "C" int desc_refine_run_dev(const desc_device_problem* dp, const double* 
         info->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return DESC_OK;
+    });
 }

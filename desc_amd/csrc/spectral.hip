@@ -285,13 +285,17 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
 
 extern "C" int desc_spectral_run_dev(const desc_device_problem* dp, const double* weights, int32_t normalize_rows, double tol,
                                      int32_t max_iters, double* R_out, desc_spectral_info* info) {
+    return no_throw("desc_spectral_run_dev", [&]() -> int {
     return spectral_impl(dp, weights, nullptr, normalize_rows, tol, max_iters, R_out, info);
+    });
 }
 // R_est = GCW(Ind, AdjMat, RijMat, SVec) -- Utils/GCW.m:9-36 with the weights formed on the device from SVec (m doubles)
 extern "C" int desc_gcw_run_dev(const desc_device_problem* dp, const double* s_vec, double tol, int32_t max_iters, double* R_out,
                                 desc_spectral_info* info) {
+    return no_throw("desc_gcw_run_dev", [&]() -> int {
     if (!s_vec) return fail(DESC_ERR_INVALID, "NULL argument");
     return spectral_impl(dp, nullptr, s_vec, 1, tol, max_iters, R_out, info);
+    });
 }
 
 static int spectral_impl(const desc_device_problem* dp, const double* weights, const double* gcw_svec, int32_t normalize_rows, double tol,
