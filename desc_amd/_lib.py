@@ -192,7 +192,49 @@ def load():
     return L
 
 
+# ---- DESC_DEBUG_GUARD=1 (diagnostics; tests/conftest.py turns it on): every buffer this module hands to the library to be
+# written is fenced by 64 bytes of guard words on both sides, and every fence still alive is verified after each native call --
+# a write past a caller buffer (or a late write into an older one) is reported at the call that made it.
+GUARD = os.environ.get("DESC_DEBUG_GUARD") == "1"
+_FENCE = 64
+_FENCE_BYTE = 0xA5
+_fences = []          # weak references to the fenced base arrays
+
+
+def out_buffer(count, dtype=np.float64):
+    """Zeroed output buffer for the library to fill (count >= 1 elements)."""
+    count = max(int(count), 1)
+    if not GUARD:
+        return np.zeros(count, dtype=dtype)
+    import weakref
+    nbytes = count * np.dtype(dtype).itemsize
+    base = np.zeros(nbytes + 2 * _FENCE, dtype=np.uint8)
+    base[:_FENCE] = _FENCE_BYTE
+    base[_FENCE + nbytes:] = _FENCE_BYTE
+    _fences.append(weakref.ref(base))
+    return base[_FENCE:_FENCE + nbytes].view(dtype)
+
+
+def verify_guards():
+    """Check the fences of every live guarded buffer; raises DescError(ERR_STATE) naming the damaged side."""
+    if not _fences:
+        return
+    live = []
+    for r in _fences:
+        base = r()
+        if base is None:
+            continue
+        live.append(r)
+        lo, hi = base[:_FENCE], base[base.size - _FENCE:]
+        if (lo != _FENCE_BYTE).any() or (hi != _FENCE_BYTE).any():
+            side = "before" if (lo != _FENCE_BYTE).any() else "after"
+            raise DescError(f"DESC_DEBUG_GUARD: native code wrote {side} a caller buffer of {base.size - 2 * _FENCE} bytes", ERR_STATE)
+    _fences[:] = live
+
+
 def check(rc):
+    if GUARD:
+        verify_guards()
     if rc != DESC_OK:
         raise DescError(f"desc_amd error {rc}: {load().desc_last_error().decode()}", rc)
 
@@ -319,20 +361,25 @@ class Solver:
         return load().desc_pgd_kernel_name(self.handle).decode()
 
     def s0(self):
-        out = np.zeros(max(self.m_cycle, 1))
+        out = out_buffer(self.m_cycle)
         check(load().desc_pgd_get_s0(self.handle, ptr(out, F64P)))
         return out[:self.m_cycle]
 
     def _result(self, iters, want_w=False, adam=None):
-        bufs = dict(s_vec=np.zeros(max(self.m, 1)), obj=np.zeros(max(iters, 1)), avg=np.zeros(max(iters, 1)))
+        bufs = dict(s_vec=out_buffer(self.m), obj=out_buffer(iters), avg=out_buffer(iters))
         r = Result()
         r.s_vec = ptr(bufs["s_vec"], F64P)
         r.obj_trace = ptr(bufs["obj"], F64P)
         r.avg_change_trace = ptr(bufs["avg"], F64P)
         if want_w:
-            bufs["w"] = np.zeros(max(self.m_cycle, 1))
+            bufs["w"] = out_buffer(self.m_cycle)
             r.w = ptr(bufs["w"], F64P)
         if adam is not None:
+            # the library reads AND writes m_cycle doubles through these pointers (HybridGradient.m_t / v_t)
+            for a in adam:
+                if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous and a.flags.writeable
+                        and (a.size == self.m_cycle or self.m_cycle == 0)):
+                    raise ValueError(f"Adam state must be two writable contiguous float64 arrays of m_cycle = {self.m_cycle} entries")
             bufs["adam_m"], bufs["adam_v"] = adam
             r.adam_m = ptr(bufs["adam_m"], F64P)
             r.adam_v = ptr(bufs["adam_v"], F64P)
@@ -362,7 +409,7 @@ class Solver:
         ev = np.ascontiguousarray(err_vec, dtype=np.float64).reshape(-1)
         if ev.size != self.m:
             raise ValueError("err_vec must have m entries")
-        se = np.zeros(max(params.iters, 1)); Rall = np.zeros(max(params.iters, 1) * 9 * max(n, 1))
+        se = out_buffer(params.iters); Rall = out_buffer(max(params.iters, 1) * 9 * max(n, 1))
         check(load().desc_pgd_run_traced(self.handle, dprob.handle, C.byref(params), ptr(ev, F64P), gcw_tol, gcw_max_iters,
                                          ptr(se, F64P), ptr(Rall, F64P), C.byref(r)))
         out = self._pack(r, bufs)
@@ -451,7 +498,7 @@ class Solver:
 def solve(prob: ProblemArrays, params: Params, want_w=False):
     """One-shot desc_pgd_solve: structure build + layout + run + download in one C call."""
     r = Result()
-    bufs = dict(s_vec=np.zeros(max(prob.m, 1)), obj=np.zeros(max(params.iters, 1)), avg=np.zeros(max(params.iters, 1)))
+    bufs = dict(s_vec=out_buffer(prob.m), obj=out_buffer(params.iters), avg=out_buffer(params.iters))
     r.s_vec = ptr(bufs["s_vec"], F64P)
     r.obj_trace = ptr(bufs["obj"], F64P)
     r.avg_change_trace = ptr(bufs["avg"], F64P)
@@ -464,8 +511,10 @@ def solve(prob: ProblemArrays, params: Params, want_w=False):
 def spectral_run(prob, weights=None, normalize_rows=False, tol=1e-13, max_iters=500, device=0):
     """desc_spectral_run[_dev] -> (R (3,3,n) Fortran-ordered, info dict).  prob: ProblemArrays or DeviceProblem."""
     n = prob.n
-    R = np.zeros(9 * max(n, 1))
+    R = out_buffer(9 * n)
     w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+    if w is not None and w.size != prob.m:
+        raise ValueError("weights must have m entries")
     info = SpectralInfo()
     if isinstance(prob, DeviceProblem):
         check(load().desc_spectral_run_dev(prob.handle, ptr(w, F64P), 1 if normalize_rows else 0, tol, max_iters, ptr(R, F64P), C.byref(info)))
@@ -479,8 +528,10 @@ def spectral_run(prob, weights=None, normalize_rows=False, tol=1e-13, max_iters=
 def gcw_run(dprob: DeviceProblem, s_vec, tol=1e-13, max_iters=500):
     """desc_gcw_run_dev: GCW with the weights formed on the device from S_vec -> (R (3,3,n), info)."""
     n = dprob.n
-    R = np.zeros(9 * max(n, 1))
+    R = out_buffer(9 * n)
     S = np.ascontiguousarray(s_vec, dtype=np.float64)
+    if S.size != dprob.m:
+        raise ValueError("s_vec must have m entries")
     info = SpectralInfo()
     check(load().desc_gcw_run_dev(dprob.handle, ptr(S, F64P), tol, max_iters, ptr(R, F64P), C.byref(info)))
     return R[:9 * n].reshape((3, 3, n), order="F"), dict(iters=info.iters, products=info.products, converged=bool(info.converged), residual=info.residual,
@@ -489,7 +540,7 @@ def gcw_run(dprob: DeviceProblem, s_vec, tol=1e-13, max_iters=500):
 
 def cemp_run(prob, beta, max_iter, nsample, seed=0, device=0):
     b = np.ascontiguousarray(beta, dtype=np.float64).reshape(-1)
-    S = np.zeros(max(prob.m, 1))
+    S = out_buffer(prob.m)
     ms = C.c_double()
     L = load()
     if isinstance(prob, DeviceProblem):
@@ -505,7 +556,9 @@ def refine_run(prob, s_vec, R_init, stop_threshold=1e-3, max_iters=100, device=0
     n = prob.n
     S = np.ascontiguousarray(s_vec, dtype=np.float64)
     Ri = np.ascontiguousarray(np.asarray(R_init, dtype=np.float64).reshape(-1, order="F"))
-    Ro = np.zeros(9 * max(n, 1))
+    Ro = out_buffer(9 * n)
+    if S.size != prob.m or Ri.size != 9 * n:
+        raise ValueError("s_vec must have m entries and R_init 3 x 3 x n")
     info = RefineInfo(); info.verbose = 1 if verbose else 0
     L = load()
     if isinstance(prob, DeviceProblem):

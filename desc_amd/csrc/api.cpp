@@ -56,12 +56,10 @@ int desc_structure_build(const desc_problem* prob, int32_t n_sample_min, uint64_
     if (n_sample_min < 1) return fail(DESC_ERR_INVALID, "n_sample_min must be >= 1");
     desc_structure* s = new (std::nothrow) desc_structure();
     if (!s) return fail(DESC_ERR_INVALID, "out of host memory");
-    try {
-        rc = (where == DESC_BUILD_DEVICE) ? build_structure_device(prob, n_sample_min, seed, device, s)
-                                          : build_structure_host(prob, n_sample_min, seed, s);
-    } catch (const std::bad_alloc&) {
-        rc = fail(DESC_ERR_INVALID, "out of host memory while building the structure");
-    }
+    rc = no_throw("desc_structure_build", [&]() -> int {
+        return (where == DESC_BUILD_DEVICE) ? build_structure_device(prob, n_sample_min, seed, device, s)
+                                            : build_structure_host(prob, n_sample_min, seed, s);
+    });
     if (rc) { structure_free_device(s); delete s; return rc; }
     *out = s;
     return DESC_OK;
@@ -110,7 +108,7 @@ int desc_structure_import(int64_t n, int64_t m, int64_t m_pos, int32_t n_sample,
 int desc_structure_get(const desc_structure* cs, desc_structure_view* v) {
     if (!cs || !v) return fail(DESC_ERR_INVALID, "NULL argument");
     desc_structure* s = const_cast<desc_structure*>(cs);      // lazily materialises the host copy of a device-built structure
-    int rc = structure_ensure_host(s);
+    int rc = no_throw("desc_structure_get", [&]() -> int { return structure_ensure_host(s); });
     if (rc) return rc;
     v->n = s->n; v->m = s->m; v->m_pos = s->m_pos; v->m_cycle = s->m_cycle;
     v->n_sample = s->n_sample; v->max_cnt = s->max_cnt;

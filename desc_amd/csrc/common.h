@@ -4,8 +4,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <exception>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "desc_amd.h"
@@ -96,6 +98,28 @@ int build_cemp_samples_device(const desc_device_problem* dp, int32_t nsample, ui
 inline desc_problem host_view(const desc_device_problem* dp) { return desc_problem{dp->n, dp->m, dp->ii.data(), dp->jj.data(), nullptr}; }
 int build_cemp_samples_host(const desc_problem* prob, int32_t nsample, uint64_t seed, hvec<int32_t>& pos_edge,
                             hvec<int32_t>& kk, hvec<int32_t>& e_jk, hvec<int32_t>& e_ki);
+// Worker threads of the host-side passes.  An exception that escapes a thread body (bad_alloc in a vector, system_error from the
+// thread constructor) would call std::terminate and take the MATLAB / Python host down: every body runs behind a catch, the
+// calling thread takes share 0 itself, all workers are joined, and the first exception is rethrown on the calling thread -- where
+// the no_throw guard of the entry point turns it into an error code.
+template <class F>
+void run_threads(int T, F&& body) {              // body(t), t = 0 .. T-1
+    if (T <= 1) { body(0); return; }
+    std::exception_ptr err;
+    std::mutex mu;
+    auto guarded = [&](int t) {
+        try { body(t); }
+        catch (...) { std::lock_guard<std::mutex> lk(mu); if (!err) err = std::current_exception(); }
+    };
+    std::vector<std::thread> th;
+    try {
+        th.reserve((size_t)T - 1);
+        for (int t = 1; t < T; ++t) th.emplace_back(guarded, t);
+        guarded(0);
+    } catch (...) { std::lock_guard<std::mutex> lk(mu); if (!err) err = std::current_exception(); }
+    for (auto& x : th) x.join();
+    if (err) std::rethrow_exception(err);
+}
 // No C++ exception may cross the C ABI (a MATLAB or Python host would be aborted): the entry points that allocate host memory run
 // their bodies through this guard.
 template <class F>

@@ -1448,7 +1448,8 @@ struct desc_pgd {
     int final_obj_T = -1;               // sweep count for which download already evaluated the objective
     int pending_fin = 0, pending_parts = 0;   // sweep whose bookkeeping (k_finalize) rides on the next column-sum launch
     int32_t* d_rank_seg = nullptr;
-    int trace_cap = 0;
+    int trace_cap = 0;          // allocated length of d_obj / d_avg (the largest budget this handle has seen)
+    int iters_cap = 0;          // max(1, params.iters) of the last reset: what the caller's trace buffers hold
     // run state
     desc_params p{};
     bool armed = false;
@@ -1505,9 +1506,7 @@ void host_parallel(int64_t count, F&& body, int64_t grain = 65536) {
     unsigned hw = std::thread::hardware_concurrency();
     int nt = (int)std::min<int64_t>(std::max(1u, std::min(hw, 16u)), std::max<int64_t>(1, count / grain));
     if (nt <= 1) { body(0, count); return; }
-    hvec<std::thread> th;
-    for (int t = 0; t < nt; ++t) th.emplace_back([=, &body]() { body(count * t / nt, count * (t + 1) / nt); });
-    for (auto& x : th) x.join();
+    run_threads(nt, [&](int t) { body(count * t / nt, count * (t + 1) / nt); });
 }
 
 StepArgs make_step(desc_pgd* h, bool* adam, int rd, int wr) {
@@ -2217,8 +2216,8 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         const unsigned g16 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256));
         hipLaunchKernelGGL(k_midx_rowsum, dim3(g16), dim3(256), 0, h->stream, h->d_rowptr, h->d_adj_seg, d_rowsum, (int)n);
         hvec<uint32_t> rs((size_t)n), rb((size_t)n);
-        DESC_HIP(hipMemcpyAsync(rs.data(), d_rowsum, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, h->stream));
         DESC_HIP(hipStreamSynchronize(h->stream));
+        DESC_HIP(hipMemcpy(rs.data(), d_rowsum, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
         uint64_t tot = 0;
         for (int64_t v = 0; v < n; ++v) { rb[v] = (uint32_t)tot; tot += rs[v]; }
         if (tot >= (1ull << 32)) return fail(DESC_ERR_TOO_LARGE, "column-index stream exceeds 2^32 entries");
@@ -2257,8 +2256,8 @@ int cycles_to_host(desc_pgd* h, const double* dev, double* host) {
     if (h->variant != VARIANT_NODE) { DESC_HIP(hipMemcpy(host, dev, sizeof(double) * h->m_cycle, hipMemcpyDeviceToHost)); return DESC_OK; }
     int g = (int)std::min<int64_t>(4096, (h->m_pos + 3) / 4);
     hipLaunchKernelGGL(k_reorder_cycles, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo, h->d_seg_perm, dev, h->d_scratch, (int)(h->seg_hi - h->seg_lo), 1);
-    DESC_HIP(hipMemcpyAsync(host, h->d_scratch, sizeof(double) * h->m_cycle, hipMemcpyDeviceToHost, h->stream));
     DESC_HIP(hipStreamSynchronize(h->stream));
+    DESC_HIP(hipMemcpy(host, h->d_scratch, sizeof(double) * h->m_cycle, hipMemcpyDeviceToHost));      // synchronous: nothing stays pending into caller memory
     return DESC_OK;
 }
 int ensure_scratch(desc_pgd* h) {
@@ -2395,6 +2394,7 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
     }
     h->t_done = 0; h->t_plugin = p->t0; h->ms_pgd = 0; h->objective_done = false; h->final_obj_T = -1; h->pending_fin = 0;
     const int cap = std::max(1, p->iters);
+    h->iters_cap = cap;
     if (cap > h->trace_cap) {
         dfree(h, h->d_obj); dfree(h, h->d_avg);
         h->d_obj = h->d_avg = nullptr; h->trace_cap = 0;
@@ -2437,7 +2437,7 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
 int desc_pgd_iterate(desc_pgd* h, int32_t n_iters) {
     if (!h) return fail(DESC_ERR_INVALID, "NULL handle");
     if (!h->armed) return fail(DESC_ERR_STATE, "desc_pgd_reset must be called first");
-    if (n_iters < 0 || h->t_done + n_iters > h->trace_cap) return fail(DESC_ERR_INVALID, "iterating past params.iters = %d", h->p.iters);
+    if (n_iters < 0 || h->t_done + n_iters > h->iters_cap) return fail(DESC_ERR_INVALID, "iterating past params.iters = %d", h->p.iters);
     int rc = set_device(h); if (rc) return rc;
     if (h->m_pos == 0) { h->t_done += n_iters; h->t_plugin += n_iters; return DESC_OK; }
     for (int q = 0; q < n_iters; ++q) { rc = enqueue_sweep(h, ++h->t_done); if (rc) return rc; }
@@ -2447,7 +2447,7 @@ int desc_pgd_iterate(desc_pgd* h, int32_t n_iters) {
 int desc_pgd_iterate_timed(desc_pgd* h, int32_t n_iters, float* ms_total, float* ms_main_kernel_avg) {
     if (!h) return fail(DESC_ERR_INVALID, "NULL handle");
     if (!h->armed) return fail(DESC_ERR_STATE, "desc_pgd_reset must be called first");
-    if (n_iters < 0 || h->t_done + n_iters > h->trace_cap) return fail(DESC_ERR_INVALID, "iterating past params.iters = %d", h->p.iters);
+    if (n_iters < 0 || h->t_done + n_iters > h->iters_cap) return fail(DESC_ERR_INVALID, "iterating past params.iters = %d", h->p.iters);
     int rc = set_device(h); if (rc) return rc;
     hipEvent_t e0, e1;
     DESC_HIP(hipEventCreate(&e0)); DESC_HIP(hipEventCreate(&e1));
@@ -2505,8 +2505,8 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, fin_args(h, h->d_partials, h->obj_grid, T, 1));
     }
     DevState st{};
-    DESC_HIP(hipMemcpyAsync(&st, h->d_state, sizeof st, hipMemcpyDeviceToHost, h->stream));
     DESC_HIP(hipStreamSynchronize(h->stream));
+    DESC_HIP(hipMemcpy(&st, h->d_state, sizeof st, hipMemcpyDeviceToHost));      // synchronous: `st` is a stack slot
     DESC_HIP(hipGetLastError());
     int iters_run = T, par = T & 1;
     if (h->m_pos > 0 && st.stop) { iters_run = st.iters_run; par = st.final_parity; }
@@ -2522,8 +2522,8 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
         if (h->variant == VARIANT_NODE) {
             int g = (int)std::min<int64_t>(1024, (h->m + 255) / 256);
             hipLaunchKernelGGL(k_extract_S, dim3(g), dim3(256), 0, h->stream, h->d_S[par], h->d_eslot, h->d_Svec, h->m);
-            DESC_HIP(hipMemcpyAsync(r->s_vec, h->d_Svec, sizeof(double) * h->m, hipMemcpyDeviceToHost, h->stream));
             DESC_HIP(hipStreamSynchronize(h->stream));
+            DESC_HIP(hipMemcpy(r->s_vec, h->d_Svec, sizeof(double) * h->m, hipMemcpyDeviceToHost));
         } else {
             DESC_HIP(hipMemcpy(r->s_vec, h->d_S[par], sizeof(double) * h->m, hipMemcpyDeviceToHost));
         }
@@ -2696,7 +2696,7 @@ int shard_enqueue_colsum(desc_pgd* h, hipStream_t st) {
 }
 double* my_slice(desc_pgd* h) { return h->x_sall + (int64_t)h->rank * h->slice_len; }
 int shard_enqueue_sweep(desc_pgd* h, hipStream_t st) {
-    if (h->t_done + 1 > h->trace_cap) return fail(DESC_ERR_INVALID, "iterating past params.iters = %d", h->p.iters);
+    if (h->t_done + 1 > h->iters_cap) return fail(DESC_ERR_INVALID, "iterating past params.iters = %d", h->p.iters);
     const int t = ++h->t_done, rd = (t - 1) & 1, wr = t & 1;
     bool adam = false;
     const StepArgs sa = make_step(h, &adam, rd, wr);
@@ -2824,7 +2824,7 @@ int desc_pgd_shard_start(desc_pgd* h, const desc_params* p) {
 int desc_pgd_shard_iterate(desc_pgd* h, int32_t n_iters) {
     if (!h || !h->armed) return fail(DESC_ERR_STATE, "desc_pgd_shard_start must be called first");
     if (!h->comm_stream) return fail(DESC_ERR_STATE, "desc_pgd_shard_set_collectives must be called first");
-    if (n_iters < 0 || h->t_done + n_iters > h->trace_cap) return fail(DESC_ERR_INVALID, "iterating past params.iters = %d", h->p.iters);
+    if (n_iters < 0 || h->t_done + n_iters > h->iters_cap) return fail(DESC_ERR_INVALID, "iterating past params.iters = %d", h->p.iters);
     int rc = set_device(h); if (rc) return rc;
     for (int q = 0; q < n_iters; ++q) {
         if ((rc = shard_enqueue_colsum(h, h->stream))) return rc;
@@ -2884,8 +2884,8 @@ int desc_pgd_stopped(desc_pgd* h, int32_t* stopped) {
     DevState st{};
     flush_finalize(h);
     if (h->comm_stream) DESC_HIP(hipStreamSynchronize(h->comm_stream));
-    DESC_HIP(hipMemcpyAsync(&st, h->d_state, sizeof st, hipMemcpyDeviceToHost, h->stream));
     DESC_HIP(hipStreamSynchronize(h->stream));
+    DESC_HIP(hipMemcpy(&st, h->d_state, sizeof st, hipMemcpyDeviceToHost));      // synchronous: `st` is a stack slot
     *stopped = st.stop;
     return DESC_OK;
 }

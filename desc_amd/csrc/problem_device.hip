@@ -3,7 +3,6 @@
 #include <chrono>
 #include <cstdlib>
 #include <new>
-#include <thread>
 #include <vector>
 
 #include "device_utils.h"
@@ -15,6 +14,7 @@ extern "C" {
 int desc_problem_upload(const desc_problem* prob, int32_t device, desc_device_problem** out) {
     if (!out) return fail(DESC_ERR_INVALID, "out is NULL");
     *out = nullptr;
+    return no_throw("desc_problem_upload", [&]() -> int {
     int rc = validate_problem(prob, true);
     if (rc) return rc;
     int ndev = 0;
@@ -32,13 +32,17 @@ int desc_problem_upload(const desc_problem* prob, int32_t device, desc_device_pr
         !A((void**)&dp->d_adj, sizeof(int32_t) * 2 * m) || !A((void**)&dp->d_adj_eid, sizeof(int32_t) * 2 * m) || !A((void**)&dp->d_rij, sizeof(double) * 9 * m))
         return bail(fail(DESC_ERR_HIP, "out of device memory for the problem (m = %lld)", (long long)m));
     // the big copy (72 B per edge; synchronous copies from pageable memory run at ~12 GB/s, asynchronous ones at ~3 GB/s
-    // on this runtime) overlaps the host-side CSR pass, which runs on a helper thread
+    // on this runtime) overlaps the host-side CSR pass, which runs on a helper thread (share 1 of run_threads: an exception in it
+    // is rethrown here after the join and becomes an error code)
     hvec<int32_t> adj, adj_eid;
-    std::thread csr([&]() {
+    hipError_t e = hipSuccess;
+    try {
+    run_threads(2, [&](int share) {
+    if (share == 1) {
         dp->ii.assign(prob->ind_i, prob->ind_i + m); dp->jj.assign(prob->ind_j, prob->ind_j + m);
         build_csr(n, m, prob->ind_i, prob->ind_j, dp->rowptr, adj, adj_eid);
-    });
-    hipError_t e = hipSuccess;
+        return;
+    }
     // the caller's rotation array is pinned in place for the duration of the copy when it is large: a registered buffer is copied
     // by DMA at PCIe speed, a pageable one is staged through the runtime's bounce buffers (DESC_UPLOAD_PIN=0 disables)
     const char* pin_env = std::getenv("DESC_UPLOAD_PIN");
@@ -49,7 +53,8 @@ int desc_problem_upload(const desc_problem* prob, int32_t device, desc_device_pr
     if (pinned) (void)hipHostUnregister((void*)prob->rij);
     if (m && e == hipSuccess) e = hipMemcpy(dp->d_ii, prob->ind_i, sizeof(int32_t) * m, hipMemcpyHostToDevice);
     if (m && e == hipSuccess) e = hipMemcpy(dp->d_jj, prob->ind_j, sizeof(int32_t) * m, hipMemcpyHostToDevice);
-    csr.join();
+    });
+    } catch (...) { desc_problem_free(dp); throw; }
     if (e == hipSuccess) e = hipMemcpy(dp->d_rowptr, dp->rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice);
     if (m && e == hipSuccess) e = hipMemcpy(dp->d_adj, adj.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice);
     if (m && e == hipSuccess) e = hipMemcpy(dp->d_adj_eid, adj_eid.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice);
@@ -57,6 +62,7 @@ int desc_problem_upload(const desc_problem* prob, int32_t device, desc_device_pr
     dp->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *out = dp;
     return DESC_OK;
+    });
 }
 
 void desc_problem_free(desc_device_problem* dp) {

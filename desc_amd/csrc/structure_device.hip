@@ -372,10 +372,7 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
         const int T = m >= (1 << 20) ? (int)std::max(1u, std::min(hw, 16u)) : 1;
         hvec<int64_t> c_pos((size_t)T + 1, 0), c_cyc((size_t)T + 1, 0);
         auto run = [&](auto&& body) {
-            if (T == 1) { body(0, (int64_t)0, m); return; }
-            hvec<std::thread> th;
-            for (int t = 0; t < T; ++t) th.emplace_back([=, &body]() { body(t, m * t / T, m * (t + 1) / T); });
-            for (auto& x : th) x.join();
+            run_threads(T, [&](int t) { body(t, m * t / T, m * (t + 1) / T); });
         };
         run([&](int t, int64_t a, int64_t b) {
             int64_t np = 0, nc = 0;

@@ -39,15 +39,12 @@ void parallel_for(int64_t count, F&& body) {
     unsigned hw = std::thread::hardware_concurrency();
     int nt = (int)std::min<int64_t>(std::max(1u, std::min(hw, 32u)), std::max<int64_t>(1, count / 2048));
     if (nt <= 1) { body(0, count, 0); return; }
-    hvec<std::thread> th;
     // interleaved blocks: low-numbered edges have larger neighbour lists on average
-    int64_t chunk = 1024;
-    for (int t = 0; t < nt; ++t)
-        th.emplace_back([=, &body]() {
-            for (int64_t a = (int64_t)t * chunk; a < count; a += (int64_t)nt * chunk)
-                body(a, std::min(count, a + chunk), t);
-        });
-    for (auto& x : th) x.join();
+    const int64_t chunk = 1024;
+    run_threads(nt, [&](int t) {
+        for (int64_t a = (int64_t)t * chunk; a < count; a += (int64_t)nt * chunk)
+            body(a, std::min(count, a + chunk), t);
+    });
 }
 
 void build_graph(Graph& g) {
@@ -180,11 +177,7 @@ void build_csr(int64_t n, int64_t m, const int32_t* ii, const int32_t* jj, hvec<
     // turned into per-chunk start offsets inside the lower / upper part of each row: the same slots as the
     // serial pass, whatever T is
     hvec<int32_t> lo((size_t)T * n, 0), up((size_t)T * n, 0), lowtot((size_t)n);
-    auto run = [&](auto&& body) {
-        hvec<std::thread> th;
-        for (int t = 0; t < T; ++t) th.emplace_back([=, &body]() { body(t, m * t / T, m * (t + 1) / T); });
-        for (auto& x : th) x.join();
-    };
+    auto run = [&](auto&& body) { run_threads(T, [&](int t) { body(t, m * t / T, m * (t + 1) / T); }); };
     run([&](int t, int64_t a, int64_t b) {
         int32_t* l = &lo[(size_t)t * n]; int32_t* u = &up[(size_t)t * n];
         for (int64_t e = a; e < b; ++e) { u[ii[e]]++; l[jj[e]]++; }

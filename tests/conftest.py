@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# every output buffer the ctypes layer hands to the library is fenced by guard words, verified after each native call
+# (desc_amd/_lib.py); must be set before desc_amd._lib is imported
+os.environ.setdefault("DESC_DEBUG_GUARD", "1")
 
 
 def pytest_configure(config):

@@ -1,0 +1,117 @@
+"""Test infrastructure: drives the host side of libdesc_amd (built against hipmock.cpp) through the call sequences of the GPU parity
+tests -- host structure builder, solver set-up with every layout forced (DESC_DEBUG_VARIANT 3/2/1), run + download into fenced
+caller buffers, device-resident problem, one-shot solve -- so that AddressSanitizer / UBSan / ThreadSanitizer see every host-side
+write.  Kernels do not run under the mock: values are not checked here, memory behaviour is.
+
+Run by tests/test_host_sanitizers.py in a subprocess with the sanitizer runtime preloaded."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+os.environ["DESC_DEBUG_GUARD"] = "1"
+os.environ["DESC_CACHE_MB"] = "0"        # every "device" block fresh from calloc: what a kernel would have produced reads back as zeros
+
+import numpy as np  # noqa: E402
+
+from desc_amd import _lib as lib  # noqa: E402
+from tests.helpers import c_params, make_problem  # noqa: E402
+
+VAR = {"band": "3", "node": "2", "gather": "1"}
+QUICK = os.environ.get("HOSTSAN_QUICK") == "1"
+
+
+def solve_once(nn, ii, jj, rij, p, variant, where, adam=False):
+    os.environ["DESC_DEBUG_VARIANT"] = VAR[variant]
+    try:
+        prob = lib.ProblemArrays(nn, ii, jj, rij)
+        st = lib.Structure.build(prob, 30, p.seed, where, 0)
+        arrays = st.arrays()
+        solver = lib.Solver(prob, st, 0)
+        solver.s0()
+        ad = (np.zeros(solver.m_cycle), np.zeros(solver.m_cycle)) if adam else None
+        solver.run(p, want_w=True, adam=ad)
+        solver.destroy(); st.free()
+    finally:
+        os.environ.pop("DESC_DEBUG_VARIANT", None)
+    return arrays
+
+
+def main():
+    L = lib.load()
+    assert hasattr(L, "hipmock_launch_count"), "this driver must run against the mock build"
+    cases = [(12, 0.6, 9), (60, 0.3, 2), (260, 0.5, 5)] if QUICK else [(12, 0.6, 9), (30, 0.5, 1), (60, 0.3, 2), (120, 0.6, 3), (200, 0.5, 4), (260, 0.5, 5)]
+    for n, p, seed in cases:                                     # tests/test_gpu_parity.py::test_uniform_constant_step
+        mo, nn, ii, jj, rij = make_problem("uniform", n=n, p=p, q=0.2, sigma=0.1, seed=seed)
+        ref = None
+        for variant in ("band", "node", "gather"):
+            a = solve_once(nn, ii, jj, rij, c_params(100, lr=0.01, seed=11), variant, lib.BUILD_HOST)
+            if ref is None:
+                ref = a
+            for k in ("pos_edge", "cum_ind", "k", "e_jk", "e_ki", "ikj", "jki"):
+                assert np.array_equal(a[k], ref[k]), k
+        # the generator must keep returning the same sorted edge list (gpurun_out/r2_tests3.log: it once did not)
+        mo2, nn2, ii2, jj2, rij2 = make_problem("uniform", n=n, p=p, q=0.2, sigma=0.1, seed=seed)
+        assert np.array_equal(ii, ii2) and np.array_equal(jj, jj2) and np.array_equal(rij, rij2)
+        print("ok uniform", n, flush=True)
+    mo, nn, ii, jj, rij = make_problem("nonuniform", n=150, p=0.4, seed=6, crpt_type="self-consistent")
+    for variant in ("band", "node", "gather"):
+        solve_once(nn, ii, jj, rij, c_params(60, lr=0.01, seed=2), variant, lib.BUILD_HOST)
+        for kind, hs in ((1, 0), (2, 0), (2, 1)):
+            pp = c_params(20, step_kind=kind, lr=0.01, seed=3, decay_interval=10, hybrid_strategy=hs)
+            solve_once(nn, ii, jj, rij, pp, variant, lib.BUILD_HOST, adam=(kind == 2 and hs == 0))
+    print("ok nonuniform + plugins", flush=True)
+    # long segments (> 64 cycles) and the multithreaded CSR / compaction passes (m >= 2^18)
+    mo, nn, ii, jj, rij = make_problem("uniform", n=310, p=0.95, q=0.2, sigma=0.1, seed=7)
+    for variant in ("band", "gather"):
+        solve_once(nn, ii, jj, rij, c_params(5, lr=0.01, seed=3), variant, lib.BUILD_HOST)
+    if not QUICK:
+        mo, nn, ii, jj, rij = make_problem("uniform", n=1200, p=0.45, q=0.2, sigma=0.1, seed=3)
+        for variant, where in (("band", lib.BUILD_HOST), ("node", lib.BUILD_DEVICE)):
+            solve_once(nn, ii, jj, rij, c_params(3, lr=0.01, seed=5), variant, where)
+        dp = lib.DeviceProblem(lib.ProblemArrays(nn, ii, jj, rij)); dp.free()
+    print("ok long segments / threads", flush=True)
+    # device-resident problem + one-shot solve + the next rows' host sides
+    mo, nn, ii, jj, rij = make_problem("uniform", n=90, p=0.5, q=0.2, sigma=0.1, seed=8)
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    dp = lib.DeviceProblem(prob)
+    st = lib.Structure.build(prob, 30, 1, lib.BUILD_DEVICE, 0)
+    s = lib.Solver(dp, st, 0); s.run(c_params(7, seed=1)); s.destroy(); st.free()
+    lib.solve(prob, c_params(9, seed=1))
+    lib.cemp_run(dp, [1.0, 2.0], 2, 20, seed=3)
+    dp.free()
+    # regression: a handle re-armed with a smaller budget must not be iterated past it (the device trace buffers keep the
+    # larger size, the caller's trace buffers have the smaller one: desc_pgd_download would write past them)
+    st = lib.Structure.build(prob, 30, 1, lib.BUILD_HOST, 0)
+    s = lib.Solver(prob, st, 0)
+    s.reset(c_params(100, seed=1)); s.iterate(100); s.download()
+    s.reset(c_params(5, seed=1)); s.iterate(5)
+    try:
+        s.iterate(1)
+    except lib.DescError as e:
+        assert e.code == lib.ERR_INVALID
+    else:
+        raise AssertionError("iterating past params.iters of the last reset must fail")
+    out = s.download(want_w=True)
+    assert out["iters_run"] == 5 and out["obj"].shape == (5,)
+    s.destroy(); st.free()
+    # shard planning of the multi-GPU path (host side: ranges, exchange layout), world 2 and 3
+    for where in (lib.BUILD_HOST,):          # (a device-built structure has no cycles under the mock: nothing to shard)
+        st = lib.Structure.build(prob, 30, 1, where, 0)
+        for world in (2, 3):
+            for rank in range(world):
+                s = lib.Solver(prob, st, 0, rank, world)
+                info = s.shard_info()
+                assert info.world == world and info.rank == rank
+                s.shard_bind(None, None, None)
+                s.reset(c_params(3, seed=1)); s.shard_finish(1); s.shard_colsum(); s.shard_sweep(); s.shard_finish(0)
+                s.destroy()
+        st.free()
+    lib.verify_guards()
+    lib.trim_memory()
+    assert L.hipmock_live_blocks() == 0, "device blocks leaked"
+    print("HOSTSAN OK launches", L.hipmock_launch_count(), flush=True)
+
+
+if __name__ == "__main__":
+    main()
