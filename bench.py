@@ -8,16 +8,18 @@ inconsistencies are already resident in HBM when the timed region starts.
 
     python bench.py --gpus N --steps K --warmup W [--workload C1..C5]
 
-Every N runs BASELINE.json configs[1] (C2: Uniform n=1000 p=0.5 q=0.3, sigma=0.1) -- strong
-scaling: the total work is fixed, at N > 1 the edges-with-cycles are sharded over the ranks with
-a reduce-scatter and an all-gather per iteration (desc_amd/sharded.py).  `value` is always C2; the
-line additionally carries `north_star_config`: the same measurement (iterations/s, roofline of the
-kernel pair, really timed end-to-end call) on C4 (configs[3], n=5000 p=0.2 -- the workload the
-north star's target is quoted on; it fits one GPU).
-Prints ONE JSON line (rank 0) with the contract's fields plus `roofline` (dominant
-kernel: the sweep, HBM-bound, algorithmic bytes 72*m_cycle + 12*m_pos per launch,
-SURVEY.md 8d) and `cpu_baseline` (the oracle's OpenMP C restatement timed on this
-host for a bounded number of iterations of the same workload).
+`value` is BASELINE.json configs[3] (C4: Uniform n=5000 p=0.2 q=0.3 sigma=0.1 -- the workload the north star's
+target is quoted on; 4 GB, fits one GPU) at every N: strong scaling, the total work is fixed, at N > 1 the
+edges-with-cycles are sharded over the ranks with a reduce-scatter and an all-gather per iteration
+(desc_amd/sharded.py).  The default line additionally carries `secondary_config`: the same measurement on C2
+(configs[1], n=1000 p=0.5).
+
+`--gpus N` without WORLD_SIZE in the environment starts the N ranks itself (one child process per GPU, before
+anything in this process touches a GPU); under `python -m torch.distributed.run` the ranks are already there.
+Rank 0 prints ONE JSON line with the contract's fields plus `roofline` (dominant kernels: column sums + sweep,
+HBM-bound, algorithmic bytes 72*m_cycle + 12*m_pos per iteration), `cpu_baseline` (the oracle's
+OpenMP C restatement timed on this host for a bounded number of iterations of the same workload; rank 0, N = 1
+only) and, at N > 1, `rccl_ranks` (ncclCommCount of the communicator the collectives ran on).
 """
 from __future__ import annotations
 
@@ -133,7 +135,7 @@ def load_traffic(name):
     """HBM bytes per iteration from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the
     bench): FETCH_SIZE and WRITE_SIZE collected in separate runs, corrected as MI355X_MICROARCH.md prescribes
     (tools/pmc_traffic.py); null for workloads that have not been profiled."""
-    for fn in ("r02_traffic.json", "r01_traffic.json"):
+    for fn in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
                 t = json.load(f).get(name, {}).get("per_iteration_bytes")
@@ -229,6 +231,57 @@ def measure(lib, name, K, W, seed, convergence, keep_arrays, n_sample_min=30):
     return res
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def spawn_ranks(args, argv):
+    """`bench.py --gpus N` started as ONE process: start N ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, one GPU each), before anything in this process has touched a GPU; rank 0 prints the
+    JSON line.  Non-zero exit if any rank fails (the others are stopped by PID)."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(args.gpus):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv,
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r))))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for q in list(pending):
+            code = q.poll()
+            if code is None:
+                continue
+            pending.remove(q)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in pending:              # a rank died: the rest would wait in a collective for ever
+                    other.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def dry_launch(args):
+    """Launch rehearsal without a GPU (tests): the ranks meet over gloo, count themselves, rank 0 prints what it saw."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(t)
+    seen = int(t.item())
+    ok = seen == args.gpus == world
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_counted": seen, "requested": args.gpus, "ok": ok}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,19 +290,27 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence", action="store_true", help="skip the run to the patience exit (profiling: keeps the kernel statistics to the timed sweeps)")
-    ap.add_argument("--no-north-star", action="store_true", help="skip the extra C4 measurement of the default run")
+    ap.add_argument("--no-secondary", "--no-north-star", dest="no_secondary", action="store_true", help="skip the extra C2 measurement of the default run")
     ap.add_argument("--seed", type=int, default=0, help="cycle-sampling seed")
     ap.add_argument("--full", action="store_true", help="no cycle sampling: n_sample_min above every codegree, all triangles swept "
                     "(BASELINE configs[4]: ~1.7e8 triangles = 5e8 edge-cycle slots at C5)")
+    ap.add_argument("--dry-launch", action="store_true", help="start the ranks, let them count themselves over gloo, touch no GPU (launch test)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, sys.argv[1:])             # nothing above or in here initialises a GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1 or os.environ.get("DESC_FORCE_SHARDED") == "1":   # the env switch rehearses the N>1 code path on one GPU
+    if args.dry_launch:
+        return dry_launch(args)
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong rank count", file=sys.stderr)
+        return 2
+    if world > 1 or os.environ.get("DESC_FORCE_SHARDED") == "1":   # the env switch rehearses the N>1 code path on one GPU
         from desc_amd.sharded import bench_sharded
         return bench_sharded(args, WORKLOADS, describe, generate, cpu_baseline)
 
     from desc_amd import _lib
-    name = args.workload or "C2"
+    name = args.workload or "C4"
     K, W = args.steps, args.warmup
     warm_up(_lib)
     nsm = (1 << 16) if args.full else 30
@@ -270,31 +331,37 @@ def main():
         "to_patience_exit_lr1": r["conv"],
         "mean_abs_err_vs_truth": r["err"],
     }
-    if args.workload is None and not args.no_north_star:
-        # the workload the north star's target is quoted on (BASELINE configs[3], fits one GPU: 4 GB): same
-        # measurement, its own roofline; `value` stays C2 (the configuration the metric line is defined on)
-        x = measure(_lib, "C4", K, W, args.seed, False, False)
-        line["north_star_config"] = {
-            "workload": describe("C4"), "value": K / x["dt"], "unit": "iters/s", "steps": K, "warmup": W, "ms_per_step": x["dt"] / K * 1e3,
-            "m_cycle": x["m_cycle"], "m_pos": x["m_pos"], "n_sample": x["n_sample"], "roofline": x["roofline"],
-            "setup_ms": x["setup_ms"], "end_to_end": x["end_to_end"], "mean_abs_err_vs_truth": x["err"]}
     if not args.no_cpu_baseline:
-        cb, ref, it = cpu_baseline(r["nn"], r["ii"], r["jj"], r["rij"], r["arrays"])
+        # the oracle's C/OpenMP port on the same workload, a bounded number of iterations (C4: ~0.5 s each on 16 threads)
+        cb, ref, it = cpu_baseline(r["nn"], r["ii"], r["jj"], r["rij"], r["arrays"], budget_s=12.0, max_iters=10 if name in ("C4", "C5") else 50)
         line["cpu_baseline"] = cb
         line["gpu_over_cpu"] = line["value"] / cb["value"]
-        # SURVEY.md 8d's other two data points (reported, never the target): the same port on one thread, and
-        # the interpreted literal restatement on C1
-        one, _, _ = cpu_baseline(r["nn"], r["ii"], r["jj"], r["rij"], r["arrays"], budget_s=8.0, max_iters=10, threads=1)
-        variants = {"port_single_thread": one}
-        try:
-            variants["literal_numpy_C1"] = literal_baseline()
-        except Exception as e:            # the literal restatement is test infrastructure: never fail the bench on it
-            variants["literal_numpy_C1"] = {"error": repr(e)}
-        line["cpu_baseline_variants"] = variants
+        r["arrays"] = None
     else:
         line["cpu_baseline"] = None
+    if args.workload is None and not args.no_secondary:
+        # BASELINE configs[1] (C2, n=1000 p=0.5): same measurement, its own roofline and CPU data points
+        x = measure(_lib, "C2", K, W, args.seed, not args.no_convergence, not args.no_cpu_baseline)
+        sec = {"workload": describe("C2"), "value": K / x["dt"], "unit": "iters/s", "steps": K, "warmup": W, "ms_per_step": x["dt"] / K * 1e3,
+               "m_cycle": x["m_cycle"], "m_pos": x["m_pos"], "n_sample": x["n_sample"], "roofline": x["roofline"],
+               "setup_ms": x["setup_ms"], "end_to_end": x["end_to_end"], "to_patience_exit_lr1": x["conv"], "mean_abs_err_vs_truth": x["err"]}
+        if not args.no_cpu_baseline:
+            cb2, _, _ = cpu_baseline(x["nn"], x["ii"], x["jj"], x["rij"], x["arrays"], budget_s=6.0, max_iters=50)
+            sec["cpu_baseline"] = cb2
+            sec["gpu_over_cpu"] = sec["value"] / cb2["value"]
+            # SURVEY.md 8d's other two data points (reported, never the target): the same port on one thread, and
+            # the interpreted literal restatement on C1
+            one, _, _ = cpu_baseline(x["nn"], x["ii"], x["jj"], x["rij"], x["arrays"], budget_s=5.0, max_iters=6, threads=1)
+            variants = {"port_single_thread_C2": one}
+            try:
+                variants["literal_numpy_C1"] = literal_baseline()
+            except Exception as e:            # the literal restatement is test infrastructure: never fail the bench on it
+                variants["literal_numpy_C1"] = {"error": repr(e)}
+            line["cpu_baseline_variants"] = variants
+        line["secondary_config"] = sec
     print(json.dumps(line))
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -190,38 +190,71 @@ class ShardedDriver:
 
 class RcclComm:
     """RCCL communicator created next to torch's own, for the fused C protocol.  Uses the librccl.so that ships
-    with PyTorch -- the copy torch.distributed's "nccl" backend has already mapped (one ROCm runtime per process)."""
+    with PyTorch -- the copy torch.distributed's "nccl" backend has already mapped (one ROCm runtime per process).
+
+    Creation is agreed on by all ranks step by step (library load, unique id, ncclCommInitRank), each step followed by a
+    MIN-reduction of a success flag over torch.distributed, so that no rank walks into the collective ncclCommInitRank
+    while another has already given up; `ok` tells the caller whether every rank holds a communicator."""
 
     def __init__(self, rank, world, device):
         import torch
         import torch.distributed as dist
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        self.lib = C.CDLL(path)
+        self.comm = C.c_void_p()
+        self.ok = False
+        self.count = 0
 
         class UniqueId(C.Structure):
             _fields_ = [("internal", C.c_char * 128)]
 
+        def all_ok(flag):
+            if world == 1:
+                return bool(flag)
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=torch.device("cuda", device))
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+
+        # 1. the library and its entry points
+        try:
+            self.lib = L = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+            L.ncclGetUniqueId.restype = C.c_int; L.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+            L.ncclCommInitRank.restype = C.c_int; L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+            L.ncclCommCount.restype = C.c_int; L.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+            L.ncclCommDestroy.restype = C.c_int; L.ncclCommDestroy.argtypes = [C.c_void_p]
+            self.reduce_scatter, self.all_gather = L.ncclReduceScatter, L.ncclAllGather
+            loaded = True
+        except (OSError, AttributeError) as e:
+            self.error = repr(e); loaded = False
+        if not all_ok(loaded):
+            self.error = getattr(self, "error", "another rank could not load librccl.so")
+            return
+        # 2. rank 0's unique id reaches everybody (None if rank 0 could not make one)
         uid = UniqueId()
+        box = [None]
         if rank == 0:
-            rc = self.lib.ncclGetUniqueId(C.byref(uid))
-            if rc:
-                raise _lib.DescError(f"ncclGetUniqueId failed: {rc}")
-        box = [bytes(C.string_at(C.byref(uid), 128))]
+            rc = L.ncclGetUniqueId(C.byref(uid))
+            box = [bytes(C.string_at(C.byref(uid), 128)) if rc == 0 else None]
         if world > 1:
             dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            self.error = "ncclGetUniqueId failed on rank 0"
+            return
         C.memmove(C.byref(uid), box[0], 128)
+        # 3. the collective initialisation, then agreement on its outcome
         torch.cuda.set_device(device)
-        self.comm = C.c_void_p()
-        self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-        rc = self.lib.ncclCommInitRank(C.byref(self.comm), world, uid, rank)
-        if rc:
-            raise _lib.DescError(f"ncclCommInitRank failed: {rc}")
-        self.reduce_scatter = self.lib.ncclReduceScatter
-        self.all_gather = self.lib.ncclAllGather
+        rc = L.ncclCommInitRank(C.byref(self.comm), world, uid, rank)
+        good = rc == 0 and bool(self.comm)
+        cnt = C.c_int(0)
+        if good and L.ncclCommCount(self.comm, C.byref(cnt)) == 0:
+            self.count = int(cnt.value)
+        good = good and self.count == world
+        if not all_ok(good):
+            self.error = f"ncclCommInitRank rc={rc}, ncclCommCount={self.count} (world {world}) on this or another rank"
+            self.destroy()
+            return
+        self.ok = True
 
     def destroy(self):
         if self.comm:
-            self.lib.ncclCommDestroy.argtypes = [C.c_void_p]
             self.lib.ncclCommDestroy(self.comm)
             self.comm = C.c_void_p()
 
@@ -375,32 +408,32 @@ def _bench_one(name, args, rank, world, device, comm, describe, generate, native
 
 
 def bench_sharded(args, WORKLOADS, describe, generate, cpu_baseline):
-    """bench.py body for --gpus N > 1 (launched by torch.distributed.run, one rank per GPU).
+    """bench.py body for N > 1 ranks (started by bench.py itself or by torch.distributed.run, one rank per GPU).
 
-    The bench line is the same workload as at N = 1 (C2, strong scaling: total work fixed, edges
-    sharded over the ranks, reduce-scatter + all-gather per iteration).  C2 is small enough that one
-    GPU is about as fast as any sharding; the line therefore also carries
-    `north_star_config`: the same measurement on C4 (BASELINE.json configs[3], n = 5000)."""
+    Same workload as at N = 1 (C4, BASELINE.json configs[3]; strong scaling: total work fixed, edges sharded over the
+    ranks, reduce-scatter + all-gather per iteration); the default line also carries `secondary_config` = C2, which is
+    small enough that one GPU is about as fast as any sharding."""
     import torch                                         # before libdesc_amd.so: see _lib.load()
     rank, world, device = init_distributed()
     comm = TorchComm()
     K, W = args.steps, args.warmup
-    name = args.workload or "C2"
+    name = args.workload or "C4"
     native = None
+    rccl_ranks, rccl_source = None, None
     if os.environ.get("DESC_SHARD_DRIVER", "native") == "native" and not comm.staged:
-        try:
-            native = RcclComm(rank, world, device)
-        except Exception as e:             # all ranks fail alike (same library, same call): fall back together
+        native = RcclComm(rank, world, device)
+        if not native.ok:
             if rank == 0:
-                print(f"[desc_amd] native RCCL communicator unavailable ({e!r}); using the piecewise torch.distributed driver", file=sys.stderr, flush=True)
+                print(f"[desc_amd] native RCCL communicator unavailable ({native.error}); using the piecewise torch.distributed driver", file=sys.stderr, flush=True)
             native = None
-        ok = comm.max_float(0.0 if native is not None else 1.0)      # any rank without it -> nobody uses it
-        if ok > 0 and native is not None:
-            native.destroy(); native = None
+        else:
+            rccl_ranks, rccl_source = native.count, "ncclCommCount of the communicator the library's collectives run on"
+    if native is None and not comm.staged:
+        rccl_ranks, rccl_source = comm.world, "torch.distributed world size (backend nccl = RCCL)"
     r = _bench_one(name, args, rank, world, device, comm, describe, generate, native)
     extra = None
-    if args.workload is None:
-        x = _bench_one("C4", args, rank, world, device, comm, describe, generate, native)
+    if args.workload is None and not getattr(args, "no_secondary", False):
+        x = _bench_one("C2", args, rank, world, device, comm, describe, generate, native)
         xb = 72.0 * x["m_cycle"] + 12.0 * x["m_pos"]
         extra = {"workload": x["workload"], "value": K / x["dt"], "unit": "iters/s", "ms_per_step": x["dt"] / K * 1e3,
                  "m_cycle": x["m_cycle"], "roofline_frac_of_aggregate_hbm": xb / (x["dt"] / K) / 1e9 / (8000.0 * world),
@@ -412,6 +445,7 @@ def bench_sharded(args, WORKLOADS, describe, generate, cpu_baseline):
         "metric": "DESC_PGD iters/sec", "value": K / dt, "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
+        "rccl_ranks": rccl_ranks, "rccl_ranks_source": rccl_source,
         "config": {"workload": r["workload"], "n": r["nn"], "m": r["m"], "m_pos": r["m_pos"], "m_cycle": r["m_cycle"],
                    "n_sample": r["n_sample"], "sampling_seed": args.seed,
                    "parallelism": f"edges sharded over {world} GPUs; reduce-scatter of the mirror sums (2 m_pos f64) + all-gather S per iteration; " + r["driver"]},
@@ -422,10 +456,13 @@ def bench_sharded(args, WORKLOADS, describe, generate, cpu_baseline):
         "cpu_baseline": None,
         "setup_ms": {"structure": r["t_struct"] * 1e3, "create_shard": r["t_create"] * 1e3},
         "mean_abs_err_vs_truth": r["err"],
-        "north_star_config": extra,
+        "secondary_config": extra,
     }
     if rank == 0:
         print(json.dumps(line), flush=True)
     import torch.distributed as dist
     dist.barrier()
+    if native is not None:
+        native.destroy()
     dist.destroy_process_group()
+    return 0

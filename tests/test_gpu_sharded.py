@@ -162,6 +162,7 @@ def test_fused_protocol_one_rank(lib, oracle, case, monkeypatch):
         if mode == "rccl":
             monkeypatch.setenv("DESC_DEBUG_FORCE_COLLECTIVES", "1")
             comm = RcclComm(0, 1, 0)
+            assert comm.ok and comm.count == 1          # ncclCommCount of the communicator the library will call into
         shard = NativeShard(prob, hst, 0, 0, 1, comm)
         hst.free()
         out = shard.run(c_params(cfg["iters"], seed=9, check_every=7, **cfg["kw"]))

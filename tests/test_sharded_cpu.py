@@ -71,3 +71,26 @@ def test_sharded_protocol_gloo(oracle, world, case):
     # every rank returns bitwise the same answer (scalars are added in rank order everywhere)
     for r in res[1:]:
         assert np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2])
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` as ONE process (no WORLD_SIZE in the environment) must start two ranks itself; --dry-launch
+    lets them meet over gloo and count themselves without touching a GPU.  A mismatch between --gpus and the ranks that
+    actually exist is an error, not an `n_gpus: 1` line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], env=env, cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # exactly one JSON line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_counted"] == 2 and rec["ok"] is True
+    # launched with the wrong number of ranks (torchrun-style environment of ONE rank, --gpus 2): refuses
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
