@@ -63,6 +63,8 @@ struct DevState {
     int32_t final_parity;  // which double buffer holds the final iterate
     int32_t last_tested;   // last iteration whose stop test (:243-256) has been applied: a download between
                            // iterations evaluates the objective early, the next sweep must not count it again
+    int32_t next_fin;      // sweep whose bookkeeping the next column-sum launch has to do (0: none).  Kept by the device so that a
+                           // captured hipGraph of several iterations can be replayed: its launches carry no iteration number
 };
 
 struct StepArgs {
@@ -369,6 +371,7 @@ constexpr int SWEEP_THREADS = 512;
 constexpr int CHUNK_LDS = 960;             // entries of the LDS image of a chunk: one 16-byte vector of w per thread
 constexpr int CHUNK_CAP = CHUNK_LDS - 4;   // cycles per chunk: the image starts up to 3 entries before the chunk (16-byte alignment)
 constexpr int MAX_SEG_CYCLES = 256;         // longest segment the node layout takes (64 lanes x 4 cycles)
+constexpr int64_t GRAPH_MAX_CYCLES = 40000000;   // graph replays (enqueue_iterations) for graphs up to this many cycles: beyond it two launch gaps per iteration are noise
 
 // first / end cycle and first / end segment of a chunk, one 16-byte scalar load
 struct alignas(16) ChunkDesc { int32_t c0, c1, l0, l1; };
@@ -936,8 +939,20 @@ struct FinArgs {
     const double* partials; DevState* st; double* obj_trace; double* avg_trace;
     int64_t m; double stop_tol; int32_t nparts, t, patience, last_only;      // t == 0: nothing to do
     int64_t rank_stride; int32_t nranks;     // sharded runs: the partials of rank r start at partials + r * rank_stride (0 / 0: one rank)
+    int32_t t_after;                         // > 0: DevState.next_fin after this call (the sweep that follows this column-sum launch); < 0: 0 (done, nothing pending)
+    int32_t dev_t;                           // 1: t comes from DevState.next_fin, which then advances by one (hipGraph replays)
 };
-__device__ __forceinline__ void finalize_wave(const FinArgs f) {
+__device__ __forceinline__ void finalize_core(const FinArgs f);
+__device__ __forceinline__ void finalize_wave(FinArgs f) {
+    DevState* st = f.st;
+    if (f.dev_t) f.t = st->next_fin;                       // every lane reads the same value; written below by lane 0 only
+    if (f.t > 0) finalize_core(f);
+    if ((threadIdx.x & 63) == 0) {
+        if (f.dev_t) st->next_fin = f.t + 1;
+        else if (f.t_after != 0) st->next_fin = max(f.t_after, 0);
+    }
+}
+__device__ __forceinline__ void finalize_core(const FinArgs f) {
     DevState* st = f.st;
     if (st->stop) return;
     const int lane = threadIdx.x & 63;
@@ -988,7 +1003,7 @@ constexpr int COLSUM_U = 8;
 __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, const int2* adj_seg, const uint32_t* moff, const uint16_t* midx, const double* w,
                                                      double* Tfull, int n, int stride_cols, const DevState* st, const int32_t* xpos, FinArgs fin) {
     if (blockIdx.x == gridDim.x - 1) {
-        if (fin.t > 0 && threadIdx.x < 64) finalize_wave(fin);
+        if (threadIdx.x < 64 && fin.st) finalize_wave(fin);
         return;
     }
     if (st->stop) return;
@@ -1458,6 +1473,13 @@ struct desc_pgd {
     double ms_upload = 0, ms_cycle_d = 0, ms_pgd = 0;
     int ablate = 0;             // diagnostics (DESC_DEBUG_ABLATE)
     std::string kname;
+    // GRAPH_ITERS iterations (column sums + sweep each) captured once per reset as a hipGraph and replayed: the launches of a
+    // replay carry no iteration number (DevState.next_fin), so one executable graph serves the whole run.  Constant step only.
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    bool graph_failed = false;
+    int graph_launches = 0;
+    struct GraphSig { double lr, stop_tol; int patience, grid; const void *partials, *obj, *avg; } graph_sig{};     // what the captured launches bake
 };
 
 namespace {
@@ -1484,6 +1506,8 @@ void free_all(desc_pgd* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     for (void* q : h->allocs) dev_free(q);
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
     for (hipEvent_t e : {h->ev_col, h->ev_rs, h->ev_sw, h->ev_done}) if (e) (void)hipEventDestroy(e);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     if (h->stream && !h->borrowed_stream) (void)hipStreamDestroy(h->stream);
@@ -1623,25 +1647,30 @@ void launch_sweep_node_layout(desc_pgd* h, const NodeSweepArgs& a, bool adam) {
 int sweep_parts(const desc_pgd* h, bool adam) { return h->variant == VARIANT_NODE && (adam ? band_adam_ok(h) : h->band_ok) ? h->band_grid : h->grid; }
 
 FinArgs fin_args(const desc_pgd* h, const double* partials, int nparts, int t, int last_only) {
-    return FinArgs{partials, h->d_state, h->d_obj, h->d_avg, h->m, h->p.stop_tol, nparts, t, h->p.patience, last_only, 0, 1};
+    return FinArgs{partials, h->d_state, h->d_obj, h->d_avg, h->m, h->p.stop_tol, nparts, t, h->p.patience, last_only, 0, 1, 0, 0};
 }
 // the bookkeeping of the last enqueued sweep, if it is still waiting for a column-sum launch to ride on
 void flush_finalize(desc_pgd* h) {
     if (!h->pending_fin) return;
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, fin_args(h, h->d_partials, h->pending_parts, h->pending_fin, 0));
+    FinArgs fin = fin_args(h, h->d_partials, h->pending_parts, h->pending_fin, 0);
+    fin.t_after = -1;                   // booked: a replayed column-sum launch must not do it again (the partials may be overwritten by then)
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, fin);
     h->pending_fin = 0;
 }
 
 // enqueue sweep number t (1-based) and its finalize; ev0/ev1 bracket the kernels of the sweep proper
-int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool captured = false) {
     const int rd = (t - 1) & 1, wr = t & 1;
     bool adam = false;
     const StepArgs st = make_step(h, &adam, rd, wr);
     if (ev0) (void)hipEventRecord(ev0, h->stream);
     if (h->variant == VARIANT_NODE) {
+        FinArgs fin = fin_args(h, h->d_partials, captured ? sweep_parts(h, adam) : h->pending_parts, h->pending_fin, 0);
+        if (captured) { fin.t = 0; fin.dev_t = 1; }          // which sweep to book-keep: DevState.next_fin, at replay time
+        else fin.t_after = t;                                // the next column-sum launch (direct or replayed) book-keeps sweep t
         hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int)), h->stream,
                            h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, h->d_w[rd], h->d_T, (int)h->n,
-                           h->colsum_stride, h->d_state, (const int32_t*)nullptr, fin_args(h, h->d_partials, h->pending_parts, h->pending_fin, 0));
+                           h->colsum_stride, h->d_state, (const int32_t*)nullptr, fin);
         h->pending_fin = 0;
         NodeSweepArgs a{};
         a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
@@ -1660,6 +1689,62 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
     h->pending_fin = t; h->pending_parts = sweep_parts(h, adam);
     if (h->variant != VARIANT_NODE) flush_finalize(h);         // no column-sum launch to ride on
     DESC_HIP(hipGetLastError());
+    return DESC_OK;
+}
+
+// GRAPH_ITERS iterations as one executable hipGraph (captured from the launch stream), or nullptr when the run does not qualify:
+// the launches inside must not depend on the iteration number, i.e. the constant step (ConstantStepSize.m), the node layout, one rank.
+constexpr int GRAPH_ITERS = 10;
+bool graph_eligible(const desc_pgd* h) {
+    const int mode = env_int("DESC_GRAPH", 1);                 // diagnostics: 0 never, 2 whatever the size
+    return mode != 0 && !h->graph_failed && h->variant == VARIANT_NODE && h->world == 1 && h->p.step_kind == DESC_STEP_CONSTANT && h->ablate == 0 &&
+           (mode == 2 || h->m_cycle <= GRAPH_MAX_CYCLES);
+}
+void drop_graph(desc_pgd* h) {
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    h->graph_exec = nullptr; h->graph = nullptr;
+}
+hipGraphExec_t iteration_graph(desc_pgd* h) {
+    const desc_pgd::GraphSig sig{h->p.lr, h->p.stop_tol, h->p.patience, sweep_parts(h, false), h->d_partials, h->d_obj, h->d_avg};
+    if (h->graph_exec && std::memcmp(&sig, &h->graph_sig, sizeof sig) == 0) return h->graph_exec;
+    drop_graph(h);
+    std::memset(&h->graph_sig, 0, sizeof h->graph_sig);
+    h->graph_sig = sig;
+    const int t_plugin = h->t_plugin, pf = h->pending_fin, pp = h->pending_parts;
+    if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); h->graph_failed = true; return nullptr; }
+    int rc = DESC_OK;
+    for (int k = 1; k <= GRAPH_ITERS && rc == DESC_OK; ++k) rc = enqueue_sweep(h, k, nullptr, nullptr, true);       // k: parity only (first sweep reads buffer 0)
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(h->stream, &g);
+    h->t_plugin = t_plugin; h->pending_fin = pf; h->pending_parts = pp;                                              // nothing was enqueued
+    if (rc != DESC_OK || e != hipSuccess || !g || hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (g) (void)hipGraphDestroy(g);
+        h->graph_exec = nullptr; h->graph_failed = true;
+        return nullptr;
+    }
+    h->graph = g;
+    return h->graph_exec;
+}
+// the next n sweeps: replays of the captured graph where a whole block of GRAPH_ITERS fits and the next sweep reads buffer 0,
+// direct launches otherwise
+int enqueue_iterations(desc_pgd* h, int n) {
+    while (n > 0) {
+        const int t = h->t_done + 1;
+        if (n >= GRAPH_ITERS && ((t - 1) & 1) == 0 && graph_eligible(h)) {
+            hipGraphExec_t ge = iteration_graph(h);
+            if (ge) {
+                DESC_HIP(hipGraphLaunch(ge, h->stream));
+                h->t_done += GRAPH_ITERS; h->t_plugin += GRAPH_ITERS; n -= GRAPH_ITERS;
+                h->pending_fin = h->t_done; h->pending_parts = sweep_parts(h, false);
+                ++h->graph_launches;
+                continue;
+            }
+        }
+        const int rc = enqueue_sweep(h, ++h->t_done); if (rc) return rc;
+        --n;
+    }
     return DESC_OK;
 }
 
@@ -2393,6 +2478,7 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
         }
     }
     h->t_done = 0; h->t_plugin = p->t0; h->ms_pgd = 0; h->objective_done = false; h->final_obj_T = -1; h->pending_fin = 0;
+
     const int cap = std::max(1, p->iters);
     h->iters_cap = cap;
     if (cap > h->trace_cap) {
@@ -2440,8 +2526,7 @@ int desc_pgd_iterate(desc_pgd* h, int32_t n_iters) {
     if (n_iters < 0 || h->t_done + n_iters > h->iters_cap) return fail(DESC_ERR_INVALID, "iterating past params.iters = %d", h->p.iters);
     int rc = set_device(h); if (rc) return rc;
     if (h->m_pos == 0) { h->t_done += n_iters; h->t_plugin += n_iters; return DESC_OK; }
-    for (int q = 0; q < n_iters; ++q) { rc = enqueue_sweep(h, ++h->t_done); if (rc) return rc; }
-    return DESC_OK;
+    return enqueue_iterations(h, n_iters);
 }
 
 int desc_pgd_iterate_timed(desc_pgd* h, int32_t n_iters, float* ms_total, float* ms_main_kernel_avg) {
@@ -2454,9 +2539,10 @@ int desc_pgd_iterate_timed(desc_pgd* h, int32_t n_iters, float* ms_total, float*
     hvec<hipEvent_t> ev;
     if (ms_main_kernel_avg) { ev.resize(2 * (size_t)n_iters); for (auto& e : ev) DESC_HIP(hipEventCreate(&e)); }
     DESC_HIP(hipEventRecord(e0, h->stream));
-    if (h->m_pos > 0)
+    if (h->m_pos > 0 && !ms_main_kernel_avg) { rc = enqueue_iterations(h, n_iters); if (rc) return rc; }
+    else if (h->m_pos > 0)                                   // per-iteration events: direct launches
         for (int q = 0; q < n_iters; ++q) {
-            rc = enqueue_sweep(h, ++h->t_done, ms_main_kernel_avg ? ev[2 * q] : nullptr, ms_main_kernel_avg ? ev[2 * q + 1] : nullptr);
+            rc = enqueue_sweep(h, ++h->t_done, ev[2 * q], ev[2 * q + 1]);
             if (rc) return rc;
         }
     else { h->t_done += n_iters; h->t_plugin += n_iters; }

@@ -88,7 +88,13 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 1.0f; 
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 2; return hipSuccess; }
 hipError_t hipLaunchKernel(const void*, dim3, dim3, void**, size_t, hipStream_t) { ++g_launches; return hipSuccess; }
+// stream capture: kernels are no-ops here anyway, so a captured graph is a token
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipSuccess; }
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = (hipGraph_t)std::malloc(8); return hipSuccess; }
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t, hipGraphNode_t*, char*, size_t) { *e = (hipGraphExec_t)std::malloc(8); return hipSuccess; }
 hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { ++g_launches; return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t e) { std::free((void*)e); return hipSuccess; }
+hipError_t hipGraphDestroy(hipGraph_t g) { std::free((void*)g); return hipSuccess; }
 
 // what the host stubs and the module constructor of a --offload-host-only object call
 hipError_t __hipPushCallConfiguration(dim3 grid, dim3 block, size_t shmem, hipStream_t stream) { g_cfg = {grid, block, shmem, stream}; return hipSuccess; }
