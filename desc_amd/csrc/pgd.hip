@@ -1646,15 +1646,17 @@ void launch_sweep_node_layout(desc_pgd* h, const NodeSweepArgs& a, bool adam) {
 // workgroups (= partial pairs) of the sweep kernel that serves this step kind
 int sweep_parts(const desc_pgd* h, bool adam) { return h->variant == VARIANT_NODE && (adam ? band_adam_ok(h) : h->band_ok) ? h->band_grid : h->grid; }
 
+// second half of d_partials: the objective kernel of a download writes there, so the partials of the last sweep stay intact and
+// book-keeping that sweep again (a replayed column-sum launch after a flush or a download) rewrites the same numbers
+double* obj_partials(const desc_pgd* h) { return h->d_partials + 2 * (size_t)std::max(std::max(h->grid, h->obj_grid), h->band_grid); }
 FinArgs fin_args(const desc_pgd* h, const double* partials, int nparts, int t, int last_only) {
     return FinArgs{partials, h->d_state, h->d_obj, h->d_avg, h->m, h->p.stop_tol, nparts, t, h->p.patience, last_only, 0, 1, 0, 0};
 }
 // the bookkeeping of the last enqueued sweep, if it is still waiting for a column-sum launch to ride on
 void flush_finalize(desc_pgd* h) {
     if (!h->pending_fin) return;
-    FinArgs fin = fin_args(h, h->d_partials, h->pending_parts, h->pending_fin, 0);
-    fin.t_after = -1;                   // booked: a replayed column-sum launch must not do it again (the partials may be overwritten by then)
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, fin);
+    // (DevState.next_fin stays: a replayed column-sum launch books the same sweep again from the same partials -- idempotent)
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, fin_args(h, h->d_partials, h->pending_parts, h->pending_fin, 0));
     h->pending_fin = 0;
 }
 
@@ -1696,7 +1698,10 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
 // the launches inside must not depend on the iteration number, i.e. the constant step (ConstantStepSize.m), the node layout, one rank.
 constexpr int GRAPH_ITERS = 10;
 bool graph_eligible(const desc_pgd* h) {
-    const int mode = env_int("DESC_GRAPH", 1);                 // diagnostics: 0 never, 2 whatever the size
+    // Off by default: measured on MI355X / ROCm 7.2 (profiles/r03_graph_ab.txt) the replays change nothing -- C1 16.5 vs 16.6 us per
+    // iteration, C2 0.150 vs 0.152 ms: the two launches of an iteration were not what a small graph waits for (each kernel is a chain
+    // of 4-6 dependent memory round trips).  DESC_GRAPH=1 enables it up to GRAPH_MAX_CYCLES, 2 for every size (tests).
+    const int mode = env_int("DESC_GRAPH", 0);
     return mode != 0 && !h->graph_failed && h->variant == VARIANT_NODE && h->world == 1 && h->p.step_kind == DESC_STEP_CONSTANT && h->ablate == 0 &&
            (mode == 2 || h->m_cycle <= GRAPH_MAX_CYCLES);
 }
@@ -2433,7 +2438,7 @@ static int create_impl(const desc_problem* prob, const double* shared_rij, const
         if (!rc) { hipError_t e = hipStreamSynchronize(h->stream); if (e != hipSuccess) rc = fail(DESC_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
     }
     if (!rc) rc = (h->variant == VARIANT_NODE) ? setup_node(h, prob, s, shared_rij) : setup_gather(h, prob, s, shared_rij);
-    if (!rc) rc = dalloc(h, &h->d_partials, 2 * (size_t)std::max(std::max(h->grid, h->obj_grid), h->band_grid));
+    if (!rc) rc = dalloc(h, &h->d_partials, 4 * (size_t)std::max(std::max(h->grid, h->obj_grid), h->band_grid));   // sweep partials, then the objective kernel's
     if (rc) { free_all(h); return rc; }
     *out = h;
     return DESC_OK;
@@ -2474,7 +2479,7 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
         if (gr >= 8 && gr / 8 * 8 != h->grid) {
             dfree(h, h->d_partials); h->d_partials = nullptr;
             h->grid = gr / 8 * 8;
-            rc = dalloc(h, &h->d_partials, 2 * (size_t)std::max(std::max(h->grid, h->obj_grid), h->band_grid)); if (rc) return rc;
+            rc = dalloc(h, &h->d_partials, 4 * (size_t)std::max(std::max(h->grid, h->obj_grid), h->band_grid)); if (rc) return rc;
         }
     }
     h->t_done = 0; h->t_plugin = p->t0; h->ms_pgd = 0; h->objective_done = false; h->final_obj_T = -1; h->pending_fin = 0;
@@ -2584,11 +2589,11 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
         h->final_obj_T = T;
         if (h->variant == VARIANT_NODE)
             hipLaunchKernelGGL(k_objective_node, dim3(h->obj_grid), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_einfo + h->seg_lo, h->d_pk,
-                               h->d_w[T & 1], h->d_S[T & 1], (int)(h->seg_hi - h->seg_lo), h->d_partials, h->d_state);
+                               h->d_w[T & 1], h->d_S[T & 1], (int)(h->seg_hi - h->seg_lo), obj_partials(h), h->d_state);
         else
             hipLaunchKernelGGL(k_objective, dim3(h->obj_grid), dim3(256), 0, h->stream, h->d_w[T & 1], h->d_S[T & 1], h->d_ejk,
-                               h->d_eki, h->m_cycle, h->d_partials, h->d_state);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, fin_args(h, h->d_partials, h->obj_grid, T, 1));
+                               h->d_eki, h->m_cycle, obj_partials(h), h->d_state);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, fin_args(h, obj_partials(h), h->obj_grid, T, 1));
     }
     DevState st{};
     DESC_HIP(hipStreamSynchronize(h->stream));

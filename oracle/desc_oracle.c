@@ -400,3 +400,77 @@ int oracle_pgd_run(int64_t m, int64_t m_pos, const int32_t* pos_edge, const int6
     if (own_adam) { free(adam_m); free(adam_v); }
     return iters_run;
 }
+
+
+/* ------------------------------------------------------------------------
+ * The same loop (DESC_PGD.m:148-261, ConstantStepSize / PiecewiseStepSize only) carried in long double (x87: 64-bit
+ * significand, eps 5.4e-20) from the first iteration to the last: a yardstick for how much of a difference between two
+ * double-precision implementations is round-off amplified by the iteration (tests: the lr = 1 fuzz case of round 2).
+ * Inputs and outputs are double; nothing is rounded to double in between.  Serial.
+ * ---------------------------------------------------------------------- */
+static int cmp_ld(const void* a, const void* b) {
+    long double x = *(const long double*)a, y = *(const long double*)b;
+    return (x > y) - (x < y);
+}
+int oracle_pgd_run_ld(int64_t m, int64_t m_pos, const int32_t* pos_edge, const int64_t* cum_ind,
+                      const int32_t* e_jk, const int32_t* e_ki, const int32_t* ikj, const int32_t* jki,
+                      const double* S0_long, const oracle_params* p,
+                      double* S_vec_out /* m */, double* wijk_out /* m_cycle */, double* obj_vals /* iters */) {
+    typedef long double real;
+    if (p->step_kind == 2) return -1;
+    int64_t m_cycle = cum_ind[m_pos];
+    size_t nc = (size_t)(m_cycle > 0 ? m_cycle : 1), ne = (size_t)(m > 0 ? m : 1);
+    real* w = (real*)malloc(sizeof(real) * nc);
+    real* w_old = (real*)malloc(sizeof(real) * nc);
+    real* g = (real*)malloc(sizeof(real) * nc);
+    real* S = (real*)malloc(sizeof(real) * ne);
+    real* S_old = (real*)malloc(sizeof(real) * ne);
+    int64_t max_cnt = 1;
+    for (int64_t l = 0; l < m_pos; ++l) if (cum_ind[l + 1] - cum_ind[l] > max_cnt) max_cnt = cum_ind[l + 1] - cum_ind[l];
+    real* ws = (real*)malloc(sizeof(real) * (size_t)max_cnt);
+    for (int64_t e = 0; e < m; ++e) S[e] = 1.0L;
+    for (int64_t l = 0; l < m_pos; ++l) {
+        int64_t lo = cum_ind[l], hi = cum_ind[l + 1];
+        real s = 0.0L;
+        for (int64_t c = lo; c < hi; ++c) { w[c] = 1.0L / (real)(hi - lo); s += w[c] * (real)S0_long[c]; }
+        S[pos_edge[l]] = s;
+    }
+    int32_t t = p->t0, misses = 0, it = 0, iters_run = 0;
+    for (it = 1; it <= p->iters; ++it) {
+        iters_run = it;
+        memcpy(w_old, w, sizeof(real) * (size_t)m_cycle);
+        memcpy(S_old, S, sizeof(real) * (size_t)m);
+        ++t;
+        real step_size = (real)p->lr;
+        if (p->step_kind == 1) step_size = (real)p->lr / (truncl((real)t / (real)p->decay_interval) + 1.0L);
+        for (int64_t l = 0; l < m_pos; ++l) {
+            int64_t lo = cum_ind[l], hi = cum_ind[l + 1], cnt = hi - lo;
+            real T1 = 0.0L, T2 = 0.0L;
+            for (int64_t c = lo; c < hi; ++c) { if (ikj[c] >= 0) T1 += w_old[ikj[c]]; if (jki[c] >= 0) T2 += w_old[jki[c]]; }
+            for (int64_t c = lo; c < hi; ++c)
+                g[c] = S_old[e_jk[c]] + S_old[e_ki[c]] + ((ikj[c] >= 0 ? T1 : 0.0L) + (jki[c] >= 0 ? T2 : 0.0L)) * (real)S0_long[c];
+            real nv = 1.0L / sqrtl((real)cnt), dot = 0.0L;
+            for (int64_t c = lo; c < hi; ++c) dot += g[c] * nv;
+            for (int64_t c = lo; c < hi; ++c) w[c] = w_old[c] - step_size * (g[c] - dot * nv);
+            for (int64_t c = 0; c < cnt; ++c) ws[c] = w[lo + c];
+            qsort(ws, (size_t)cnt, sizeof(real), cmp_ld);
+            int64_t Ti = 0; real tail = 0.0L;
+            for (int64_t i1 = 0; i1 < cnt; ++i1) {
+                real s = 0.0L; for (int64_t q = i1; q < cnt; ++q) s += ws[q] - ws[i1];
+                if (s < 1.0L) { Ti = i1; tail = s; break; }
+            }
+            real T = ws[Ti] - (1.0L - tail) / (real)(cnt - Ti);
+            real s = 0.0L;
+            for (int64_t c = lo; c < hi; ++c) { real v = w[c] - T; w[c] = v > 0.0L ? v : 0.0L; s += w[c] * (real)S0_long[c]; }
+            S[pos_edge[l]] = s;
+        }
+        real obj = 0.0L;
+        for (int64_t c = 0; c < m_cycle; ++c) obj += w[c] * (S[e_jk[c]] + S[e_ki[c]]);
+        obj_vals[it - 1] = (double)obj;
+        if (it > 1 && obj_vals[it - 2] - obj_vals[it - 1] < p->stop_tol) { if (++misses >= p->patience) break; } else misses = 0;
+    }
+    for (int64_t e = 0; e < m; ++e) S_vec_out[e] = (double)S[e];
+    for (int64_t c = 0; c < m_cycle; ++c) wijk_out[c] = (double)w[c];
+    free(w); free(w_old); free(g); free(S); free(S_old); free(ws);
+    return iters_run;
+}

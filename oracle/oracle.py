@@ -155,5 +155,27 @@ def pgd_run(st, S0, iters, step_kind=0, lr=0.01, beta1=0.9, beta2=0.999, decay_i
     return dict(S_vec=S_vec[:m], w=w[:mc], obj=obj[:it], avg=avg[:it], iters_run=it)
 
 
+def pgd_run_ld(st, S0, iters, step_kind=0, lr=0.01, decay_interval=25, t0=0, patience=30, stop_tol=1e-5):
+    """oracle_pgd_run_ld: the same loop carried in long double from start to end (constant / piecewise step), a yardstick
+    for round-off amplification.  Returns dict(S_vec, w, obj, iters_run), rounded to double once at the end."""
+    L = lib()
+    m, mp, mc = st["m"], st["m_pos"], st["m_cycle"]
+    S_vec = np.zeros(max(m, 1)); w = np.zeros(max(mc, 1)); obj = np.zeros(max(iters, 1))
+    p = _Params(iters, step_kind, lr, 0.9, 0.999, float(decay_interval), 0, t0, patience, stop_tol)
+    I32, I64, F64 = C.c_int32, C.c_int64, C.c_double
+    S0c = np.ascontiguousarray(S0, dtype=np.float64)
+    if S0c.shape[0] == 0:
+        S0c = np.zeros(1)
+    arrs = [np.ascontiguousarray(st[k]) if st[k].shape[0] else np.zeros(1, dtype=np.int32)
+            for k in ("pos_edge", "e_jk", "e_ki", "ikj", "jki")]
+    L.oracle_pgd_run_ld.restype = C.c_int
+    it = L.oracle_pgd_run_ld(C.c_int64(m), C.c_int64(mp), _p(arrs[0], I32), _p(st["cum_ind"], I64),
+                             _p(arrs[1], I32), _p(arrs[2], I32), _p(arrs[3], I32), _p(arrs[4], I32),
+                             _p(S0c, F64), C.byref(p), _p(S_vec, F64), _p(w, F64), _p(obj, F64))
+    if it < 0:
+        raise ValueError("oracle_pgd_run_ld: constant / piecewise step only")
+    return dict(S_vec=S_vec[:m], w=w[:mc], obj=obj[:it], iters_run=it)
+
+
 def num_threads():
     return lib().oracle_num_threads()

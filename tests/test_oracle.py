@@ -251,3 +251,21 @@ def test_statistical_recovery_like_the_demo(oracle):
     assert err < 0.03
     corrupted = mo.corrupted
     assert res["S_vec"][corrupted].mean() > 3 * res["S_vec"][~corrupted].mean()
+
+
+def test_long_double_yardstick_follows_the_double_oracle(oracle):
+    """oracle_pgd_run_ld (the loop of DESC_PGD.m:148-261 carried in long double) agrees with the double-precision restatement to
+    round-off at a contracting step (lr = 0.01), takes the same stop decision, and shows the amplification at lr = 1 that the GPU
+    regression test of the round-2 fuzz case relies on (distance growing with the iteration count)."""
+    mo, nn, ii, jj, rij = make_problem("uniform", n=70, p=0.6, q=0.2, sigma=0.1, seed=12)
+    st = oracle.build_structure(nn, ii, jj, seed=4)
+    S0 = oracle.cycle_d(ii, jj, rij.reshape(-1, 9), st)
+    a, b = oracle.pgd_run(st, S0, 60, lr=0.01), oracle.pgd_run_ld(st, S0, 60, lr=0.01)
+    assert a["iters_run"] == b["iters_run"] == 60
+    assert np.abs(a["S_vec"] - b["S_vec"]).max() < 1e-13 and np.abs(a["w"] - b["w"]).max() < 1e-13
+    assert np.allclose(a["obj"], b["obj"], rtol=1e-13)
+    kw = dict(step_kind=1, lr=1.0, decay_interval=7, patience=4, stop_tol=1e-2)
+    a, b = oracle.pgd_run(st, S0, 400, **kw), oracle.pgd_run_ld(st, S0, 400, **kw)
+    assert a["iters_run"] == b["iters_run"] < 400
+    d = [np.abs(oracle.pgd_run(st, S0, t, lr=1.0)["w"] - oracle.pgd_run_ld(st, S0, t, lr=1.0)["w"]).max() for t in (2, 12, 24)]
+    assert d[0] < 1e-14 and d[0] < d[1] < d[2]

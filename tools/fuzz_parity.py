@@ -59,10 +59,19 @@ while time.time() < t_end:
         for key in STRUCT_KEYS:
             assert np.array_equal(a[key], st[key]), "structure " + key
         assert out["iters_run"] == ref["iters_run"], "iters_run %d vs %d" % (out["iters_run"], ref["iters_run"])
-        # Adam divides by sqrt(v) + 1e-8: round-off is amplified; lr = 1 amplifies it too (10 400-case run of round 2: one case at 1.4e-10 after 40 iterations)
-        tol = (1e-8 if lr >= 0.1 else 1e-9) if sk == 2 else (5e-10 if lr >= 1.0 else 1e-10)
+        # Adam divides by sqrt(v) + 1e-8: round-off is amplified.  Everything else: 1e-10.  lr = 1 amplifies round-off by
+        # ~1.3x per sweep (tests/test_gpu_parity.py::test_fuzz_case_945063979_is_roundoff): a case beyond 1e-10 there is judged against
+        # the long-double run of the same loop -- it passes if the HIP result is within 4x of the double oracle's own distance to it
+        tol = (1e-8 if lr >= 0.1 else 1e-9) if sk == 2 else 1e-10
         e1 = float(np.abs(out["S_vec"] - ref["S_vec"]).max()) if nn else 0.0
         e2 = float(np.abs(out["w"] - ref["w"]).max()) if st["m_cycle"] else 0.0
+        if max(e1, e2) > tol and sk != 2 and lr >= 1.0:
+            ld = O.pgd_run_ld(st, S0, iters, **{k: v for k, v in step.items() if k != "hybrid_strategy"})
+            yard = max(float(np.abs(ref["S_vec"] - ld["S_vec"]).max()), float(np.abs(ref["w"] - ld["w"]).max()))
+            eh = max(float(np.abs(out["S_vec"] - ld["S_vec"]).max()), float(np.abs(out["w"] - ld["w"]).max()))
+            print("yardstick", tag, "hip-vs-oracle %.3g, oracle-vs-long-double %.3g, hip-vs-long-double %.3g" % (max(e1, e2), yard, eh), flush=True)
+            assert eh <= 4 * yard and yard <= 1e-9, "values %g %g beyond 4x the round-off yardstick %g" % (e1, e2, yard)
+            e1 = e2 = 0.0
         worst = max(worst, e1, e2)
         assert e1 <= tol and e2 <= tol, "values %g %g" % (e1, e2)
         assert np.allclose(out["obj"], ref["obj"], rtol=1e-11, atol=1e-9), "objective trace"
