@@ -29,7 +29,7 @@ EXPORTS = [
     "desc_pgd_sizes", "desc_pgd_kernel_name", "desc_pgd_solve", "desc_selftest_group_sum",
     "desc_pgd_create_shard", "desc_pgd_shard_info", "desc_pgd_shard_bind", "desc_pgd_shard_colsum", "desc_pgd_shard_sweep",
     "desc_pgd_shard_finish", "desc_pgd_shard_objective", "desc_pgd_shard_set_collectives", "desc_pgd_shard_start",
-    "desc_pgd_shard_iterate", "desc_pgd_shard_run", "desc_pgd_stopped", "desc_device_synchronize", "desc_memcpy_d2h", "desc_memcpy_h2d", "desc_debug_band_plan", "desc_trim_memory", "desc_spectral_run", "desc_cemp_run", "desc_refine_run",
+    "desc_pgd_shard_iterate", "desc_pgd_shard_run", "desc_pgd_stopped", "desc_device_synchronize", "desc_memcpy_d2h", "desc_memcpy_h2d", "desc_debug_band_plan", "desc_debug_spmm_variants", "desc_trim_memory", "desc_spectral_run", "desc_cemp_run", "desc_refine_run",
 ]
 
 I32P = C.POINTER(C.c_int32)
@@ -170,6 +170,7 @@ def load():
     L.desc_pgd_shard_iterate.argtypes = [C.c_void_p, C.c_int32]
     L.desc_pgd_shard_run.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Result)]
     L.desc_debug_band_plan.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_int32, C.c_int32, C.c_int32, I64P]
+    L.desc_debug_spmm_variants.argtypes = [C.c_void_p, C.c_int32, F64P]
     L.desc_trim_memory.restype = C.c_int64
     L.desc_trim_memory.argtypes = []
     L.desc_device_synchronize.argtypes = [C.c_int32]
@@ -567,6 +568,13 @@ def refine_run(prob, s_vec, R_init, stop_threshold=1e-3, max_iters=100, device=0
         check(L.desc_refine_run(C.byref(prob.c), ptr(S, F64P), ptr(Ri, F64P), stop_threshold, max_iters, device, ptr(Ro, F64P), C.byref(info)))
     return Ro[:9 * n].reshape((3, 3, n), order="F"), dict(iters=info.iters, cg_iters=info.cg_iters, score=info.score, ms_total=info.ms_total,
                                                         cg_unconverged=info.cg_unconverged, cg_residual=info.cg_residual)
+
+
+def spmm_variants(dprob: DeviceProblem, reps=20):
+    """desc_debug_spmm_variants: ms per block-SpMM product, vector-FMA vs v_mfma_f64_4x4x4 form (measurement hook)."""
+    out = out_buffer(4)
+    check(load().desc_debug_spmm_variants(dprob.handle, int(reps), ptr(out, F64P)))
+    return dict(ms_valu=float(out[0]), ms_mfma=float(out[1]), max_abs_diff=float(out[2]), mfma_layout=int(out[3]))
 
 
 def trim_memory():

@@ -27,46 +27,76 @@ namespace {
 constexpr int BW = 6;    // block width of the subspace iteration
 
 // y[v] = alpha * sum_t blocks[t] * x[adj[t]] + s1 * x[v] + s2 * z[v];  x, y, z: (3n x BW) row-major
-// (z may alias y: every element is read before it is written by the same lane); 16 lanes per node row
-// The 2m blocks are stored component-major (blocks[q * nslots + t], q = r + 3k): the 16 lanes of a row read 16
-// consecutive doubles per component (coalesced) instead of nine 8-byte picks at a 72-byte stride; the operand
-// rows of x (144 B, L2-resident) come in as nine 16-byte loads.
+// (z may alias y: every element is read before it is written by the same lane).
+// The 2m blocks are stored component-major (blocks[q * nslots + t], q = r + 3k): the lanes of a row read consecutive
+// doubles per component (coalesced) instead of nine 8-byte picks at a 72-byte stride; the operand rows of x (144 B,
+// L2-resident) come in as nine 16-byte loads.
+// TPR threads share one node row: the whole 256-thread workgroup for rows of hundreds of slots (C2, C4, C5: the round-2 kernel gave
+// a row to 16 lanes, i.e. 62 dependent load->FMA rounds per lane and 1.2 waves per SIMD on the whole chip at n = 5000 -- 0.35 ms per
+// product at C4 for 0.36 GB of matrix), one wave for short rows.  Two slots are in flight per lane; partial sums are combined in a
+// fixed order (DPP butterfly, then the four waves in index order): bitwise reproducible.
+template <int TPR>
 __global__ __launch_bounds__(256) void k_bsr_spmm(const int32_t* rowptr, const int32_t* adj, const double* blocks, int64_t nslots, const double* x,
                                                   const double* z, double* y, int n, double alpha, double s1, double s2) {
-    const int lane = threadIdx.x & 63, l16 = lane & 15;
-    const int row0 = (blockIdx.x * 256 + threadIdx.x) >> 4;
-    const int nrows = (gridDim.x * 256) >> 4;
-    for (int vb = row0 - (row0 % 4); vb < n; vb += nrows) {      // the 4 rows of a wave advance together (DPP needs full waves)
-        const int v = vb + (row0 % 4);
+    static_assert(TPR == 64 || TPR == 256, "one wave or one workgroup per row");
+    constexpr int RPB = 256 / TPR;
+    __shared__ double sh[4][3 * BW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, tr = threadIdx.x % TPR;
+    for (int v0 = blockIdx.x * RPB; v0 < n; v0 += gridDim.x * RPB) {
+        const int v = v0 + threadIdx.x / TPR;
         double acc[3][BW];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < BW; ++c) acc[r][c] = 0.0;
         if (v < n) {
-            for (int t = rowptr[v] + l16; t < rowptr[v + 1]; t += 16) {
-                double B[9];                                         // column-major 3x3: B(r,k) = B[r + 3k]
+            const int r1 = rowptr[v + 1];
+            for (int t = rowptr[v] + tr; t < r1; t += 2 * TPR) {
+                const bool two = t + TPR < r1;
+                const int t2 = two ? t + TPR : t;
+                double B[2][9];                                      // column-major 3x3: B(r,k) = B[r + 3k]
 #pragma unroll
-                for (int q = 0; q < 9; ++q) B[q] = blocks[(int64_t)q * nslots + t];
-                const double2* xj = reinterpret_cast<const double2*>(x + (int64_t)3 * BW * adj[t]);
-                double xr[3 * BW];
+                for (int q = 0; q < 9; ++q) { B[0][q] = blocks[(int64_t)q * nslots + t]; B[1][q] = blocks[(int64_t)q * nslots + t2]; }
+                const double2* xa = reinterpret_cast<const double2*>(x + (int64_t)3 * BW * adj[t]);
+                const double2* xb = reinterpret_cast<const double2*>(x + (int64_t)3 * BW * adj[t2]);
+                double xr[2][3 * BW];
 #pragma unroll
-                for (int q = 0; q < 3 * BW / 2; ++q) { const double2 v2 = xj[q]; xr[2 * q] = v2.x; xr[2 * q + 1] = v2.y; }
+                for (int q = 0; q < 3 * BW / 2; ++q) {
+                    const double2 u = xa[q], w = xb[q];
+                    xr[0][2 * q] = u.x; xr[0][2 * q + 1] = u.y; xr[1][2 * q] = w.x; xr[1][2 * q + 1] = w.y;
+                }
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
+                for (int h = 0; h < 2; ++h) {
+                    if (h == 1 && !two) break;
 #pragma unroll
-                    for (int c = 0; c < BW; ++c) {
-                        const double xv = xr[k * BW + c];
+                    for (int k = 0; k < 3; ++k)
 #pragma unroll
-                        for (int r = 0; r < 3; ++r) acc[r][c] += B[r + 3 * k] * xv;
-                    }
+                        for (int c = 0; c < BW; ++c) {
+                            const double xv = xr[h][k * BW + c];
+#pragma unroll
+                            for (int r = 0; r < 3; ++r) acc[r][c] += B[h][r + 3 * k] * xv;
+                        }
+                }
             }
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int c = 0; c < BW; ++c) acc[r][c] = group16_sum(acc[r][c]);
-        if (v < n && l16 == 0) {
+            for (int c = 0; c < BW; ++c) acc[r][c] = group_sum<64>(acc[r][c]);
+        if (TPR == 256) {
+            __syncthreads();                                         // the previous row's sums have been read
+            if (lane == 0)
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < BW; ++c) sh[wv][r * BW + c] = acc[r][c];
+            __syncthreads();
+            if (v < n && threadIdx.x < 3 * BW) {
+                const int64_t o = (int64_t)3 * v * BW + threadIdx.x;
+                const double tot = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+                y[o] = alpha * tot + s1 * x[o] + (s2 != 0.0 ? s2 * z[o] : 0.0);
+            }
+        } else if (v < n && lane == 0) {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -74,6 +104,52 @@ __global__ __launch_bounds__(256) void k_bsr_spmm(const int32_t* rowptr, const i
                     const int64_t o = ((int64_t)3 * v + r) * BW + c;
                     y[o] = alpha * acc[r][c] + s1 * x[o] + (s2 != 0.0 ? s2 * z[o] : 0.0);
                 }
+        }
+    }
+}
+
+// The same product on the f64 matrix cores, for the record ("MFMA: measure, expect HBM/L2-bound"):
+// v_mfma_f64_4x4x4 multiplies four independent 4x4x4 tiles per instruction, one per 16-lane group.  A tile = one CSR slot:
+// A = its 3x3 block padded to 4x4, B = rows 0..2 of the operand x[adj] x four of its BW = 6 columns (two instructions per slot for
+// the six columns), D accumulates that 16-lane group's share of y[v].  One lane holds ONE element of A and of B, so a slot costs 16 lanes
+// x 3 loads (9 of the 16 A lanes and 9-12 of the B lanes carry data) against 1 lane x 27 loads in k_bsr_spmm: 1.8x the load lane-operations
+// for 54 useful multiply-adds out of the 128 the two instructions perform.  LAY: bit 0 / 1 / 2 = element (x, y) of A / B / D sits in lane
+// 4*y + x of its group instead of 4*x + y (probed at run time with exact integer data by desc_debug_spmm_variants).
+__global__ __launch_bounds__(256) void k_mfma_layout_probe(const double* a, const double* b, double* d) {
+    double acc = 0.0;
+    acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a[threadIdx.x], b[threadIdx.x], acc, 0, 0, 0);
+    d[threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_bsr_spmm_mfma(const int32_t* rowptr, const int32_t* adj, const double* blocks, int64_t nslots, const double* x,
+                                                       const double* z, double* y, int n, double alpha, double s1, double s2, int lay) {
+    __shared__ double sh[16][3 * BW];                                // one partial y per 16-lane group
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 4, p = lane & 15;
+    const int ai = (lay & 1) ? (p & 3) : (p >> 2), ak = (lay & 1) ? (p >> 2) : (p & 3);     // A element (row i, component k) of this lane
+    const int bk = (lay & 2) ? (p & 3) : (p >> 2), bj = (lay & 2) ? (p >> 2) : (p & 3);     // B element (component k, column j)
+    const int di = (lay & 4) ? (p & 3) : (p >> 2), dj = (lay & 4) ? (p >> 2) : (p & 3);     // D element (row i, column j)
+    const bool a_on = ai < 3 && ak < 3, b_on = bk < 3;
+    for (int v = blockIdx.x; v < n; v += gridDim.x) {
+        double d0 = 0.0, d1 = 0.0;                                   // columns 0..3 and 4..7 (6, 7 unused)
+        const int r1 = rowptr[v + 1];
+        for (int t0 = rowptr[v]; t0 < r1; t0 += 16) {                // 16 slots per workgroup step, one per lane group
+            const int t = t0 + grp;
+            const bool on = t < r1;
+            const int tt = on ? t : t0;
+            const int u = adj[tt];
+            const double av = (on && a_on) ? blocks[(int64_t)(ai + 3 * ak) * nslots + tt] : 0.0;
+            const double b0 = (on && b_on) ? x[(int64_t)3 * BW * u + bk * BW + bj] : 0.0;
+            const double b1 = (on && b_on && bj < BW - 4) ? x[(int64_t)3 * BW * u + bk * BW + 4 + bj] : 0.0;
+            d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b0, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b1, d1, 0, 0, 0);
+        }
+        __syncthreads();
+        if (di < 3) { sh[grp][di * BW + dj] = d0; if (dj < BW - 4) sh[grp][di * BW + 4 + dj] = d1; }
+        __syncthreads();
+        if (threadIdx.x < 3 * BW) {
+            double tot = 0.0;
+            for (int g = 0; g < 16; ++g) tot += sh[g][threadIdx.x];
+            const int64_t o = (int64_t)3 * v * BW + threadIdx.x;
+            y[o] = alpha * tot + s1 * x[o] + (s2 != 0.0 ? s2 * z[o] : 0.0);
         }
     }
 }
@@ -411,9 +487,11 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
     double theta[BW] = {}, Z[BW * BW], res = 1e300;
     int it = 0, products = 0;
     bool converged = false;
-    const int sgrid = (int)std::min<int64_t>(4096, (n * 16 + 255) / 256);
+    const bool wide_rows = 2 * m >= 192 * n;                   // average row of >= 192 slots: a workgroup per row, else a wave
+    const int sgrid = (int)std::min<int64_t>(8192, wide_rows ? n : (n + 3) / 4);
     auto spmm = [&](const double* x, const double* z, double* y, double alpha, double s1, double s2) {
-        hipLaunchKernelGGL(k_bsr_spmm, dim3(sgrid), dim3(256), 0, 0, d_rowptr, d_adj, d_blocks, (int64_t)2 * m, x, z, y, (int)n, alpha, s1, s2);
+        if (wide_rows) hipLaunchKernelGGL(k_bsr_spmm<256>, dim3(sgrid), dim3(256), 0, 0, d_rowptr, d_adj, d_blocks, (int64_t)2 * m, x, z, y, (int)n, alpha, s1, s2);
+        else hipLaunchKernelGGL(k_bsr_spmm<64>, dim3(sgrid), dim3(256), 0, 0, d_rowptr, d_adj, d_blocks, (int64_t)2 * m, x, z, y, (int)n, alpha, s1, s2);
         ++products;
     };
     const double lo = -sigma;
@@ -502,4 +580,81 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
         info->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return DESC_OK;
+}
+
+
+// Diagnostics (tools/next_rows_bench.py): times the block SpMM of the Spectral connection matrix (unit weights) in its two forms
+// -- k_bsr_spmm (vector FMA) and k_bsr_spmm_mfma (v_mfma_f64_4x4x4) -- on the same operand, `reps` products each, HIP events.
+// out[0], out[1] = ms per product (VALU, MFMA; -1 if the MFMA operand layout could not be identified), out[2] = max |difference| of
+// the two results, out[3] = the layout code found.
+extern "C" int desc_debug_spmm_variants(const desc_device_problem* dp, int32_t reps, double* out) {
+    return no_throw("desc_debug_spmm_variants", [&]() -> int {
+    if (!dp || !out || reps < 1) return fail(DESC_ERR_INVALID, "bad argument");
+    DESC_HIP(hipSetDevice(dp->device));
+    const int64_t n = dp->n, m = dp->m, rows = 3 * n;
+    if (n == 0 || m == 0) return fail(DESC_ERR_INVALID, "empty problem");
+    int rc;
+    Dev D;
+    double *d_blocks, *d_X, *d_Y1, *d_Y2, *d_dinv, *d_pa, *d_pb, *d_pd;
+    if ((rc = D.alloc(&d_blocks, 18 * m)) || (rc = D.alloc(&d_X, rows * BW)) || (rc = D.alloc(&d_Y1, rows * BW)) || (rc = D.alloc(&d_Y2, rows * BW)) ||
+        (rc = D.alloc(&d_dinv, n)) || (rc = D.alloc(&d_pa, 64)) || (rc = D.alloc(&d_pb, 64)) || (rc = D.alloc(&d_pd, 64))) return rc;
+    hvec<double> ones((size_t)n, 1.0), X0((size_t)rows * BW);
+    for (size_t t = 0; t < X0.size(); ++t) X0[t] = (double)(int64_t)(mix64(0xC0FFEEull + t) >> 11) / 4503599627370496.0 - 1.0;
+    DESC_HIP(hipMemcpy(d_dinv, ones.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    DESC_HIP(hipMemcpy(d_X, X0.data(), sizeof(double) * rows * BW, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_assemble_blocks, dim3((unsigned)std::min<int64_t>(4096, (n + 3) / 4)), dim3(256), 0, 0, dp->d_rowptr, dp->d_adj, dp->d_adj_eid, dp->d_rij,
+                       (const double*)nullptr, d_dinv, d_blocks, (int64_t)2 * m, (int)n);
+    // operand layout of v_mfma_f64_4x4x4: exact small integers, eight hypotheses
+    double pa[64], pb[64], pd[64];
+    for (int l = 0; l < 64; ++l) { pa[l] = 1 + (l * 7) % 13; pb[l] = 2 + (l * 5) % 11; }
+    DESC_HIP(hipMemcpy(d_pa, pa, sizeof pa, hipMemcpyHostToDevice));
+    DESC_HIP(hipMemcpy(d_pb, pb, sizeof pb, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_mfma_layout_probe, dim3(1), dim3(64), 0, 0, d_pa, d_pb, d_pd);
+    DESC_HIP(hipMemcpy(pd, d_pd, sizeof pd, hipMemcpyDeviceToHost));
+    int lay = -1;
+    for (int h = 0; h < 8 && lay < 0; ++h) {
+        bool ok = true;
+        for (int l = 0; l < 64 && ok; ++l) {
+            const int g = l >> 4, q = l & 15;
+            const int i = (h & 4) ? (q & 3) : (q >> 2), j = (h & 4) ? (q >> 2) : (q & 3);
+            double e = 0.0;
+            for (int k = 0; k < 4; ++k) {
+                const int la = 16 * g + ((h & 1) ? 4 * k + i : 4 * i + k), lb = 16 * g + ((h & 2) ? 4 * j + k : 4 * k + j);
+                e += pa[la] * pb[lb];
+            }
+            ok = e == pd[l];
+        }
+        if (ok) lay = h;
+    }
+    const bool wide = 2 * m >= 192 * n;
+    const int sgrid = (int)std::min<int64_t>(8192, wide ? n : (n + 3) / 4);
+    hipEvent_t e0, e1;
+    DESC_HIP(hipEventCreate(&e0)); DESC_HIP(hipEventCreate(&e1));
+    auto timed = [&](int which) -> double {
+        for (int r = -2; r < reps; ++r) {                              // two untimed warm-up products
+            if (r == 0) (void)hipEventRecord(e0, 0);
+            if (which == 0) {
+                if (wide) hipLaunchKernelGGL(k_bsr_spmm<256>, dim3(sgrid), dim3(256), 0, 0, dp->d_rowptr, dp->d_adj, d_blocks, (int64_t)2 * m, d_X, d_X, d_Y1, (int)n, 1.0, 0.0, 0.0);
+                else hipLaunchKernelGGL(k_bsr_spmm<64>, dim3(sgrid), dim3(256), 0, 0, dp->d_rowptr, dp->d_adj, d_blocks, (int64_t)2 * m, d_X, d_X, d_Y1, (int)n, 1.0, 0.0, 0.0);
+            } else
+                hipLaunchKernelGGL(k_bsr_spmm_mfma, dim3((unsigned)std::min<int64_t>(8192, n)), dim3(256), 0, 0, dp->d_rowptr, dp->d_adj, d_blocks, (int64_t)2 * m, d_X, d_X, d_Y2, (int)n, 1.0, 0.0, 0.0, lay);
+        }
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        return ms / reps;
+    };
+    out[0] = timed(0);
+    out[1] = lay >= 0 ? timed(1) : -1.0;
+    out[2] = 0.0; out[3] = lay;
+    if (lay >= 0) {
+        hvec<double> y1((size_t)rows * BW), y2((size_t)rows * BW);
+        DESC_HIP(hipMemcpy(y1.data(), d_Y1, sizeof(double) * rows * BW, hipMemcpyDeviceToHost));
+        DESC_HIP(hipMemcpy(y2.data(), d_Y2, sizeof(double) * rows * BW, hipMemcpyDeviceToHost));
+        for (size_t t = 0; t < y1.size(); ++t) out[2] = std::max(out[2], std::fabs(y1[t] - y2[t]));
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    DESC_HIP(hipGetLastError());
+    return DESC_OK;
+    });
 }

@@ -346,6 +346,11 @@ int desc_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes);
  * first / end segment of the rank). */
 int desc_debug_band_plan(const desc_problem* prob, const desc_structure* s, int32_t world, int32_t rank, int32_t grid, int64_t* stats);
 
+/* Measurement hook (tools/next_rows_bench.py; SURVEY.md 8d "document the MFMA measurement rather than assume"): the 3x3-block SpMM of the
+ * connection matrix (Spectral.m:27-37) with unit weights, `reps` products in its vector-FMA form and in a v_mfma_f64_4x4x4 form on the
+ * same operand.  out[4]: ms per product (vector FMA), ms per product (MFMA; -1: operand layout not identified), max |difference|, layout code. */
+int desc_debug_spmm_variants(const desc_device_problem* dp, int32_t reps, double* out);
+
 /* Test hook: sums `in` over aligned groups of G = 16/32/64 lanes with the kernels'
  * DPP / permlane-swap reduction; every element of a group receives the group total. */
 int desc_selftest_group_sum(const double* in, double* out, int32_t count, int32_t G, int32_t device);

@@ -106,3 +106,17 @@ def test_refinement_with_truncated_edges_against_dense_oracle(oracle):
     assert info["iters"] == iters_ref, (info, iters_ref)
     assert np.abs(R - R_ref).max() < 1e-6, np.abs(R - R_ref).max()
     assert abs(info["score"] - score_ref) < 1e-8
+
+
+def test_c2_cemp_against_batched_oracle():
+    """CEMP at BASELINE configs[1] (n = 1000, p = 0.5: 2.5e5 edges x 50 samples, 6 rounds with the demo's reweighting,
+    Demo/compare_algorithms.m:26-28) against the NumPy restatement of CEMP.m:24-132 on the same keyed samples.
+    Tolerance 1e-12 (f64; summation order, libm exp / acos rounding) as in the small-n test."""
+    from desc_amd import CEMP
+    from oracle.cemp_oracle import cemp_oracle_batched
+    mo, nn, ii, jj, rij = bench.generate("C2")
+    params = dict(max_iter=6, reweighting=2.0 ** np.arange(6), nsample=50, seed=7)
+    S = CEMP(mo.Ind, mo.RijMat, params)
+    ref = cemp_oracle_batched(mo.Ind, mo.RijMat, 6, params["reweighting"], 50, seed=7)
+    assert np.abs(S - ref).max() < 1e-12
+    assert np.mean(np.abs(S - mo.ErrVec)) < 0.03

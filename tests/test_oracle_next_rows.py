@@ -135,3 +135,16 @@ def test_matlab_quantile_definition():
     assert np.quantile(x, 1.0, method="hazen") == 4.0
     assert np.quantile(np.arange(1.0, 6.0), 0.3, method="hazen") == 2.0
     assert np.isclose(np.quantile(np.arange(1.0, 6.0), 0.8, method="hazen"), 4.5)
+
+
+def test_batched_cemp_restatement_equals_the_literal_one():
+    """cemp_oracle_batched (the per-edge loops of CEMP.m:62-125 batched over chunks of edges, used for the full-size GPU parity
+    test at C2) against the loop-by-loop restatement, with a chunk size that does not divide m and an edge without cycles."""
+    from desc_amd.models import Uniform_Topology
+    from oracle.cemp_oracle import cemp_oracle_batched
+    for n, p, ns, seed in [(40, 0.5, 50, 1), (60, 0.12, 20, 2)]:
+        mo = Uniform_Topology(n, p, 0.2, 0.1, "uniform", seed=seed)
+        a = cemp_oracle(mo.Ind, mo.RijMat, 5, [1.0, 2.0, 4.0], ns, seed=seed)
+        b = cemp_oracle_batched(mo.Ind, mo.RijMat, 5, [1.0, 2.0, 4.0], ns, seed=seed, chunk=37)
+        assert np.abs(a - b).max() < 1e-13
+    assert (a == 1).any()            # the sparse graph has edges without cycles (CEMP.m:103)

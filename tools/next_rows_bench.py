@@ -76,3 +76,19 @@ res["DESC_minus_DESC_PGD_ms"] = res["DESC_wrapper_ms"] - res["DESC_PGD_wrapper_m
 res["desc_pgd_solve_ms"] = out["desc_pgd_solve"]["ms_wall"]
 res["DESC_rot_err"] = rot_err(Re)
 print(json.dumps({"device_resident_problem": res}))
+
+# ---- rooflines of the next rows' dominant kernels (HBM-bound; peak 8 TB/s as in bench.py).  Algorithmic bytes:
+#   block SpMM (Spectral.m:27-37 as a sparse product): per CSR slot the 72-B block + its 4-B column index once, the 144-B operand row
+#       (6 vectors x 3 components) gathered, per node row 144 B written                       -> 2m (72 + 4 + 144) + n 144 per product
+#   CEMP round (CEMP.m:107-126): per sample S0 8 B + two edge ids 8 B + two S gathers 16 B    -> 32 m_pos nsample + 8 m per round
+#   CEMP S0 (CEMP.m:80-101): per sample two 72-B blocks gathered + two ids 8 B + k 4 B + S0 written 8 B -> 164 per sample (+ 72 per edge)
+dp = _lib.DeviceProblem(prob, 0)
+v = _lib.spmm_variants(dp, reps=30)
+dp.free()
+roof = {"peak_GBs": 8000.0}
+roof["k_bsr_spmm"] = dict(ms=v["ms_valu"], bytes=spmm_bytes, achieved_GBs=spmm_bytes / v["ms_valu"] / 1e6, frac=spmm_bytes / v["ms_valu"] / 1e6 / 8000.0,
+                          matrix_bytes_only=2 * m * 72, matrix_GBs=2 * m * 72 / v["ms_valu"] / 1e6)
+roof["k_bsr_spmm_mfma_f64_4x4x4"] = dict(ms=v["ms_mfma"], layout_code=v["mfma_layout"], max_abs_diff_vs_valu=v["max_abs_diff"],
+                                         achieved_GBs=(spmm_bytes / v["ms_mfma"] / 1e6) if v["ms_mfma"] > 0 else None,
+                                         verdict="MFMA form slower" if v["ms_mfma"] > v["ms_valu"] else "MFMA form faster")
+print(json.dumps({"next_row_rooflines": roof}))
