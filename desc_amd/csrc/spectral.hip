@@ -16,7 +16,9 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "device_utils.h"
@@ -113,20 +115,35 @@ __global__ __launch_bounds__(256) void k_bsr_spmm(const int32_t* rowptr, const i
 // A = its 3x3 block padded to 4x4, B = rows 0..2 of the operand x[adj] x four of its BW = 6 columns (two instructions per slot for
 // the six columns), D accumulates that 16-lane group's share of y[v].  One lane holds ONE element of A and of B, so a slot costs 16 lanes
 // x 3 loads (9 of the 16 A lanes and 9-12 of the B lanes carry data) against 1 lane x 27 loads in k_bsr_spmm: 1.8x the load lane-operations
-// for 54 useful multiply-adds out of the 128 the two instructions perform.  LAY: bit 0 / 1 / 2 = element (x, y) of A / B / D sits in lane
-// 4*y + x of its group instead of 4*x + y (probed at run time with exact integer data by desc_debug_spmm_variants).
-__global__ __launch_bounds__(256) void k_mfma_layout_probe(const double* a, const double* b, double* d) {
-    double acc = 0.0;
-    acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a[threadIdx.x], b[threadIdx.x], acc, 0, 0, 0);
-    d[threadIdx.x] = acc;
+// for 54 useful multiply-adds out of the 128 the two instructions perform.  Which lane of a 16-lane group holds which element of A, B
+// and D is probed at run time with unit vectors (k_mfma_layout_probe) and handed over as a table.
+struct MfmaLayout { signed char ai[16], ak[16], bk[16], bj[16], di[16], dj[16]; };   // per lane of a 16-lane group: element coordinates
+// exact probes: unit vectors through the instruction.  rowmask[la] = lanes of D that see A's lane la (b = ones), colmask[lb] = lanes
+// of D that see B's lane lb (a = ones), compat[la][lb] = 1 iff A's lane la and B's lane lb meet in some product (same block, same k)
+__global__ __launch_bounds__(64) void k_mfma_layout_probe(unsigned long long* rowmask, unsigned long long* colmask, unsigned char* compat) {
+    const int lane = threadIdx.x;
+    for (int la = 0; la < 64; ++la) {
+        const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(lane == la ? 1.0 : 0.0, 1.0, 0.0, 0, 0, 0);
+        const unsigned long long mk = __ballot(d != 0.0);
+        if (lane == 0) rowmask[la] = mk;
+    }
+    for (int lb = 0; lb < 64; ++lb) {
+        const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, lane == lb ? 1.0 : 0.0, 0.0, 0, 0, 0);
+        const unsigned long long mk = __ballot(d != 0.0);
+        if (lane == 0) colmask[lb] = mk;
+    }
+    for (int la = 0; la < 64; ++la)
+        for (int lb = 0; lb < 64; ++lb) {
+            const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(lane == la ? 1.0 : 0.0, lane == lb ? 1.0 : 0.0, 0.0, 0, 0, 0);
+            const unsigned long long mk = __ballot(d != 0.0);
+            if (lane == 0) compat[la * 64 + lb] = mk != 0ull;
+        }
 }
 __global__ __launch_bounds__(256) void k_bsr_spmm_mfma(const int32_t* rowptr, const int32_t* adj, const double* blocks, int64_t nslots, const double* x,
-                                                       const double* z, double* y, int n, double alpha, double s1, double s2, int lay) {
+                                                       const double* z, double* y, int n, double alpha, double s1, double s2, MfmaLayout lay) {
     __shared__ double sh[16][3 * BW];                                // one partial y per 16-lane group
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 4, p = lane & 15;
-    const int ai = (lay & 1) ? (p & 3) : (p >> 2), ak = (lay & 1) ? (p >> 2) : (p & 3);     // A element (row i, component k) of this lane
-    const int bk = (lay & 2) ? (p & 3) : (p >> 2), bj = (lay & 2) ? (p >> 2) : (p & 3);     // B element (component k, column j)
-    const int di = (lay & 4) ? (p & 3) : (p >> 2), dj = (lay & 4) ? (p >> 2) : (p & 3);     // D element (row i, column j)
+    const int ai = lay.ai[p], ak = lay.ak[p], bk = lay.bk[p], bj = lay.bj[p], di = lay.di[p], dj = lay.dj[p];
     const bool a_on = ai < 3 && ak < 3, b_on = bk < 3;
     for (int v = blockIdx.x; v < n; v += gridDim.x) {
         double d0 = 0.0, d1 = 0.0;                                   // columns 0..3 and 4..7 (6, 7 unused)
@@ -382,6 +399,16 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
     if (n == 0) return DESC_OK;
     DESC_HIP(hipSetDevice(dp->device));
     auto t0 = std::chrono::steady_clock::now();
+    auto t_lap = t0;
+    const char* tenv = std::getenv("DESC_DEBUG_TIMING");
+    const bool timing = tenv && std::atoi(tenv) != 0;
+    auto lap = [&](const char* what) {                      // diagnostics: DESC_DEBUG_TIMING=1 prints where the call spends its time
+        if (!timing) return;
+        (void)hipDeviceSynchronize();
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[desc_amd] spectral %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_lap).count());
+        t_lap = now;
+    };
     if (tol <= 0) tol = 1e-13;
     if (max_iters <= 0) max_iters = 500;
 
@@ -401,8 +428,11 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
         DESC_HIP(hipMemcpy(deg.data(), d_deg, sizeof(double) * n, hipMemcpyDeviceToHost));
         for (int64_t v = 0; v < n; ++v) if (!std::isfinite(deg[v])) return fail(DESC_ERR_INVALID, "S_vec holds a negative or non-finite entry (node %lld)", (long long)v);
     } else {
+        if (!weights) {                                     // unit weights: the degree is the CSR row length (no pass over the edges)
+            for (int64_t v = 0; v < n; ++v) deg[v] = (double)(dp->rowptr[v + 1] - dp->rowptr[v]);
+        } else
         for (int64_t e = 0; e < m; ++e) {
-            const double w = weights ? weights[e] : 1.0;
+            const double w = weights[e];
             if (!(w >= 0) || !std::isfinite(w)) return fail(DESC_ERR_INVALID, "weight %lld is not a finite non-negative number", (long long)e);
             deg[dp->ii[e]] += w; deg[dp->jj[e]] += w;
         }
@@ -411,6 +441,7 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
             DESC_HIP(hipMemcpy(d_w, weights, sizeof(double) * m, hipMemcpyHostToDevice));
         }
     }
+    lap("weights + degrees");
     double sigma = 0.0;
     hvec<double> dinv((size_t)n, 1.0);               // D^-1/2
     if (normalize_rows) {
@@ -440,6 +471,7 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
         DESC_HIP(hipDeviceSynchronize());
     }
     DESC_HIP(hipMemcpy(d_Y, X0.data(), sizeof(double) * rows * BW, hipMemcpyHostToDevice));
+    lap("assemble + start block");
 
     hvec<double> part((size_t)ggrid * 2 * BW * BW);
     double G1[BW * BW], G2[BW * BW];
@@ -545,6 +577,7 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
         if ((rc = grams(d_X, d_Y))) return rc;
         jacobi_eig<BW>(G1, theta, Z);
     }
+    lap("subspace iteration");
     SmallMat CZ; std::memcpy(CZ.c, Z, sizeof Z);
     hipLaunchKernelGGL(k_combine, dim3(512), dim3(256), 0, 0, d_X, d_Y, rows, CZ);
     DESC_HIP(hipGetLastError());
@@ -566,11 +599,18 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
         const double sg = det > 0 ? 1.0 : (det < 0 ? -1.0 : 0.0);
         for (int64_t r = 0; r < rows; ++r) V[(size_t)r * 3] *= sg;
     }
-    for (int64_t v = 0; v < n; ++v) {
-        double R[9];
-        project_so3(&V[(size_t)9 * v], R);                   // rows 3v..3v+2 of V = the node's 3x3 block, row-major
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R_out[9 * v + r + 3 * c] = R[r * 3 + c];   // MATLAB column-major 3x3xn
+    {   // per-node SVD projection (Spectral.m:41-46): independent 3x3 problems, host threads for large n
+        unsigned hw = std::thread::hardware_concurrency();
+        const int T = (int)std::min<int64_t>(std::max(1u, std::min(hw, 16u)), std::max<int64_t>(1, n / 512));
+        run_threads(T, [&](int t) {
+            for (int64_t v = n * t / T; v < n * (t + 1) / T; ++v) {
+                double R[9];
+                project_so3(&V[(size_t)9 * v], R);           // rows 3v..3v+2 of V = the node's 3x3 block, row-major
+                for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R_out[9 * v + r + 3 * c] = R[r * 3 + c];   // MATLAB column-major 3x3xn
+            }
+        });
     }
+    lap("normalise + project");
     if (info) {
         info->iters = std::min(it, max_iters);
         info->converged = converged ? 1 : 0;
@@ -595,37 +635,70 @@ extern "C" int desc_debug_spmm_variants(const desc_device_problem* dp, int32_t r
     if (n == 0 || m == 0) return fail(DESC_ERR_INVALID, "empty problem");
     int rc;
     Dev D;
-    double *d_blocks, *d_X, *d_Y1, *d_Y2, *d_dinv, *d_pa, *d_pb, *d_pd;
+    double *d_blocks, *d_X, *d_Y1, *d_Y2, *d_dinv;
     if ((rc = D.alloc(&d_blocks, 18 * m)) || (rc = D.alloc(&d_X, rows * BW)) || (rc = D.alloc(&d_Y1, rows * BW)) || (rc = D.alloc(&d_Y2, rows * BW)) ||
-        (rc = D.alloc(&d_dinv, n)) || (rc = D.alloc(&d_pa, 64)) || (rc = D.alloc(&d_pb, 64)) || (rc = D.alloc(&d_pd, 64))) return rc;
+        (rc = D.alloc(&d_dinv, n))) return rc;
     hvec<double> ones((size_t)n, 1.0), X0((size_t)rows * BW);
     for (size_t t = 0; t < X0.size(); ++t) X0[t] = (double)(int64_t)(mix64(0xC0FFEEull + t) >> 11) / 4503599627370496.0 - 1.0;
     DESC_HIP(hipMemcpy(d_dinv, ones.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     DESC_HIP(hipMemcpy(d_X, X0.data(), sizeof(double) * rows * BW, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_assemble_blocks, dim3((unsigned)std::min<int64_t>(4096, (n + 3) / 4)), dim3(256), 0, 0, dp->d_rowptr, dp->d_adj, dp->d_adj_eid, dp->d_rij,
                        (const double*)nullptr, d_dinv, d_blocks, (int64_t)2 * m, (int)n);
-    // operand layout of v_mfma_f64_4x4x4: exact small integers, eight hypotheses
-    double pa[64], pb[64], pd[64];
-    for (int l = 0; l < 64; ++l) { pa[l] = 1 + (l * 7) % 13; pb[l] = 2 + (l * 5) % 11; }
-    DESC_HIP(hipMemcpy(d_pa, pa, sizeof pa, hipMemcpyHostToDevice));
-    DESC_HIP(hipMemcpy(d_pb, pb, sizeof pb, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_mfma_layout_probe, dim3(1), dim3(64), 0, 0, d_pa, d_pb, d_pd);
-    DESC_HIP(hipMemcpy(pd, d_pd, sizeof pd, hipMemcpyDeviceToHost));
-    int lay = -1;
-    for (int h = 0; h < 8 && lay < 0; ++h) {
-        bool ok = true;
-        for (int l = 0; l < 64 && ok; ++l) {
-            const int g = l >> 4, q = l & 15;
-            const int i = (h & 4) ? (q & 3) : (q >> 2), j = (h & 4) ? (q >> 2) : (q & 3);
-            double e = 0.0;
-            for (int k = 0; k < 4; ++k) {
-                const int la = 16 * g + ((h & 1) ? 4 * k + i : 4 * i + k), lb = 16 * g + ((h & 2) ? 4 * j + k : 4 * k + j);
-                e += pa[la] * pb[lb];
+    // operand layout of v_mfma_f64_4x4x4 from unit-vector probes: lanes of A with the same D footprint share a row i, lanes of B with the
+    // same footprint share a column j, an A lane and a B lane that produce anything share a summation index k
+    int lay_ok = 1;
+    MfmaLayout L{};
+    {
+        unsigned long long* d_rm; unsigned long long* d_cm; unsigned char* d_cp;
+        if ((rc = D.alloc(&d_rm, 64)) || (rc = D.alloc(&d_cm, 64)) || (rc = D.alloc(&d_cp, 4096))) return rc;
+        hipLaunchKernelGGL(k_mfma_layout_probe, dim3(1), dim3(64), 0, 0, d_rm, d_cm, d_cp);
+        unsigned long long rm[64], cm[64]; unsigned char cp[4096];
+        DESC_HIP(hipMemcpy(rm, d_rm, sizeof rm, hipMemcpyDeviceToHost));
+        DESC_HIP(hipMemcpy(cm, d_cm, sizeof cm, hipMemcpyDeviceToHost));
+        DESC_HIP(hipMemcpy(cp, d_cp, sizeof cp, hipMemcpyDeviceToHost));
+        auto label = [](const unsigned long long* mask, int base, signed char* out) {      // classes of equal footprint among lanes base..base+15
+            unsigned long long seen[16]; int ns = 0;
+            for (int q = 0; q < 16; ++q) {
+                int c = -1;
+                for (int t = 0; t < ns; ++t) if (seen[t] == mask[base + q]) c = t;
+                if (c < 0) { if (ns == 16) return 99; seen[ns] = mask[base + q]; c = ns++; }
+                out[q] = (signed char)c;
             }
-            ok = e == pd[l];
+            return ns;
+        };
+        const unsigned long long grp0 = 0xFFFFull;
+        for (int q = 0; q < 16; ++q) if ((rm[q] & ~grp0) || (cm[q] & ~grp0) || !rm[q] || !cm[q]) lay_ok = 0;      // block 0 = lanes 0..15
+        if (lay_ok && (label(rm, 0, L.ai) != 4 || label(cm, 0, L.bj) != 4)) lay_ok = 0;
+        if (lay_ok) {
+            // k of a B lane: its rank among the B lanes of column class 0; k of an A lane: the k of the class-0 B lane it meets
+            int kb = 0; int b_of_k[4] = {-1, -1, -1, -1};
+            for (int q = 0; q < 16; ++q) if (L.bj[q] == 0 && kb < 4) b_of_k[kb++] = q;
+            if (kb != 4) lay_ok = 0;
+            for (int q = 0; q < 16 && lay_ok; ++q) {
+                L.ak[q] = -1;
+                for (int k = 0; k < 4; ++k) if (cp[q * 64 + b_of_k[k]]) L.ak[q] = (signed char)k;
+                if (L.ak[q] < 0) lay_ok = 0;
+            }
+            // k of every B lane: the k of an A lane (row class 0) it meets
+            int a_of_k[4] = {-1, -1, -1, -1};
+            for (int q = 0; q < 16 && lay_ok; ++q) if (L.ai[q] == 0) a_of_k[(int)L.ak[q]] = q;
+            for (int q = 0; q < 16 && lay_ok; ++q) {
+                L.bk[q] = -1;
+                for (int k = 0; k < 4; ++k) if (a_of_k[k] >= 0 && cp[a_of_k[k] * 64 + q]) L.bk[q] = (signed char)k;
+                if (L.bk[q] < 0) lay_ok = 0;
+            }
+            // D lane ld: row class of the A lanes that reach it, column class of the B lanes that reach it
+            for (int ld = 0; ld < 16 && lay_ok; ++ld) {
+                L.di[ld] = L.dj[ld] = -1;
+                for (int q = 0; q < 16; ++q) { if (rm[q] >> ld & 1ull) L.di[ld] = L.ai[q]; if (cm[q] >> ld & 1ull) L.dj[ld] = L.bj[q]; }
+                if (L.di[ld] < 0 || L.dj[ld] < 0) lay_ok = 0;
+            }
+            // the other three blocks must repeat the pattern 16 lanes further on
+            for (int g = 1; g < 4 && lay_ok; ++g)
+                for (int q = 0; q < 16; ++q) if (rm[16 * g + q] != rm[q] << (16 * g) || cm[16 * g + q] != cm[q] << (16 * g)) lay_ok = 0;
         }
-        if (ok) lay = h;
     }
+    const int lay = lay_ok ? 1 : -1;
     const bool wide = 2 * m >= 192 * n;
     const int sgrid = (int)std::min<int64_t>(8192, wide ? n : (n + 3) / 4);
     hipEvent_t e0, e1;
@@ -637,7 +710,7 @@ extern "C" int desc_debug_spmm_variants(const desc_device_problem* dp, int32_t r
                 if (wide) hipLaunchKernelGGL(k_bsr_spmm<256>, dim3(sgrid), dim3(256), 0, 0, dp->d_rowptr, dp->d_adj, d_blocks, (int64_t)2 * m, d_X, d_X, d_Y1, (int)n, 1.0, 0.0, 0.0);
                 else hipLaunchKernelGGL(k_bsr_spmm<64>, dim3(sgrid), dim3(256), 0, 0, dp->d_rowptr, dp->d_adj, d_blocks, (int64_t)2 * m, d_X, d_X, d_Y1, (int)n, 1.0, 0.0, 0.0);
             } else
-                hipLaunchKernelGGL(k_bsr_spmm_mfma, dim3((unsigned)std::min<int64_t>(8192, n)), dim3(256), 0, 0, dp->d_rowptr, dp->d_adj, d_blocks, (int64_t)2 * m, d_X, d_X, d_Y2, (int)n, 1.0, 0.0, 0.0, lay);
+                hipLaunchKernelGGL(k_bsr_spmm_mfma, dim3((unsigned)std::min<int64_t>(8192, n)), dim3(256), 0, 0, dp->d_rowptr, dp->d_adj, d_blocks, (int64_t)2 * m, d_X, d_X, d_Y2, (int)n, 1.0, 0.0, 0.0, L);
         }
         (void)hipEventRecord(e1, 0);
         (void)hipEventSynchronize(e1);
