@@ -30,13 +30,14 @@ __global__ __launch_bounds__(256) void k_cemp_s0(const int32_t* pos_edge, const 
     for (int64_t l = wid; l < m_pos; l += nw) {
         const int e = pos_edge[l], i = ind_i[e], j = ind_j[e];
         double A[9];
-        for (int t = 0; t < 9; ++t) A[t] = rij[9 * (int64_t)e + t];
+        load_block9(rij + 9 * (int64_t)e, A);
         double acc = 0.0;
         for (int s = lane; s < nsample; s += 64) {
             const int64_t c = l * nsample + s;
             const int k = kk[c];
-            const double* pb = rij + 9 * (int64_t)e_jk[c];
-            const double* pc = rij + 9 * (int64_t)e_ki[c];
+            double pb[9], pc[9];                           // the two gathered blocks, in registers (16-byte loads)
+            load_block9(rij + 9 * (int64_t)e_jk[c], pb);
+            load_block9(rij + 9 * (int64_t)e_ki[c], pc);
             const bool tb = !(j < k), tc = !(k < i);
             double tr = 0.0;
             for (int r = 0; r < 3; ++r) {

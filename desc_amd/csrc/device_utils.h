@@ -121,6 +121,16 @@ __device__ __forceinline__ uint64_t d_sample_key(uint64_t seed, uint64_t edge, u
     return d_mix64(a ^ ((k + 1) * 0xD1B54A32D192ED03ull));
 }
 
+// one 72-byte rotation block into registers: four 16-byte loads + one 8-byte load (blocks are 8-byte aligned: 72 e bytes; gfx950
+// serves unaligned 16-byte global loads) instead of nine 8-byte ones -- a gathered block costs the address pipeline one pass per load
+// instruction and lane, so the setup kernels that gather two blocks per cycle (S0_long, DESC_PGD.m:129-147) issue 10 instead of 18
+typedef double dbl2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void load_block9(const double* p, double* o) {
+    const dbl2_a8* q = reinterpret_cast<const dbl2_a8*>(p);
+    const dbl2_a8 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+    o[0] = v0.x; o[1] = v0.y; o[2] = v1.x; o[3] = v1.y; o[4] = v2.x; o[5] = v2.y; o[6] = v3.x; o[7] = v3.y; o[8] = p[8];
+}
+
 // Blocks b and b+8 share an XCD (round-robin dispatch, observed; speed only).
 // Give each XCD a contiguous range of logical blocks so neighbouring edge
 // segments -- which gather each other's cycle weights -- share one L2.

@@ -117,11 +117,12 @@ __device__ __forceinline__ double simplex_threshold(double ws, bool act0, int la
 
 // product-of-three trace in the reference's accumulation order (DESC_PGD.m:137-146)
 __device__ __forceinline__ double cycle_trace(const double* A, const double* pb, bool tb, const double* pc, bool tc) {
-    double B[9], C[9];
+    double Bm[9], Cm[9], B[9], C[9];
+    load_block9(pb, Bm); load_block9(pc, Cm);
     for (int r = 0; r < 3; ++r)
         for (int s = 0; s < 3; ++s) {
-            B[r + 3 * s] = tb ? pb[s + 3 * r] : pb[r + 3 * s];
-            C[r + 3 * s] = tc ? pc[s + 3 * r] : pc[r + 3 * s];
+            B[r + 3 * s] = tb ? Bm[s + 3 * r] : Bm[r + 3 * s];
+            C[r + 3 * s] = tc ? Cm[s + 3 * r] : Cm[r + 3 * s];
         }
     double tr = 0.0;
     for (int r = 0; r < 3; ++r) {
@@ -1039,44 +1040,6 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
             for (int round = 0; round < MAX_SEG_CYCLES / 32; ++round) {
                 uint32_t pv[2 * COLSUM_U]; double wvv[2 * COLSUM_U];
                 bool more = false;
-#if DESC_EXP & 1
-                // the second half (contributing cycles 16..31 of each segment) only where some segment of this wave has that many:
-                // at n_sample / codeg ~ 0.25-0.3 (C4, C5) most segments contribute 8-13 cycles and half of the load and
-                // LDS-add instructions of a batch were issued with every lane off
-                int nacts[COLSUM_U];
-                bool second = false;
-#pragma unroll
-                for (int u = 0; u < COLSUM_U; ++u) {
-                    const int tt = 4 * (g0 + 4 * u) + sub;
-                    nacts[u] = tt < deg ? (seg_cf[tt] & 0x1FF) : 0;
-                    second |= nacts[u] > 32 * round + 16;
-                    more |= nacts[u] > 32 * (round + 1);
-                }
-                const bool any_second = __any(second);
-#pragma unroll
-                for (int u = 0; u < COLSUM_U; ++u) {
-                    const int tt = 4 * (g0 + 4 * u) + sub;
-                    pv[2 * u] = 0xFFFFu; pv[2 * u + 1] = 0xFFFFu; wvv[2 * u] = 0.0; wvv[2 * u + 1] = 0.0;
-                    const int q = l16 + 32 * round;
-                    if (q < nacts[u]) { pv[2 * u] = midx[(size_t)seg_mo[tt] + q]; wvv[2 * u] = w[(int64_t)seg_base[tt] + q]; }
-                }
-                if (any_second) {
-#pragma unroll
-                    for (int u = 0; u < COLSUM_U; ++u) {
-                        const int tt = 4 * (g0 + 4 * u) + sub;
-                        const int q = l16 + 32 * round + 16;
-                        if (q < nacts[u]) { pv[2 * u + 1] = midx[(size_t)seg_mo[tt] + q]; wvv[2 * u + 1] = w[(int64_t)seg_base[tt] + q]; }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < COLSUM_U; ++u)
-                    if (pv[2 * u] != 0xFFFFu) unsafeAtomicAdd(&mine[pv[2 * u]], wvv[2 * u]);          // ds_add_f64
-                if (any_second) {
-#pragma unroll
-                    for (int u = 0; u < COLSUM_U; ++u)
-                        if (pv[2 * u + 1] != 0xFFFFu) unsafeAtomicAdd(&mine[pv[2 * u + 1]], wvv[2 * u + 1]);
-                }
-#else
 #pragma unroll
                 for (int u = 0; u < COLSUM_U; ++u) {
                     const int tt = 4 * (g0 + 4 * u) + sub;
@@ -1098,7 +1061,6 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
 #pragma unroll
                 for (int u = 0; u < 2 * COLSUM_U; ++u)
                     if (pv[u] != 0xFFFFu) unsafeAtomicAdd(&mine[pv[u]], wvv[u]);          // ds_add_f64
-#endif
                 if (!__any(more)) break;
             }
         }

@@ -111,13 +111,11 @@ __global__ __launch_bounds__(256) void k_bsr_spmm(const int32_t* rowptr, const i
 }
 
 // The same product on the f64 matrix cores, for the record ("MFMA: measure, expect HBM/L2-bound"):
-// v_mfma_f64_4x4x4 multiplies four independent 4x4x4 tiles per instruction, one per 16-lane group.  A tile = one CSR slot:
+// v_mfma_f64_4x4x4 multiplies four independent 4x4x4 tiles per instruction, one per group of 16 lanes (which lanes: see k_bsr_spmm_mfma).  A tile = one CSR slot:
 // A = its 3x3 block padded to 4x4, B = rows 0..2 of the operand x[adj] x four of its BW = 6 columns (two instructions per slot for
 // the six columns), D accumulates that 16-lane group's share of y[v].  One lane holds ONE element of A and of B, so a slot costs 16 lanes
 // x 3 loads (9 of the 16 A lanes and 9-12 of the B lanes carry data) against 1 lane x 27 loads in k_bsr_spmm: 1.8x the load lane-operations
-// for 54 useful multiply-adds out of the 128 the two instructions perform.  Which lane of a 16-lane group holds which element of A, B
-// and D is probed at run time with unit vectors (k_mfma_layout_probe) and handed over as a table.
-struct MfmaLayout { signed char ai[16], ak[16], bk[16], bj[16], di[16], dj[16]; };   // per lane of a 16-lane group: element coordinates
+// for 54 useful multiply-adds out of the 128 the two instructions perform.
 // exact probes: unit vectors through the instruction.  rowmask[la] = lanes of D that see A's lane la (b = ones), colmask[lb] = lanes
 // of D that see B's lane lb (a = ones), compat[la][lb] = 1 iff A's lane la and B's lane lb meet in some product (same block, same k)
 __global__ __launch_bounds__(64) void k_mfma_layout_probe(unsigned long long* rowmask, unsigned long long* colmask, unsigned char* compat) {
@@ -139,28 +137,31 @@ __global__ __launch_bounds__(64) void k_mfma_layout_probe(unsigned long long* ro
             if (lane == 0) compat[la * 64 + lb] = mk != 0ull;
         }
 }
+// Operand layout of v_mfma_f64_4x4x4 on gfx950 (found with the probe above, checked against it at every call of
+// desc_debug_spmm_variants): the four tiles are NOT 16-lane groups -- tile y = (lane >> 2) & 3; A: row = lane & 3, k = lane >> 4;
+// B: column = lane & 3, k = lane >> 4; D: row = lane >> 4, column = lane & 3.
 __global__ __launch_bounds__(256) void k_bsr_spmm_mfma(const int32_t* rowptr, const int32_t* adj, const double* blocks, int64_t nslots, const double* x,
-                                                       const double* z, double* y, int n, double alpha, double s1, double s2, MfmaLayout lay) {
-    __shared__ double sh[16][3 * BW];                                // one partial y per 16-lane group
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 4, p = lane & 15;
-    const int ai = lay.ai[p], ak = lay.ak[p], bk = lay.bk[p], bj = lay.bj[p], di = lay.di[p], dj = lay.dj[p];
-    const bool a_on = ai < 3 && ak < 3, b_on = bk < 3;
+                                                       const double* z, double* y, int n, double alpha, double s1, double s2) {
+    __shared__ double sh[16][3 * BW];                                // one partial y per tile (4 waves x 4 tiles)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lx = lane & 3, ty = (lane >> 2) & 3, lr = lane >> 4, tile = 4 * wv + ty;
+    const bool a_on = lx < 3 && lr < 3, b_on = lr < 3;               // A element (row lx, component lr); B element (component lr, column lx)
     for (int v = blockIdx.x; v < n; v += gridDim.x) {
-        double d0 = 0.0, d1 = 0.0;                                   // columns 0..3 and 4..7 (6, 7 unused)
+        double d0 = 0.0, d1 = 0.0;                                   // columns 0..3 and 4..7 (6, 7 unused) of row lr of this tile's partial y
         const int r1 = rowptr[v + 1];
-        for (int t0 = rowptr[v]; t0 < r1; t0 += 16) {                // 16 slots per workgroup step, one per lane group
-            const int t = t0 + grp;
+        for (int t0 = rowptr[v]; t0 < r1; t0 += 16) {                // 16 slots per workgroup step, one per tile
+            const int t = t0 + tile;
             const bool on = t < r1;
             const int tt = on ? t : t0;
             const int u = adj[tt];
-            const double av = (on && a_on) ? blocks[(int64_t)(ai + 3 * ak) * nslots + tt] : 0.0;
-            const double b0 = (on && b_on) ? x[(int64_t)3 * BW * u + bk * BW + bj] : 0.0;
-            const double b1 = (on && b_on && bj < BW - 4) ? x[(int64_t)3 * BW * u + bk * BW + 4 + bj] : 0.0;
+            const double av = (on && a_on) ? blocks[(int64_t)(lx + 3 * lr) * nslots + tt] : 0.0;
+            const double b0 = (on && b_on) ? x[(int64_t)3 * BW * u + lr * BW + lx] : 0.0;
+            const double b1 = (on && b_on && lx < BW - 4) ? x[(int64_t)3 * BW * u + lr * BW + 4 + lx] : 0.0;
             d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b0, d0, 0, 0, 0);
             d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b1, d1, 0, 0, 0);
         }
         __syncthreads();
-        if (di < 3) { sh[grp][di * BW + dj] = d0; if (dj < BW - 4) sh[grp][di * BW + 4 + dj] = d1; }
+        if (lr < 3) { sh[tile][lr * BW + lx] = d0; if (lx < BW - 4) sh[tile][lr * BW + 4 + lx] = d1; }
         __syncthreads();
         if (threadIdx.x < 3 * BW) {
             double tot = 0.0;
@@ -644,10 +645,10 @@ extern "C" int desc_debug_spmm_variants(const desc_device_problem* dp, int32_t r
     DESC_HIP(hipMemcpy(d_X, X0.data(), sizeof(double) * rows * BW, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_assemble_blocks, dim3((unsigned)std::min<int64_t>(4096, (n + 3) / 4)), dim3(256), 0, 0, dp->d_rowptr, dp->d_adj, dp->d_adj_eid, dp->d_rij,
                        (const double*)nullptr, d_dinv, d_blocks, (int64_t)2 * m, (int)n);
-    // operand layout of v_mfma_f64_4x4x4 from unit-vector probes: lanes of A with the same D footprint share a row i, lanes of B with the
-    // same footprint share a column j, an A lane and a B lane that produce anything share a summation index k
+    // operand layout of v_mfma_f64_4x4x4: the unit-vector probes must show exactly the layout k_bsr_spmm_mfma is written for --
+    // A's lane (x, y, r) reaches D's lanes (*, y, x), B's lane (x, y, r) reaches D's lanes (x, y, *), with lane = 16 r + 4 y + x,
+    // and an A lane meets a B lane iff they share the tile y and the summation index r
     int lay_ok = 1;
-    MfmaLayout L{};
     {
         unsigned long long* d_rm; unsigned long long* d_cm; unsigned char* d_cp;
         if ((rc = D.alloc(&d_rm, 64)) || (rc = D.alloc(&d_cm, 64)) || (rc = D.alloc(&d_cp, 4096))) return rc;
@@ -656,46 +657,14 @@ extern "C" int desc_debug_spmm_variants(const desc_device_problem* dp, int32_t r
         DESC_HIP(hipMemcpy(rm, d_rm, sizeof rm, hipMemcpyDeviceToHost));
         DESC_HIP(hipMemcpy(cm, d_cm, sizeof cm, hipMemcpyDeviceToHost));
         DESC_HIP(hipMemcpy(cp, d_cp, sizeof cp, hipMemcpyDeviceToHost));
-        auto label = [](const unsigned long long* mask, int base, signed char* out) {      // classes of equal footprint among lanes base..base+15
-            unsigned long long seen[16]; int ns = 0;
-            for (int q = 0; q < 16; ++q) {
-                int c = -1;
-                for (int t = 0; t < ns; ++t) if (seen[t] == mask[base + q]) c = t;
-                if (c < 0) { if (ns == 16) return 99; seen[ns] = mask[base + q]; c = ns++; }
-                out[q] = (signed char)c;
-            }
-            return ns;
-        };
-        const unsigned long long grp0 = 0xFFFFull;
-        for (int q = 0; q < 16; ++q) if ((rm[q] & ~grp0) || (cm[q] & ~grp0) || !rm[q] || !cm[q]) lay_ok = 0;      // block 0 = lanes 0..15
-        if (lay_ok && (label(rm, 0, L.ai) != 4 || label(cm, 0, L.bj) != 4)) lay_ok = 0;
-        if (lay_ok) {
-            // k of a B lane: its rank among the B lanes of column class 0; k of an A lane: the k of the class-0 B lane it meets
-            int kb = 0; int b_of_k[4] = {-1, -1, -1, -1};
-            for (int q = 0; q < 16; ++q) if (L.bj[q] == 0 && kb < 4) b_of_k[kb++] = q;
-            if (kb != 4) lay_ok = 0;
-            for (int q = 0; q < 16 && lay_ok; ++q) {
-                L.ak[q] = -1;
-                for (int k = 0; k < 4; ++k) if (cp[q * 64 + b_of_k[k]]) L.ak[q] = (signed char)k;
-                if (L.ak[q] < 0) lay_ok = 0;
-            }
-            // k of every B lane: the k of an A lane (row class 0) it meets
-            int a_of_k[4] = {-1, -1, -1, -1};
-            for (int q = 0; q < 16 && lay_ok; ++q) if (L.ai[q] == 0) a_of_k[(int)L.ak[q]] = q;
-            for (int q = 0; q < 16 && lay_ok; ++q) {
-                L.bk[q] = -1;
-                for (int k = 0; k < 4; ++k) if (a_of_k[k] >= 0 && cp[a_of_k[k] * 64 + q]) L.bk[q] = (signed char)k;
-                if (L.bk[q] < 0) lay_ok = 0;
-            }
-            // D lane ld: row class of the A lanes that reach it, column class of the B lanes that reach it
-            for (int ld = 0; ld < 16 && lay_ok; ++ld) {
-                L.di[ld] = L.dj[ld] = -1;
-                for (int q = 0; q < 16; ++q) { if (rm[q] >> ld & 1ull) L.di[ld] = L.ai[q]; if (cm[q] >> ld & 1ull) L.dj[ld] = L.bj[q]; }
-                if (L.di[ld] < 0 || L.dj[ld] < 0) lay_ok = 0;
-            }
-            // the other three blocks must repeat the pattern 16 lanes further on
-            for (int g = 1; g < 4 && lay_ok; ++g)
-                for (int q = 0; q < 16; ++q) if (rm[16 * g + q] != rm[q] << (16 * g) || cm[16 * g + q] != cm[q] << (16 * g)) lay_ok = 0;
+        if (std::getenv("DESC_DEBUG_TIMING"))                  // diagnostics: the raw footprints
+            for (int q = 0; q < 64; ++q) fprintf(stderr, "[desc_amd] mfma probe lane %2d: A -> D %016llx   B -> D %016llx\n", q, rm[q], cm[q]);
+        for (int l = 0; l < 64; ++l) {
+            const int lx = l & 3, ly = (l >> 2) & 3;
+            if (rm[l] != 0xFull << (16 * lx + 4 * ly)) lay_ok = 0;
+            if (cm[l] != 0x0001000100010001ull << (4 * ly + lx)) lay_ok = 0;
+            for (int l2 = 0; l2 < 64; ++l2)
+                if ((cp[l * 64 + l2] != 0) != (((l >> 2) & 3) == ((l2 >> 2) & 3) && (l >> 4) == (l2 >> 4))) lay_ok = 0;
         }
     }
     const int lay = lay_ok ? 1 : -1;
@@ -710,7 +679,7 @@ extern "C" int desc_debug_spmm_variants(const desc_device_problem* dp, int32_t r
                 if (wide) hipLaunchKernelGGL(k_bsr_spmm<256>, dim3(sgrid), dim3(256), 0, 0, dp->d_rowptr, dp->d_adj, d_blocks, (int64_t)2 * m, d_X, d_X, d_Y1, (int)n, 1.0, 0.0, 0.0);
                 else hipLaunchKernelGGL(k_bsr_spmm<64>, dim3(sgrid), dim3(256), 0, 0, dp->d_rowptr, dp->d_adj, d_blocks, (int64_t)2 * m, d_X, d_X, d_Y1, (int)n, 1.0, 0.0, 0.0);
             } else
-                hipLaunchKernelGGL(k_bsr_spmm_mfma, dim3((unsigned)std::min<int64_t>(8192, n)), dim3(256), 0, 0, dp->d_rowptr, dp->d_adj, d_blocks, (int64_t)2 * m, d_X, d_X, d_Y2, (int)n, 1.0, 0.0, 0.0, L);
+                hipLaunchKernelGGL(k_bsr_spmm_mfma, dim3((unsigned)std::min<int64_t>(8192, n)), dim3(256), 0, 0, dp->d_rowptr, dp->d_adj, d_blocks, (int64_t)2 * m, d_X, d_X, d_Y2, (int)n, 1.0, 0.0, 0.0);
         }
         (void)hipEventRecord(e1, 0);
         (void)hipEventSynchronize(e1);

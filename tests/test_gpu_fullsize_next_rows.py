@@ -120,3 +120,20 @@ def test_c2_cemp_against_batched_oracle():
     ref = cemp_oracle_batched(mo.Ind, mo.RijMat, 6, params["reweighting"], 50, seed=7)
     assert np.abs(S - ref).max() < 1e-12
     assert np.mean(np.abs(S - mo.ErrVec)) < 0.03
+
+
+def test_demo_composition_on_the_reference_size():
+    """Demo/compare_algorithms.m:59-99 through the Python mirror (examples/compare_algorithms.py) on BASELINE configs[0]
+    (n = 200, p = 0.5, q = 0.2, sigma = 0.1): Spectral, CEMP + GCW, DESC_init, DESC on one model, aligned and tabulated.
+    The order the reference's paper reports: robust weighting beats the plain spectral estimate, the refinement does not hurt."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("compare_algorithms", os.path.join(root, "examples", "compare_algorithms.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    rows, extra = mod.run(200, 0.5, 0.2, 0.1, seed=0, verbose=False)
+    err = {name: mean for name, mean, _ in rows}
+    assert set(err) == {"Spectral", "CEMP+GCW", "DESC_init", "DESC"}
+    assert err["DESC_init"] < 0.5 * err["Spectral"] and err["CEMP+GCW"] < 0.5 * err["Spectral"]
+    assert err["DESC"] <= err["DESC_init"] + 0.05 and err["DESC"] < 2.0
+    assert extra["mean_abs_err_desc"] < 0.06 and extra["mean_abs_err_cemp"] < 0.06
