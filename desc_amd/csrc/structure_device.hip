@@ -44,6 +44,75 @@ __global__ void k_bitmaps(const int32_t* rowptr, const int32_t* adj, unsigned lo
             atomicOr(&row[adj[t] >> 6], 1ull << (adj[t] & 63));
     }
 }
+// The same bitmaps straight from the edge list (no CSR needed first): two atomic ORs per edge into the L2-resident rows
+__global__ void k_bitmaps_edges(const int32_t* ind_i, const int32_t* ind_j, unsigned long long* bits, int64_t m, int words) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < m; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = ind_i[e], j = ind_j[e];
+        atomicOr(&bits[(size_t)i * words + (j >> 6)], 1ull << (j & 63));
+        atomicOr(&bits[(size_t)j * words + (i >> 6)], 1ull << (i & 63));
+    }
+}
+// degree and number of smaller neighbours of every node, from the bitmaps and their rank table
+__global__ void k_degrees(const unsigned long long* bits, const uint32_t* rank, int32_t* deg, int32_t* low, int n, int words) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const size_t last = (size_t)v * words + (words - 1), own = (size_t)v * words + (v >> 6);
+    deg[v] = (int32_t)(rank[last] + (uint32_t)__popcll(bits[last]));
+    low[v] = (int32_t)(rank[own] + (uint32_t)__popcll(bits[own] & ((1ull << (v & 63)) - 1ull)));
+}
+// rowptr = exclusive scan of deg (n + 1 entries), upstart = exclusive scan of deg - low = id of the first edge (v, .) in the
+// (i,j)-sorted edge list.  One workgroup: n is the number of nodes.
+__global__ __launch_bounds__(1024) void k_scan_rows(const int32_t* deg, const int32_t* low, int32_t* rowptr, int32_t* upstart, int n) {
+    __shared__ int sa[1024], sb[1024];
+    __shared__ int carry_a, carry_b;
+    if (threadIdx.x == 0) { carry_a = 0; carry_b = 0; }
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int v = base + threadIdx.x;
+        const int a = v < n ? deg[v] : 0, b = v < n ? deg[v] - low[v] : 0;
+        sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int xa = threadIdx.x >= d ? sa[threadIdx.x - d] : 0, xb = threadIdx.x >= d ? sb[threadIdx.x - d] : 0;
+            __syncthreads();
+            sa[threadIdx.x] += xa; sb[threadIdx.x] += xb;
+            __syncthreads();
+        }
+        if (v < n) { rowptr[v] = carry_a + sa[threadIdx.x] - a; upstart[v] = carry_b + sb[threadIdx.x] - b; }
+        __syncthreads();
+        if (threadIdx.x == 1023) { carry_a += sa[1023]; carry_b += sb[1023]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rowptr[n] = carry_a;
+}
+// CSR adjacency (neighbours ascending) and the edge id of every slot, from the bitmaps: 16 lanes per node row, lanes over its
+// words.  Slot of neighbour u in row v = rowptr[v] + rank[v][word] + (bits below u in that word); the edge {v,u} is the
+// (position of the larger endpoint among the smaller one's larger neighbours)-th edge of the smaller endpoint: Ind is sorted by (i,j).
+__global__ __launch_bounds__(256) void k_csr_from_bits(const unsigned long long* bits, const uint32_t* rank, const int32_t* rowptr, const int32_t* low,
+                                                       const int32_t* upstart, int32_t* adj, int32_t* adj_eid, int n, int words) {
+    const int l16 = threadIdx.x & 15;
+    const int row0 = (blockIdx.x * 256 + threadIdx.x) >> 4, nrows = (gridDim.x * 256) >> 4;
+    for (int v = row0; v < n; v += nrows) {
+        const int r0 = rowptr[v], lv = low[v], us = upstart[v];
+        for (int w = l16; w < words; w += 16) {
+            unsigned long long x = bits[(size_t)v * words + w];
+            int pos = r0 + (int)rank[(size_t)v * words + w];
+            while (x) {
+                const int u = w * 64 + __ffsll((long long)x) - 1;
+                int e;
+                if (u > v) e = us + (pos - r0 - lv);
+                else {
+                    const size_t wu = (size_t)u * words + (v >> 6);
+                    const int idx = (int)(rank[wu] + (uint32_t)__popcll(bits[wu] & ((1ull << (v & 63)) - 1ull)));     // position of v in row u
+                    e = upstart[u] + (idx - low[u]);
+                }
+                adj[pos] = u; adj_eid[pos] = e;
+                ++pos;
+                x &= x - 1;
+            }
+        }
+    }
+}
 // rank[v][w] = number of neighbours of v in words < w
 __global__ void k_rank(const unsigned long long* bits, uint32_t* rank, int n, int words) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -297,12 +366,6 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
     DESC_HIP(hipSetDevice(device));
     s->n = n; s->m = m; s->dev = device; s->seed = seed;
 
-    // CSR on the host (one pass; Ind is sorted by (i,j), so rows come out ascending)
-    hvec<int32_t> rowptr, adj, adj_eid;
-    build_csr(n, m, prob->ind_i, prob->ind_j, rowptr, adj, adj_eid);
-    s->max_deg = 0;
-    for (int64_t v = 0; v < n; ++v) s->max_deg = std::max(s->max_deg, rowptr[v + 1] - rowptr[v]);
-    lap("host csr");
     // device arrays that outlive this call are owned by the structure object (structure_free_device)
     auto keep = [&](auto** out, size_t count) -> int {
         void* q = nullptr;
@@ -312,30 +375,40 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
     };
     DevBuf D;
     int rc;
-    int32_t *d_codeg, *d_hist;
+    int32_t *d_codeg, *d_hist, *d_deg, *d_low, *d_upstart;
     unsigned long long* d_bits;
     s->words = (int32_t)words;
     if ((rc = keep(&s->d_rowptr, n + 1)) || (rc = keep(&s->d_adj, 2 * m)) || (rc = keep(&s->d_adj_eid, 2 * m)) ||
         (rc = keep(&s->d_ii, m)) || (rc = keep(&s->d_jj, m)) || (rc = D.alloc(&d_codeg, m)) || (rc = D.alloc(&d_hist, n + 1)) ||
+        (rc = D.alloc(&d_deg, n)) || (rc = D.alloc(&d_low, n)) || (rc = D.alloc(&d_upstart, n)) ||
         (rc = keep(&s->d_bits, (size_t)n * words)) || (rc = keep(&s->d_rank, (size_t)n * words))) return rc;
     d_bits = s->d_bits;
     lap("alloc");
-    DESC_HIP(hipMemcpy(s->d_rowptr, rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
-    lap("first memcpy");
+    // The CSR index of the graph is made on the device (round 3; the host pass over the edges and the upload of its 2 x 2m ints
+    // were 7-9 ms of a 200 ms solve at C4): bitmaps from the edge list -> rank table -> degrees -> row starts -> adjacency and edge ids.
     if (m) {
-        DESC_HIP(hipMemcpy(s->d_adj, adj.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(s->d_adj_eid, adj_eid.data(), sizeof(int32_t) * 2 * m, hipMemcpyHostToDevice));
         DESC_HIP(hipMemcpy(s->d_ii, prob->ind_i, sizeof(int32_t) * m, hipMemcpyHostToDevice));
         DESC_HIP(hipMemcpy(s->d_jj, prob->ind_j, sizeof(int32_t) * m, hipMemcpyHostToDevice));
     }
-    s->rowptr_host = std::move(rowptr);               // the solver's host-side plan needs the row starts again
-    lap("alloc+upload");
-    DESC_HIP(hipMemset(d_bits, 0, sizeof(unsigned long long) * (size_t)n * words));
-    DESC_HIP(hipMemset(d_hist, 0, sizeof(int32_t) * (n + 1)));
+    lap("upload Ind");
+    DESC_HIP(hipMemsetAsync(d_bits, 0, sizeof(unsigned long long) * (size_t)n * words, 0));
+    DESC_HIP(hipMemsetAsync(d_hist, 0, sizeof(int32_t) * (n + 1), 0));
+    hvec<int32_t> rowptr((size_t)n + 1, 0);
     if (n > 0) {
-        hipLaunchKernelGGL(k_bitmaps, dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), 0, 0, s->d_rowptr, s->d_adj, d_bits, (int)n, (int)words);
+        if (m) hipLaunchKernelGGL(k_bitmaps_edges, dim3((unsigned)std::min<int64_t>(4096, (m + 255) / 256)), dim3(256), 0, 0, s->d_ii, s->d_jj, d_bits, m, (int)words);
         hipLaunchKernelGGL(k_rank, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_bits, s->d_rank, (int)n, (int)words);
+        hipLaunchKernelGGL(k_degrees, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_bits, s->d_rank, d_deg, d_low, (int)n, (int)words);
+        hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, 0, d_deg, d_low, s->d_rowptr, d_upstart, (int)n);
+        hipLaunchKernelGGL(k_csr_from_bits, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (n * 16 + 255) / 256))), dim3(256), 0, 0,
+                           d_bits, s->d_rank, s->d_rowptr, d_low, d_upstart, s->d_adj, s->d_adj_eid, (int)n, (int)words);
+        DESC_HIP(hipGetLastError());
+        DESC_HIP(hipMemcpy(rowptr.data(), s->d_rowptr, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost));
     }
+    if (rowptr[n] != 2 * m) return fail(DESC_ERR_INVALID, "Ind lists an edge twice (the adjacency holds %lld of %lld entries)", (long long)rowptr[n], (long long)(2 * m));
+    s->max_deg = 0;
+    for (int64_t v = 0; v < n; ++v) s->max_deg = std::max(s->max_deg, rowptr[v + 1] - rowptr[v]);
+    s->rowptr_host = std::move(rowptr);               // the solver's host-side plan needs the row starts again
+    lap("device csr");
     if (m > 0)      // a codegree is at most the smaller degree: max_deg + 1 bins (in LDS up to 8192; n + 1 would push n > 8191 onto global atomics -- 30 ms at n = 10000)
         hipLaunchKernelGGL(k_codeg, dim3((unsigned)std::min<int64_t>(2048, (m + 3) / 4)), dim3(256), 0, 0, s->d_ii, s->d_jj, d_bits, d_codeg, d_hist, m, (int)words,
                            (int)std::min<int64_t>(n + 1, (int64_t)s->max_deg + 1));
