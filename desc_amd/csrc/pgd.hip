@@ -393,9 +393,9 @@ struct NodeSweepArgs {
     const double* S_old;       // Sfull, 2m
     double* S_new;
     const double* Tfull;       // 2m: Tfull[rowptr[v]+t] = sum_k w(v,k; nbr_t), masked; sharded runs: T1, T2 per owned segment
-    int32_t t_seg_lo;          // >= 0: Tfull holds T1 of segment l at l - t_seg_lo and T2 at t_half + l - t_seg_lo (after the reduce-scatter)
-    int32_t t_half;            //       (T1 block, then T2 block: the column-sum pass then writes runs of consecutive positions)
-    double* s_slice;           // sharded runs: the new S of segment l also goes to s_slice[l - t_seg_lo] (this rank's all-gather slice)
+    const int2* xt;            // sharded runs (else NULL): per device-order segment {ta, tb}: Tfull (= the reduce-scattered sums of this rank) holds
+                               // T1 of the segment at ta, T2 at tb (exchange layout: see k_xpos); ta is also its place in the all-gather slice
+    double* s_slice;           // sharded runs: the new S of segment l goes to s_slice[ta] (this rank's all-gather slice)
     const double* nv_tab;
     double* partials;
     const DevState* state;
@@ -461,8 +461,8 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
     if (nk == 0) { block_partials(obj_acc, chg_acc, a.partials, lb); return; }
     if (tid <= MAX_SEG_CYCLES) s_nv[tid] = tid <= a.max_cnt ? a.nv_tab[tid] : 0.0;
 
-    struct RecRaw { int b0, b1; EdgeInfo ei; };
-    struct Rec { int qb, cnt, rbi, rbj, sa, sb, seg; };   // qb: image entry of the segment's first cycle
+    struct RecRaw { int b0, b1; EdgeInfo ei; int2 x; };
+    struct Rec { int qb, cnt, rbi, rbj, sa, sb, seg; };   // qb: image entry of the segment's first cycle; sharded runs: seg = ta, sb = tb
     struct Gat { double sjk[E], ski[E], T1, T2, So; };
     struct Landed { double ss[E], T1, T2, So; };       // S(jk)+S(ki) per cycle, mirror sums, old S of the segment
     struct Carry { StreamRegs s; Landed g; Rec r; };
@@ -473,14 +473,15 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
         const int t = d.l0 + min(ts, d.l1 - d.l0 - 1);
         RecRaw r;
         r.b0 = a.cum[t]; r.b1 = a.cum[t + 1]; r.ei = a.einfo[t];
+        r.x = a.xt ? a.xt[t] : int2{0, 0};
         return r;
     };
     auto land_rec = [&](const ChunkDesc d, const RecRaw q) -> Rec {
         Rec r;
         r.qb = q.b0 - (d.c0 & ~3);
         r.cnt = ts < d.l1 - d.l0 ? q.b1 - q.b0 : 0;
-        r.rbi = q.ei.rb_i; r.rbj = q.ei.rb_j; r.sa = q.ei.slot_a; r.sb = q.ei.slot_b;
-        r.seg = d.l0 + min(ts, d.l1 - d.l0 - 1);
+        r.rbi = q.ei.rb_i; r.rbj = q.ei.rb_j; r.sa = q.ei.slot_a; r.sb = a.xt ? q.x.y : q.ei.slot_b;
+        r.seg = q.x.x;
         return r;
     };
     auto load_stream = [&](const ChunkDesc d) -> StreamRegs {   // 16-byte loads; image entry 0 = cycle a0 = c0 & ~3
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
             if (a.ablate & 16) sj = (int)((p >> 16) & 511u);                            // only the j-row gathers redirected
             g.sjk[e] = a.S_old[sj]; g.ski[e] = a.S_old[si];
         }
-        const int ta = a.t_seg_lo >= 0 ? r.seg - a.t_seg_lo : r.sa, tb = a.t_seg_lo >= 0 ? ta + a.t_half : r.sb;
+        const int ta = a.xt ? r.seg : r.sa, tb = r.sb;
         g.T1 = a.Tfull[ta];                      // column j of node i = sum(wijk(IKJ(mask)))  (:189)
         g.T2 = a.Tfull[tb];                      // column i of node j = sum(wijk(JKI(mask)))  (:190)
         g.So = a.S_old[r.sa];
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
             if (cnt > 0 && r16 == 0) {
                 chg_acc += fabs(part - c.g.So);                                                      // :232
                 // sharded runs: only the all-gather slice is written; k_unpack_S scatters S of every edge, this rank's included
-                if (a.s_slice) a.s_slice[r0.seg - a.t_seg_lo] = part;
+                if (a.s_slice) a.s_slice[r0.seg] = part;
                 else { a.S_new[r0.sa] = part; a.S_new[r0.sb] = part; }
             }
         }
@@ -724,8 +725,8 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
     double obj_acc = 0.0, chg_acc = 0.0;
 
     constexpr bool VREC = SPW > 4;         // eight segments per wave: their records would not fit the SGPRs -- per-lane vector loads instead
-    struct RecRaw { int c0[VREC ? 1 : SPW], c1[VREC ? 1 : SPW]; EdgeInfo ei[VREC ? 1 : SPW]; int t0; };      // wave-uniform (SGPRs); VREC: this lane group's record (VGPRs)
-    struct Rec { int c0, cnt, rbi, rbj, sa, sb, seg; };                   // this lane group's segment
+    struct RecRaw { int c0[VREC ? 1 : SPW], c1[VREC ? 1 : SPW]; EdgeInfo ei[VREC ? 1 : SPW]; int xa[VREC ? 1 : SPW], xb[VREC ? 1 : SPW]; int t0; };      // wave-uniform (SGPRs); VREC: this lane group's record (VGPRs)
+    struct Rec { int c0, cnt, rbi, rbj, sa, sb, seg; };                   // this lane group's segment; sharded runs: seg = ta, sb = tb (exchange positions)
     struct Str { uint32_t pk[E]; double w[E], d[E], am[EA], av[EA]; };     // am / av: HybridGradient.m_t / v_t (Adam only)
     struct Gat { double sj[E], si[E], T1, T2, So; };
 
@@ -741,6 +742,8 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
             if constexpr (VREC) {
                 const int t = min(q.t0 + grp, pd.seg_hi - 1);
                 q.c0[0] = a.cum[t]; q.c1[0] = a.cum[t + 1]; q.ei[0] = a.einfo[t];
+                q.xa[0] = 0; q.xb[0] = 0;
+                if (a.xt) { const int2 x = a.xt[t]; q.xa[0] = x.x; q.xb[0] = x.y; }
                 return q;
             }
 #pragma unroll
@@ -748,6 +751,8 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
                 const int t = min(q.t0 + s2, pd.seg_hi - 1);
                 q.c0[s2] = uniform_load(a.cum, t); q.c1[s2] = uniform_load(a.cum, t + 1);
                 q.ei[s2] = uniform_load_einfo(a.einfo, t);
+                q.xa[s2] = 0; q.xb[s2] = 0;
+                if (a.xt) { q.xa[s2] = uniform_load((const int32_t*)a.xt, 2 * t); q.xb[s2] = uniform_load((const int32_t*)a.xt, 2 * t + 1); }      // wave-uniform branch
             }
             return q;
         };
@@ -755,16 +760,16 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
             Rec r{};
             if constexpr (VREC) {
                 r.c0 = q.c0[0]; r.cnt = q.t0 + grp < pd.seg_hi ? q.c1[0] - q.c0[0] : 0;
-                r.rbi = q.ei[0].rb_i - pd.row_lo; r.rbj = q.ei[0].rb_j; r.sa = q.ei[0].slot_a; r.sb = q.ei[0].slot_b;
-                r.seg = min(q.t0 + grp, pd.seg_hi - 1);
+                r.rbi = q.ei[0].rb_i - pd.row_lo; r.rbj = q.ei[0].rb_j; r.sa = q.ei[0].slot_a; r.sb = a.xt ? q.xb[0] : q.ei[0].slot_b;
+                r.seg = q.xa[0];
                 return r;
             }
 #pragma unroll
             for (int s2 = 0; s2 < SPW; ++s2)
                 if (grp == s2) {
                     r.c0 = q.c0[s2]; r.cnt = q.t0 + s2 < pd.seg_hi ? q.c1[s2] - q.c0[s2] : 0;
-                    r.rbi = q.ei[s2].rb_i - pd.row_lo; r.rbj = q.ei[s2].rb_j; r.sa = q.ei[s2].slot_a; r.sb = q.ei[s2].slot_b;
-                    r.seg = min(q.t0 + s2, pd.seg_hi - 1);
+                    r.rbi = q.ei[s2].rb_i - pd.row_lo; r.rbj = q.ei[s2].rb_j; r.sa = q.ei[s2].slot_a; r.sb = a.xt ? q.xb[s2] : q.ei[s2].slot_b;
+                    r.seg = q.xa[s2];
                 }
             return r;
         };
@@ -789,7 +794,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
                         : a.S_old[((DESC_BAND_ABLATE & 64) ? (r.rbj & 0x1FFFF) : r.rbj) + (int)((p >> 16) & 0x7FFFu)];   // 64: rows confined to 1 MiB (L2 hits)
                 g.si[e] = (DESC_BAND_ABLATE & 16) ? 0.5 : s_rows[r.rbi + (int)(p & 0x7FFFu)];
             }
-            const int ta = a.t_seg_lo >= 0 ? r.seg - a.t_seg_lo : r.sa, tb = a.t_seg_lo >= 0 ? ta + a.t_half : r.sb;
+            const int ta = a.xt ? r.seg : r.sa, tb = r.sb;
             g.T1 = (DESC_BAND_ABLATE & 32) ? 0.25 : a.Tfull[ta];                      // column j of node i = sum(wijk(IKJ(mask)))  (:189)
             g.T2 = (DESC_BAND_ABLATE & 32) ? 0.25 : a.Tfull[tb];                      // column i of node j = sum(wijk(JKI(mask)))  (:190)
             g.So = (DESC_BAND_ABLATE & 16) ? 0.5 : s_rows[r.sa - pd.row_lo];
@@ -876,7 +881,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
                 }
             if (cnt > 0 && rr == 0) {
                 chg_acc += fabs(part - g.So);                                                            // :232
-                if (a.s_slice) a.s_slice[r.seg - a.t_seg_lo] = part;          // sharded: k_unpack_S scatters it (see k_sweep_node)
+                if (a.s_slice) a.s_slice[r.seg] = part;                       // sharded: k_unpack_S copies it into the CSR-aligned replica
                 else { a.S_new[r.sa] = part; a.S_new[r.sb] = part; }
             }
         };
@@ -1281,28 +1286,86 @@ __global__ __launch_bounds__(256) void k_midx_entries(const int2* adj_seg, const
     }
 }
 
-// exchange position of every CSR slot for the sharded runs: slot (v,u) of edge e owned by rank r lands at
-// r*t_part + (q - rank_seg[r]) + (v is the larger endpoint ? t_part/2 : 0), q = device position of e; edges without
-// cycles go to the spare last element
-__global__ __launch_bounds__(256) void k_xpos(const int32_t* rowptr, const int32_t* adj, const int32_t* adj_eid, const int32_t* devpos,
-                                              const int32_t* rank_seg, int world, int64_t t_part, int32_t* xpos, int n) {
+// ---- exchange layout of the sharded runs (round 3) -------------------------------------------------------------------
+// Rank r owns the nodes [node_lo[r], node_lo[r+1]) (whole bands) and with them the edges (i, j), i < j, whose SMALLER endpoint it owns:
+// a contiguous range [e_lo[r], e_lo[r+1]) of the (i,j)-sorted edge list.  Its part of the reduce-scatter buffer (t_part = 2 t_half doubles):
+//   [0, t_half)        T1 of its edges, in edge order            -> node i's column-sum workgroup writes the T1 of ALL its larger
+//                                                                   neighbours as ONE contiguous run (CSR order of row i = edge order)
+//   [t_half, 2 t_half) T2 of its edges, ordered by (j, i)        -> node j's workgroup writes its smaller neighbours' T2 as at most
+//                                                                   `world` contiguous runs (the smaller neighbours owned by one rank
+//                                                                   are consecutive in row j)
+// (round 2 ordered both halves by the sweep's segment order (band, j, i): every rank wrote all 2m slots 8 bytes at a time, +58 us per
+//  iteration at C4 whatever the number of ranks).  The all-gather slice of a rank = S of its edges in edge order, so the unpack copies
+//  the larger-neighbour half of every CSR row contiguously and gathers the other half.
+// prefB[r * n + v] = number of T2 entries of owner r that precede node v's run = sum over v' < v of |{u < v', u owned by r}|
+__device__ __forceinline__ int nbrs_below(const int32_t* adj, int r0, int r1, int x) {       // neighbours of the row smaller than x
+    int lo = 0, hi = r1 - r0;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (adj[r0 + mid] < x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__global__ __launch_bounds__(1024) void k_prefB(const int32_t* rowptr, const int32_t* adj, const int32_t* node_lo, int32_t* prefB, int n) {
+    __shared__ int sa[1024];
+    __shared__ int carry;
+    const int r = blockIdx.x, vlo = node_lo[r], vhi = node_lo[r + 1];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int v = base + threadIdx.x;
+        int c = 0;
+        if (v < n) { const int r0 = rowptr[v], r1 = rowptr[v + 1]; c = nbrs_below(adj, r0, r1, min(vhi, v)) - nbrs_below(adj, r0, r1, min(vlo, v)); }
+        sa[threadIdx.x] = c;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int x = threadIdx.x >= d ? sa[threadIdx.x - d] : 0;
+            __syncthreads();
+            sa[threadIdx.x] += x;
+            __syncthreads();
+        }
+        if (v < n) prefB[(int64_t)r * n + v] = carry + sa[threadIdx.x] - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += sa[1023];
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ int owner_of_node(const int32_t* node_lo, int world, int v) { int r = 0; while (r + 1 < world && v >= node_lo[r + 1]) ++r; return r; }
+// xpos[t]: where the column sum of CSR slot t = (v, u) goes in the send buffer; spos[t]: where S of edge {v, u} sits in the gathered slices
+__global__ __launch_bounds__(256) void k_xpos(const int32_t* rowptr, const int32_t* adj, const int32_t* adj_eid, const int32_t* node_lo, const int32_t* e_lo,
+                                              const int32_t* prefB, int world, int64_t t_part, int64_t slice_len, int32_t* xpos, int32_t* spos, int n) {
     const int l16 = threadIdx.x & 15;
     const int row0 = (blockIdx.x * 256 + threadIdx.x) >> 4, nrows = (gridDim.x * 256) >> 4;
-    for (int v = row0; v < n; v += nrows)
-        for (int t = rowptr[v] + l16; t < rowptr[v + 1]; t += 16) {
-            const int q = devpos[adj_eid[t]];
-            int64_t pos = (int64_t)world * t_part;
-            if (q >= 0) {
-                int r = 0;
-                while (r + 1 < world && q >= rank_seg[r + 1]) ++r;
-                pos = (int64_t)r * t_part + (int64_t)(q - rank_seg[r]) + (v < adj[t] ? 0 : t_part / 2);
+    const int64_t t_half = t_part / 2;
+    for (int v = row0; v < n; v += nrows) {
+        const int r0 = rowptr[v], r1 = rowptr[v + 1];
+        const int rv = owner_of_node(node_lo, world, v);
+        for (int t = r0 + l16; t < r1; t += 16) {
+            const int u = adj[t], e = adj_eid[t];
+            if (u > v) {                                         // T1 of edge (v, u); S of the edge: both with the owner of v
+                xpos[t] = (int32_t)((int64_t)rv * t_part + (e - e_lo[rv]));
+                spos[t] = (int32_t)((int64_t)rv * slice_len + (e - e_lo[rv]));
+            } else {                                             // column u of node v = T2 of edge (u, v), owned by the owner of u
+                const int ru = owner_of_node(node_lo, world, u);
+                const int first = nbrs_below(adj, r0, r1, node_lo[ru]);          // first smaller neighbour of v that ru owns
+                xpos[t] = (int32_t)((int64_t)ru * t_part + t_half + prefB[(int64_t)ru * n + v] + ((t - r0) - first));
+                spos[t] = (int32_t)((int64_t)ru * slice_len + (e - e_lo[ru]));
             }
-            xpos[t] = (int32_t)pos;
         }
+    }
+}
+// {ta, tb} of the segments this rank owns (device order): positions of their T1 / T2 in its part of the exchange buffer
+__global__ __launch_bounds__(256) void k_xt(const int32_t* pos_edge2, const EdgeInfo* einfo, const int32_t* ind_i, const int32_t* ind_j, const int32_t* rowptr,
+                                            const int32_t* adj, const int32_t* node_lo, const int32_t* e_lo, const int32_t* prefB, int rank, int64_t t_half,
+                                            int seg_lo, int seg_hi, int2* xt, int n) {
+    for (int q = seg_lo + blockIdx.x * 256 + threadIdx.x; q < seg_hi; q += gridDim.x * 256) {
+        const int e = pos_edge2[q], j = ind_j[e];
+        const int r0 = rowptr[j], r1 = rowptr[j + 1];
+        const int first = nbrs_below(adj, r0, r1, node_lo[rank]);
+        xt[q] = int2{e - e_lo[rank], (int)(t_half + prefB[(int64_t)rank * n + j] + ((einfo[q].slot_b - r0) - first))};
+        (void)ind_i;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_init_node(const int32_t* cum, const EdgeInfo* einfo, const double* S0,
-                                                   double* w, double* S_a, double* S_b, int m_pos, double* s_slice) {
+                                                   double* w, double* S_a, double* S_b, int m_pos, double* s_slice, const int2* xt) {
     const int lane = threadIdx.x & 63;
     const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * 256) >> 6;
@@ -1315,7 +1378,7 @@ __global__ __launch_bounds__(256) void k_init_node(const int32_t* cum, const Edg
         if (lane == 0) {
             const EdgeInfo ei = einfo[l];
             S_a[ei.slot_a] = s; S_a[ei.slot_b] = s; S_b[ei.slot_a] = s; S_b[ei.slot_b] = s;
-            if (s_slice) s_slice[l] = s;
+            if (s_slice) s_slice[xt[l].x] = s;
         }
     }
 }
@@ -1366,23 +1429,18 @@ __global__ __launch_bounds__(256) void k_reorder_cycles(const int32_t* cum, cons
 // k_unpack_S scatters S of every edge into both of its CSR slots, and its extra last workgroup adds all ranks'
 // partials in rank order (identical sums, hence identical stop decisions, on every rank) and runs the stop rule.
 constexpr int SHARD_PARTS = 512;
-__global__ __launch_bounds__(256) void k_unpack_S(const EdgeInfo* einfo, const int32_t* rank_seg, int world, const double* sall,
-                                                  int64_t slice_len, double* S_a, double* S_b, FinArgs fin) {
+__global__ __launch_bounds__(256) void k_unpack_S(const int32_t* spos, int64_t nslots, const double* sall, double* S_a, double* S_b, FinArgs fin) {
     if (blockIdx.x == gridDim.x - 1) {
         if (fin.t > 0 && threadIdx.x < 64) finalize_wave(fin);
         return;
     }
     // once the stop rule has fired the slices hold the discarded sweep: the double buffers must keep the final iterate
-    if (fin.st->stop) return;
-    for (int r = 0; r < world; ++r) {
-        const int lo = rank_seg[r], hi = rank_seg[r + 1];
-        const double* sl = sall + (int64_t)r * slice_len;
-        for (int t = blockIdx.x * 256 + threadIdx.x; t < hi - lo; t += (gridDim.x - 1) * 256) {
-            const EdgeInfo ei = einfo[lo + t];
-            const double v = sl[t];
-            S_a[ei.slot_a] = v; S_a[ei.slot_b] = v;
-            if (S_b) { S_b[ei.slot_a] = v; S_b[ei.slot_b] = v; }
-        }
+    if (fin.st->stop || !S_a) return;
+    // every CSR slot from its place in the gathered slices: coalesced writes; reads contiguous for the larger-neighbour half of a row
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nslots; t += (int64_t)(gridDim.x - 1) * 256) {
+        const double v = sall[spos[t]];
+        S_a[t] = v;
+        if (S_b) S_b[t] = v;
     }
 }
 
@@ -1459,7 +1517,9 @@ struct desc_pgd {
     hvec<int64_t> rank_seg;      // world+1 segment boundaries
     double* x_T = nullptr;              // caller-bound exchange buffers (device): owner-sorted partial mirror sums (send)
     double* x_Trecv = nullptr;          // reduce-scattered mirror sums of the owned segments
-    int32_t* d_xpos = nullptr;          // 2m: CSR slot -> position in x_T
+    int32_t* d_xpos = nullptr;          // 2m: CSR slot -> position of its column sum in x_T (k_xpos)
+    int32_t* d_spos = nullptr;          // 2m: CSR slot -> position of its edge's S in the gathered slices x_sall
+    int2* d_xt = nullptr;               // m_pos (device order; owned segments filled): {ta, tb} = places of T1 / T2 in x_Trecv, ta also in the slice
     int64_t t_part = 0;
     double* x_sall = nullptr;           //   world * slice_len
     bool borrowed_stream = false, objective_done = false;
@@ -1680,7 +1740,7 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
         h->pending_fin = 0;
         NodeSweepArgs a{};
         a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
-        a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->d_T; a.t_seg_lo = -1; a.nv_tab = h->d_nv; a.partials = h->d_partials;
+        a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->d_T; a.xt = nullptr; a.nv_tab = h->d_nv; a.partials = h->d_partials;
         a.state = h->d_state; a.st = st; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks; a.max_cnt = h->max_cnt; a.ablate = h->ablate;
         launch_sweep_node_layout(h, a, adam);
     } else {
@@ -1838,6 +1898,7 @@ struct NodePlan {
     hvec<int32_t> cum2;        // m_pos+1, device order, global cycle numbering
     hvec<int32_t> chunk_seg;   // nchunks+1
     hvec<int64_t> rank_chunk;  // world+1
+    hvec<int32_t> rank_node;   // world+1: rank r owns the nodes [rank_node[r], rank_node[r+1]) -- whole bands -- and the segments whose smaller endpoint they are
 };
 
 // row_cap > 0: bands = maximal runs of consecutive nodes whose CSR rows hold <= row_cap entries together (the band
@@ -1897,17 +1958,42 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
         const int32_t l = P.order[q];
         P.cum2[q + 1] = P.cum2[q] + (int32_t)(s->cum_ind[l + 1] - s->cum_ind[l]);
     }
+    // Several ranks: a rank owns whole bands (its exchange layout is indexed by node ranges, k_xpos); the cuts go to the band boundaries
+    // that split the cycles most evenly (a band is ~0.4 % of the work at C4), and chunks do not straddle them.
+    hvec<int64_t> cut_seg;                                   // device position of the first segment of every rank, + mp
+    P.rank_node.assign((size_t)world + 1, (int32_t)n);
+    P.rank_node[0] = 0;
+    cut_seg.assign((size_t)world + 1, mp);
+    cut_seg[0] = 0;
+    if (world > 1) {
+        const int64_t total = P.cum2[mp];
+        int64_t b = 0;
+        for (int r = 1; r < world; ++r) {
+            const int64_t want = total * r / world;
+            while (b < nb && (int64_t)P.cum2[P.bstart[b]] < want) ++b;          // first band that starts at or beyond the target
+            if (b > 0 && b <= nb && want - (int64_t)P.cum2[P.bstart[b - 1]] < (int64_t)P.cum2[P.bstart[std::min(b, nb)]] - want && P.bstart[b - 1] > cut_seg[r - 1]) --b;
+            const int64_t bb = std::min(b, nb);
+            cut_seg[r] = std::max<int64_t>(P.bstart[bb], cut_seg[r - 1]);
+            P.rank_node[r] = bb < nb ? P.band_lo[bb] : (int32_t)n;
+            if (P.rank_node[r] < P.rank_node[r - 1]) P.rank_node[r] = P.rank_node[r - 1];
+        }
+    }
     P.chunk_seg.clear();
     P.chunk_seg.push_back(0);
-    for (int64_t q = 0; q < mp;) {     // chunks: <= CHUNK_CAP cycles and <= CHUNK_SEG segments
-        int64_t e = q;
-        while (e < mp && e - q < max_seg && P.cum2[e + 1] - P.cum2[q] <= CHUNK_CAP) ++e;
-        q = e;                          // max_cnt <= MAX_SEG_CYCLES <= CHUNK_CAP: always advances
-        P.chunk_seg.push_back((int32_t)q);
-    }
-    const int64_t nch = (int64_t)P.chunk_seg.size() - 1;
     P.rank_chunk.assign((size_t)world + 1, 0);
-    for (int r = 0; r <= world; ++r) P.rank_chunk[r] = nch * r / world;
+    {
+        int rnext = 1;
+        for (int64_t q = 0; q < mp;) {     // chunks: <= CHUNK_CAP cycles and <= CHUNK_SEG segments
+            while (rnext < world && cut_seg[rnext] <= q) P.rank_chunk[rnext++] = (int64_t)P.chunk_seg.size() - 1;
+            const int64_t stop = rnext < world ? cut_seg[rnext] : mp;
+            int64_t e = q;
+            while (e < stop && e - q < max_seg && P.cum2[e + 1] - P.cum2[q] <= CHUNK_CAP) ++e;
+            q = e;                          // max_cnt <= MAX_SEG_CYCLES <= CHUNK_CAP: always advances
+            P.chunk_seg.push_back((int32_t)q);
+        }
+        const int64_t nch = (int64_t)P.chunk_seg.size() - 1;
+        while (rnext <= world) P.rank_chunk[rnext++] = nch;
+    }
     return DESC_OK;
 }
 
@@ -2039,8 +2125,12 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     h->rank_seg.assign((size_t)h->world + 1, 0);
     int64_t max_local = 0;
     for (int r = 0; r <= h->world; ++r) h->rank_seg[r] = P.chunk_seg[P.rank_chunk[r]];
-    for (int r = 0; r < h->world; ++r) max_local = std::max(max_local, h->rank_seg[r + 1] - h->rank_seg[r]);
-    h->slice_len = max_local + 2 * SHARD_PARTS;     // S of the owned edges, then the workgroup partials (see k_unpack_S)
+    // exchange layout (k_xpos): a rank owns the edges whose smaller endpoint lies in its node range -- a contiguous range of the sorted edge list
+    hvec<int32_t> e_lo((size_t)h->world + 1, (int32_t)m);
+    for (int r = 0; r <= h->world; ++r)
+        e_lo[r] = (int32_t)(std::lower_bound(prob->ind_i, prob->ind_i + m, P.rank_node[r]) - prob->ind_i);
+    for (int r = 0; r < h->world; ++r) max_local = std::max<int64_t>(max_local, e_lo[r + 1] - e_lo[r]);
+    h->slice_len = max_local + 2 * SHARD_PARTS;     // S of the owned edges (edge order), then the workgroup partials (see k_unpack_S)
     h->slice_S = max_local;
     h->t_part = 2 * std::max<int64_t>(max_local, 1);
     const int64_t mcl = h->cyc_hi - h->cyc_lo;            // local cycles
@@ -2138,23 +2228,6 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
             }
     });
     }
-    hvec<int32_t> xpos;                          // host path: exchange positions of the CSR slots (k_xpos on the device path)
-    if (!dev_cycles) {
-        xpos.resize((size_t)2 * m);
-        host_parallel(n, [&](int64_t a, int64_t b) {
-            for (int64_t v = a; v < b; ++v)
-                for (int32_t t = rowptr[v]; t < rowptr[v + 1]; ++t) {
-                    const int32_t q = devpos[adj_eid[t]];
-                    int64_t pos = (int64_t)h->world * h->t_part;
-                    if (q >= 0) {
-                        int r = 0;
-                        while (r + 1 < h->world && q >= h->rank_seg[r + 1]) ++r;
-                        pos = (int64_t)r * h->t_part + (int64_t)(q - h->rank_seg[r]) + (v < adj[t] ? 0 : h->t_part / 2);
-                    }
-                    xpos[t] = (int32_t)pos;
-                }
-        });
-    }
     lap("host pack");
     // chunk tables: all chunks, local cycle numbering
     hvec<ChunkDesc> chunk_desc((size_t)std::max<int64_t>(nch_all, 1));
@@ -2178,6 +2251,8 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     if ((rc = dalloc(h, &h->d_chunk_desc, chunk_desc.size()))) return rc;
     if ((rc = dalloc(h, &h->d_rank_seg, (size_t)h->world + 1))) return rc;
     if ((rc = dalloc(h, &h->d_xpos, 2 * m))) return rc;
+    if ((rc = dalloc(h, &h->d_spos, 2 * m))) return rc;
+    if ((rc = dalloc(h, &h->d_xt, mp))) return rc;
     if (h->band_ok) {
         if ((rc = dalloc(h, &h->d_pieces, pieces.size()))) return rc;
         if ((rc = dalloc(h, &h->d_piece_ptr, piece_ptr.size()))) return rc;
@@ -2236,7 +2311,6 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         if ((rc = upload(h, d_adj_eid, adj_eid.data(), (size_t)2 * m))) return rc;
         if ((rc = upload(h, d_kf, kf.data(), (size_t)mcl))) return rc;
         if ((rc = upload(h, h->d_seg_perm, seg_perm.data(), (size_t)mcl))) return rc;
-        if ((rc = upload(h, h->d_xpos, xpos.data(), (size_t)2 * m))) return rc;
     }
     DESC_HIP(hipStreamSynchronize(h->stream));
     h->ms_upload = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -2299,10 +2373,25 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         }
         hipLaunchKernelGGL(k_adj_seg, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256))), dim3(256), 0, h->stream,
                            h->d_rowptr, d_adj, d_adj_eid, d_devpos, h->d_cum, d_counts, (int)h->seg_lo, (int)h->seg_hi, h->d_adj_seg, (int)n);
-        hipLaunchKernelGGL(k_xpos, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256))), dim3(256), 0, h->stream,
-                           h->d_rowptr, d_adj, d_adj_eid, d_devpos, h->d_rank_seg, h->world, h->t_part, h->d_xpos, (int)n);
         DESC_HIP(hipStreamSynchronize(h->stream));
         dfree(h, d_devpos); dfree(h, d_counts);
+    }
+    {   // exchange layout of the sharded runs (both paths have the CSR index, the edge list and the segment tables on the device by now)
+        int32_t *d_node_lo = nullptr, *d_elo = nullptr, *d_prefB = nullptr;
+        if ((rc = dalloc(h, &d_node_lo, (size_t)h->world + 1)) || (rc = dalloc(h, &d_elo, (size_t)h->world + 1)) || (rc = dalloc(h, &d_prefB, (size_t)h->world * std::max<int64_t>(n, 1)))) return rc;
+        if ((rc = upload(h, d_node_lo, P.rank_node.data(), (size_t)h->world + 1)) || (rc = upload(h, d_elo, e_lo.data(), (size_t)h->world + 1))) return rc;
+        if (n > 0) {
+            const unsigned g16 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256));
+            hipLaunchKernelGGL(k_prefB, dim3(h->world), dim3(1024), 0, h->stream, h->d_rowptr, d_adj, d_node_lo, d_prefB, (int)n);
+            hipLaunchKernelGGL(k_xpos, dim3(g16), dim3(256), 0, h->stream, h->d_rowptr, d_adj, d_adj_eid, d_node_lo, d_elo, d_prefB, h->world, h->t_part, h->slice_len,
+                               h->d_xpos, h->d_spos, (int)n);
+            if (nsl > 0)
+                hipLaunchKernelGGL(k_xt, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (nsl + 255) / 256))), dim3(256), 0, h->stream, d_pos_edge2, h->d_einfo,
+                                   d_ii, d_jj, h->d_rowptr, d_adj, d_node_lo, d_elo, d_prefB, h->rank, h->t_part / 2, (int)h->seg_lo, (int)h->seg_hi, h->d_xt, (int)n);
+        }
+        DESC_HIP(hipStreamSynchronize(h->stream));            // e_lo / rank_node: host sources of the copies
+        DESC_HIP(hipGetLastError());
+        dfree(h, d_node_lo); dfree(h, d_elo); dfree(h, d_prefB);
     }
     {   // the column-index stream of the column-sum pass (needs adj_seg and pk: both complete on the stream by now)
         uint32_t *d_rowsum = nullptr, *d_rowbase = nullptr;
@@ -2516,11 +2605,15 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
         hipLaunchKernelGGL(k_fill, dim3(g), dim3(256), 0, h->stream, h->d_S[0], slen, 1.0);
         hipLaunchKernelGGL(k_fill, dim3(g), dim3(256), 0, h->stream, h->d_S[1], slen, 1.0);
     }
+    if (h->x_sall && h->slice_S > 0) {          // sharded: S of the edges this rank owns, edge order; edges without cycles keep 1 (:148)
+        int g = (int)std::min<int64_t>(1024, (h->slice_S + 255) / 256);
+        hipLaunchKernelGGL(k_fill, dim3(g), dim3(256), 0, h->stream, h->x_sall + (int64_t)h->rank * h->slice_len, h->slice_S, 1.0);
+    }
     if (h->m_pos > 0) {
         int g = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (h->m_pos + 3) / 4));
         if (h->variant == VARIANT_NODE)
             hipLaunchKernelGGL(k_init_node, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_einfo + h->seg_lo, h->d_S0, h->d_w[0], h->d_S[0], h->d_S[1], (int)(h->seg_hi - h->seg_lo),
-                               h->x_sall ? h->x_sall + (int64_t)h->rank * h->slice_len : (double*)nullptr);
+                               h->x_sall ? h->x_sall + (int64_t)h->rank * h->slice_len : (double*)nullptr, h->d_xt + h->seg_lo);
         else
             hipLaunchKernelGGL(k_init, dim3(g), dim3(256), 0, h->stream, h->d_cum, h->d_pos_edge, h->d_S0, h->d_w[0], h->d_S[0], h->d_S[1], (int)h->m_pos);
     }
@@ -2797,9 +2890,9 @@ int shard_enqueue_sweep(desc_pgd* h, hipStream_t st) {
     const StepArgs sa = make_step(h, &adam, rd, wr);
     NodeSweepArgs a{};
     a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
-    a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_Trecv; a.t_seg_lo = (int32_t)h->seg_lo; a.t_half = (int32_t)(h->t_part / 2); a.nv_tab = h->d_nv;
+    a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_Trecv; a.xt = h->d_xt; a.nv_tab = h->d_nv;
     a.s_slice = my_slice(h); a.partials = my_slice(h) + h->slice_S;       // S and the workgroup partials go straight into the slice
-    if (shard_direct(h)) { a.Tfull = h->d_T; a.t_seg_lo = -1; a.s_slice = nullptr; }
+    if (shard_direct(h)) { a.Tfull = h->d_T; a.xt = nullptr; a.s_slice = nullptr; }
     a.state = h->d_state; a.st = sa; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks;
     a.max_cnt = h->max_cnt; a.ablate = 0;
     const hipStream_t keep = h->stream; h->stream = st;
@@ -2811,11 +2904,11 @@ int shard_enqueue_sweep(desc_pgd* h, hipStream_t st) {
 }
 // after the all-gather: S of every edge into the CSR-aligned copy (+ traces and stop rule of sweep t when fin_t > 0)
 int shard_enqueue_unpack(desc_pgd* h, hipStream_t st, double* S_a, double* S_b, int fin_t, int last_only, int /*nparts*/) {
-    const int g = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (h->slice_S + 255) / 256));
+    const int g = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (2 * h->m + 255) / 256));
     // the whole partial area of every slice is added (sweep grids may differ between ranks on tiny problems; unused pairs are zero)
     FinArgs f = fin_args(h, h->x_sall + h->slice_S, SHARD_PARTS, fin_t, last_only);
     f.rank_stride = h->slice_len; f.nranks = h->world;
-    hipLaunchKernelGGL(k_unpack_S, dim3(g + 1), dim3(256), 0, st, h->d_einfo, h->d_rank_seg, S_a ? h->world : 0, h->x_sall, h->slice_len, S_a, S_b, f);
+    hipLaunchKernelGGL(k_unpack_S, dim3(g + 1), dim3(256), 0, st, h->d_spos, (int64_t)2 * h->m, h->x_sall, S_a, S_b, f);
     if (last_only)        // the objective pass filled more pairs than a sweep does: clear this rank's area for further iterations
         DESC_HIP(hipMemsetAsync(my_slice(h) + h->slice_S, 0, sizeof(double) * 2 * SHARD_PARTS, st));
     DESC_HIP(hipGetLastError());
