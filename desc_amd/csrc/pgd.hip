@@ -2058,6 +2058,43 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
         for (int b = 0; b < G; ++b) heap.push_back({0, b});
         auto cmp = [](const std::pair<int64_t, int>& x, const std::pair<int64_t, int>& y) { return x > y; };
         std::make_heap(heap.begin(), heap.end(), cmp);
+        // Band affinity (experiment, DESC_DEBUG_AFFINITY = slack in K cycles, 0 = off): the next unit of a band goes to the workgroup that
+        // took the band's previous unit -- whose LDS still holds the band's rows: the piece is simply extended, no row load -- unless that
+        // workgroup is more than `slack` cycles ahead of the least loaded one.
+        const int64_t aff_slack = (int64_t)env_int("DESC_DEBUG_AFFINITY", 0) * 1024;
+        if (aff_slack > 0) {
+            hvec<int64_t> load((size_t)G, 0);
+            hvec<int> last_wg((size_t)nbands, -1);
+            for (int64_t J = 0; J < nJ; ++J) {
+                const int64_t jlim = (J + 1) * JB;
+                for (int64_t bd = 0; bd < nbands; ++bd) {
+                    int64_t lo = cur[bd]; const int64_t hi = bend[bd];
+                    if (lo >= hi) continue;
+                    int64_t a0 = lo, a1 = hi;
+                    while (a0 < a1) { const int64_t mid = (a0 + a1) >> 1; if (j_of(mid) < jlim) a0 = mid + 1; else a1 = mid; }
+                    const int64_t e = a0;
+                    cur[bd] = e;
+                    while (lo < e) {
+                        int64_t x = lo;
+                        while (x < e && cum2[x + 1] - cum2[lo] <= cap) ++x;
+                        if (x == lo) x = lo + 1;
+                        int wmin = 0;
+                        for (int w = 1; w < G; ++w) if (load[w] < load[wmin]) wmin = w;
+                        const int wl = last_wg[bd];
+                        if (wl >= 0 && load[wl] <= load[wmin] + aff_slack && !per_wg[wl].empty() && per_wg[wl].back().seg_hi == (int32_t)lo &&
+                            per_wg[wl].back().row_lo == P.rowptr[P.band_lo[bd]]) {
+                            per_wg[wl].back().seg_hi = (int32_t)x;                 // same rows, contiguous segments: one longer piece
+                            load[wl] += cum2[x] - cum2[lo];
+                        } else {
+                            per_wg[wmin].push_back(piece_of(bd, lo, x));
+                            load[wmin] += cum2[x] - cum2[lo] + 4096;
+                            last_wg[bd] = wmin;
+                        }
+                        lo = x;
+                    }
+                }
+            }
+        } else
         for (int64_t J = 0; J < nJ; ++J) {
             const int64_t jlim = (J + 1) * JB;
             for (int64_t bd = 0; bd < nbands; ++bd) {
