@@ -1484,6 +1484,7 @@ struct desc_pgd {
     PieceDesc* d_pieces = nullptr;
     int32_t* d_piece_ptr = nullptr;
     hvec<void*> allocs;
+    hvec<void*> uc_allocs;      // uncached blocks (experiment): freed with hipFree, never parked
     // common
     int32_t* d_cum = nullptr;
     double *d_S0 = nullptr, *d_w[2] = {nullptr, nullptr}, *d_S[2] = {nullptr, nullptr};
@@ -1548,12 +1549,26 @@ struct desc_pgd {
 
 namespace {
 
+inline int env_int_early(const char* name) { const char* v = std::getenv(name); return v ? std::atoi(v) : 0; }
 template <class T>
 int dalloc(desc_pgd* h, T** p, size_t count) {
     *p = nullptr;
     void* q = nullptr;
     DESC_HIP(dev_alloc(&q, sizeof(T) * (count > 0 ? count : 1)));
     h->allocs.push_back(q);
+    *p = (T*)q;
+    return DESC_OK;
+}
+// Experiment (DESC_DEBUG_UNCACHED bit mask: 1 weights, 2 S0, 4 packed words): the streamed per-cycle arrays in uncached device memory
+// (MTYPE UC: their lines do not stay in the L2), so that the rows of S the sweep gathers from keep their place there.  Such blocks bypass
+// the block cache (an uncached block must never be handed out as an ordinary one).
+template <class T>
+int dalloc_stream(desc_pgd* h, T** p, size_t count, int bit) {
+    if (!(env_int_early("DESC_DEBUG_UNCACHED") & bit)) return dalloc(h, p, count);
+    *p = nullptr;
+    void* q = nullptr;
+    DESC_HIP(hipExtMallocWithFlags(&q, sizeof(T) * (count > 0 ? count : 1), hipDeviceMallocUncached));
+    h->uc_allocs.push_back(q);
     *p = (T*)q;
     return DESC_OK;
 }
@@ -1570,6 +1585,7 @@ void free_all(desc_pgd* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     for (void* q : h->allocs) dev_free(q);
+    if (!h->uc_allocs.empty()) { (void)hipDeviceSynchronize(); for (void* q : h->uc_allocs) (void)hipFree(q); }
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     for (hipEvent_t e : {h->ev_col, h->ev_rs, h->ev_sw, h->ev_done}) if (e) (void)hipEventDestroy(e);
@@ -2058,10 +2074,13 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
         for (int b = 0; b < G; ++b) heap.push_back({0, b});
         auto cmp = [](const std::pair<int64_t, int>& x, const std::pair<int64_t, int>& y) { return x > y; };
         std::make_heap(heap.begin(), heap.end(), cmp);
-        // Band affinity (experiment, DESC_DEBUG_AFFINITY = slack in K cycles, 0 = off): the next unit of a band goes to the workgroup that
-        // took the band's previous unit -- whose LDS still holds the band's rows: the piece is simply extended, no row load -- unless that
-        // workgroup is more than `slack` cycles ahead of the least loaded one.
-        const int64_t aff_slack = (int64_t)env_int("DESC_DEBUG_AFFINITY", 0) * 1024;
+        // Band affinity (round 3): the next unit of a band goes to the workgroup that took the band's previous unit -- whose LDS still holds
+        // the band's rows: its piece is simply extended, no row load -- unless that workgroup is more than `slack` cycles ahead of the least
+        // loaded one (then plain list scheduling, as in round 2).  Measured (profiles/r03_band_affinity.txt, sweep averages in one call):
+        // C4 3636 -> 1738 pieces, 1183 -> 1148 us (-3 %) at a slack of 16 K cycles (~half a unit); 4 K -1 %, 8 K -2 %, 32 K 0, 64 K +2 %,
+        // 256 K +23 % (the workgroups drift apart in j and lose the L2 locality of the j rows); C5 (529 bands on 256 workgroups: every
+        // workgroup alternates between two bands, little to merge) within noise.  DESC_DEBUG_AFFINITY = slack in K cycles, 0 = off.
+        const int64_t aff_slack = (int64_t)env_int("DESC_DEBUG_AFFINITY", 16) * 1024;
         if (aff_slack > 0) {
             hvec<int64_t> load((size_t)G, 0);
             hvec<int> last_wg((size_t)nbands, -1);
@@ -2271,10 +2290,10 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     for (int64_t t = 0; t < nch_all; ++t)
         chunk_desc[t] = ChunkDesc{cum2[P.chunk_seg[t]] - (int32_t)h->cyc_lo, cum2[P.chunk_seg[t + 1]] - (int32_t)h->cyc_lo, P.chunk_seg[t], P.chunk_seg[t + 1]};
 
-    if ((rc = dalloc(h, &h->d_S0, mcl + 8))) return rc;   // +8: 16-byte tail reads
-    if ((rc = dalloc(h, &h->d_w[0], mcl + 8))) return rc;
-    if ((rc = dalloc(h, &h->d_w[1], mcl + 8))) return rc;
-    if ((rc = dalloc(h, &h->d_pk, mcl + 8))) return rc;
+    if ((rc = dalloc_stream(h, &h->d_S0, mcl + 8, 2))) return rc;   // +8: 16-byte tail reads
+    if ((rc = dalloc_stream(h, &h->d_w[0], mcl + 8, 1))) return rc;
+    if ((rc = dalloc_stream(h, &h->d_w[1], mcl + 8, 1))) return rc;
+    if ((rc = dalloc_stream(h, &h->d_pk, mcl + 8, 4))) return rc;
     if ((rc = dalloc(h, &h->d_seg_perm, mcl))) return rc;
     if ((rc = dalloc(h, &h->d_einfo, mp))) return rc;
     if ((rc = dalloc(h, &h->d_rowptr, n + 1))) return rc;

@@ -61,6 +61,7 @@ hipError_t hipFree(void* p) {
     std::free(p);
     return hipSuccess;
 }
+hipError_t hipExtMallocWithFlags(void** p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { *p = std::calloc(1, bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }

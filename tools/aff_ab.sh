@@ -2,7 +2,7 @@
 # A/B of the band-affinity piece scheduling (DESC_DEBUG_AFFINITY = slack in K cycles; 0 = production list scheduling)
 cd /tmp && export TMPDIR=/tmp
 for wl in "$@"; do
-  for a in 0 16 64 0 256; do
+  for a in $AFF_LIST; do
     export DESC_DEBUG_AFFINITY=$a
     rm -rf /tmp/ab_prof
     DESC_DEBUG_TIMING=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_prof -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 30 --warmup 5 --no-cpu-baseline --no-convergence > /dev/null 2> /tmp/ab_err.txt
