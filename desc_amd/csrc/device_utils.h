@@ -17,6 +17,7 @@ namespace desc {
 
 // device memory through the library's block cache (devmem.hip): same contract as hipMalloc / hipFree
 hipError_t dev_alloc(void** out, size_t bytes);
+hipError_t dev_alloc_uncached(void** out, size_t bytes);      // MTYPE UC block (same cache, never handed out as an ordinary one)
 void dev_free(void* p);
 
 // One DPP-moved copy of a double (two 32-bit v_mov_b32_dpp).  All four controls used

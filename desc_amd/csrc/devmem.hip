@@ -14,7 +14,7 @@
 
 namespace desc {
 namespace {
-struct Block { void* p; size_t bytes; int dev; };
+struct Block { void* p; size_t bytes; int dev; bool uc; };      // uc: uncached device memory (hipDeviceMallocUncached): only ever handed out as such
 std::mutex g_mu;
 std::vector<Block> g_parked;                         // released blocks waiting for reuse
 std::unordered_map<void*, Block> g_live;             // blocks handed out
@@ -25,7 +25,12 @@ size_t cache_cap() {
 }
 }  // namespace
 
-hipError_t dev_alloc(void** out, size_t bytes) {
+static hipError_t dev_alloc_impl(void** out, size_t bytes, bool uc);
+hipError_t dev_alloc(void** out, size_t bytes) { return dev_alloc_impl(out, bytes, false); }
+// Uncached device memory (MTYPE UC): loads and stores of such a block do not leave their lines in the L2.  For arrays a kernel streams
+// through exactly once per launch next to data it gathers from repeatedly (pgd.hip: S0 and the packed words of the band sweep).
+hipError_t dev_alloc_uncached(void** out, size_t bytes) { return dev_alloc_impl(out, bytes, true); }
+static hipError_t dev_alloc_impl(void** out, size_t bytes, bool uc) {
     *out = nullptr;
     if (bytes == 0) bytes = 8;
     bytes = (bytes + 255) & ~(size_t)255;
@@ -37,7 +42,7 @@ hipError_t dev_alloc(void** out, size_t bytes) {
         size_t best = (size_t)-1; size_t bi = 0;
         for (size_t i = 0; i < g_parked.size(); ++i) {
             const Block& b = g_parked[i];
-            if (b.dev == dev && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 + 4096 && b.bytes < best) { best = b.bytes; bi = i; }
+            if (b.dev == dev && b.uc == uc && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 + 4096 && b.bytes < best) { best = b.bytes; bi = i; }
         }
         if (best != (size_t)-1) {
             const Block b = g_parked[bi];
@@ -49,15 +54,16 @@ hipError_t dev_alloc(void** out, size_t bytes) {
         }
     }
     void* p = nullptr;
-    e = hipMalloc(&p, bytes);
+    auto raw = [&]() { return uc ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) : hipMalloc(&p, bytes); };
+    e = raw();
     if (e != hipSuccess) {                            // make room: give the parked blocks back and try once more
         (void)hipGetLastError();
         desc_trim_memory();
-        e = hipMalloc(&p, bytes);
+        e = raw();
         if (e != hipSuccess) return e;
     }
     std::lock_guard<std::mutex> lk(g_mu);
-    g_live[p] = Block{p, bytes, dev};
+    g_live[p] = Block{p, bytes, dev, uc};
     *out = p;
     return hipSuccess;
 }

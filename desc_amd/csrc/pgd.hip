@@ -876,6 +876,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
             for (int e = 0; e < E; ++e)
                 if ((okm >> e) & 1u) {
                     if (DESC_BAND_ABLATE & 256) __builtin_nontemporal_store(ws[e], &a.w_new[(int64_t)r.c0 + rr + LPS * e]);
+                    else if (DESC_EXP & 1) __hip_atomic_store(&a.w_new[(int64_t)r.c0 + rr + LPS * e], ws[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through, the line leaves the L2
                     else a.w_new[(int64_t)r.c0 + rr + LPS * e] = ws[e];
                     if (ADAM) { a.st.adam_m_out[(int64_t)r.c0 + rr + LPS * e] = mo[e % EA]; a.st.adam_v_out[(int64_t)r.c0 + rr + LPS * e] = vo[e % EA]; }
                 }
@@ -1484,7 +1485,7 @@ struct desc_pgd {
     PieceDesc* d_pieces = nullptr;
     int32_t* d_piece_ptr = nullptr;
     hvec<void*> allocs;
-    hvec<void*> uc_allocs;      // uncached blocks (experiment): freed with hipFree, never parked
+    int uc_default = 0;         // which streamed arrays go to uncached memory (dalloc_stream)
     // common
     int32_t* d_cum = nullptr;
     double *d_S0 = nullptr, *d_w[2] = {nullptr, nullptr}, *d_S[2] = {nullptr, nullptr};
@@ -1549,7 +1550,6 @@ struct desc_pgd {
 
 namespace {
 
-inline int env_int_early(const char* name) { const char* v = std::getenv(name); return v ? std::atoi(v) : 0; }
 template <class T>
 int dalloc(desc_pgd* h, T** p, size_t count) {
     *p = nullptr;
@@ -1559,16 +1559,21 @@ int dalloc(desc_pgd* h, T** p, size_t count) {
     *p = (T*)q;
     return DESC_OK;
 }
-// Experiment (DESC_DEBUG_UNCACHED bit mask: 1 weights, 2 S0, 4 packed words): the streamed per-cycle arrays in uncached device memory
-// (MTYPE UC: their lines do not stay in the L2), so that the rows of S the sweep gathers from keep their place there.  Such blocks bypass
-// the block cache (an uncached block must never be handed out as an ordinary one).
+// The arrays the band sweep streams through exactly once per launch and never writes -- S0 (8 B per cycle) and the packed words (4 B) --
+// live in UNCACHED device memory (MTYPE UC; devmem.hip): their lines do not stay in the L2, where the rows of S the sweep gathers from then
+// keep their place.  Measured (profiles/r03_uncached_streams.txt, rocprofv3 sweep averages in one call): C4 1170 -> 1130 us (-3.4 %); the
+// weights too (read, written, read again by the column sums): +17 %, not done; C5 / C2 / C3: see the file.  DESC_DEBUG_UNCACHED overrides
+// the mask (1 weights, 2 S0, 4 packed words, 8 the column-index stream of the column sums, 16 their slot records; default 6 on graphs
+// whose S does not fit the L2s, else 0).
 template <class T>
 int dalloc_stream(desc_pgd* h, T** p, size_t count, int bit) {
-    if (!(env_int_early("DESC_DEBUG_UNCACHED") & bit)) return dalloc(h, p, count);
+    const char* ev = std::getenv("DESC_DEBUG_UNCACHED");
+    const int mask = ev ? std::atoi(ev) : h->uc_default;
+    if (!(mask & bit)) return dalloc(h, p, count);
     *p = nullptr;
     void* q = nullptr;
-    DESC_HIP(hipExtMallocWithFlags(&q, sizeof(T) * (count > 0 ? count : 1), hipDeviceMallocUncached));
-    h->uc_allocs.push_back(q);
+    DESC_HIP(dev_alloc_uncached(&q, sizeof(T) * (count > 0 ? count : 1)));
+    h->allocs.push_back(q);
     *p = (T*)q;
     return DESC_OK;
 }
@@ -1585,7 +1590,6 @@ void free_all(desc_pgd* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     for (void* q : h->allocs) dev_free(q);
-    if (!h->uc_allocs.empty()) { (void)hipDeviceSynchronize(); for (void* q : h->uc_allocs) (void)hipFree(q); }
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     for (hipEvent_t e : {h->ev_col, h->ev_rs, h->ev_sw, h->ev_done}) if (e) (void)hipEventDestroy(e);
@@ -2290,6 +2294,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     for (int64_t t = 0; t < nch_all; ++t)
         chunk_desc[t] = ChunkDesc{cum2[P.chunk_seg[t]] - (int32_t)h->cyc_lo, cum2[P.chunk_seg[t + 1]] - (int32_t)h->cyc_lo, P.chunk_seg[t], P.chunk_seg[t + 1]};
 
+    h->uc_default = (h->band_ok && (int64_t)2 * m * 8 > (12ll << 20)) ? 6 : 0;      // S beyond the L2s: S0 and the packed words in uncached memory (dalloc_stream)
     if ((rc = dalloc_stream(h, &h->d_S0, mcl + 8, 2))) return rc;   // +8: 16-byte tail reads
     if ((rc = dalloc_stream(h, &h->d_w[0], mcl + 8, 1))) return rc;
     if ((rc = dalloc_stream(h, &h->d_w[1], mcl + 8, 1))) return rc;
@@ -2297,7 +2302,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     if ((rc = dalloc(h, &h->d_seg_perm, mcl))) return rc;
     if ((rc = dalloc(h, &h->d_einfo, mp))) return rc;
     if ((rc = dalloc(h, &h->d_rowptr, n + 1))) return rc;
-    if ((rc = dalloc(h, &h->d_adj_seg, 2 * m))) return rc;
+    if ((rc = dalloc_stream(h, &h->d_adj_seg, 2 * m, 16))) return rc;
     if ((rc = dalloc(h, &h->d_src_start, mp))) return rc;
     if ((rc = dalloc(h, &h->d_eslot, m))) return rc;
     if ((rc = dalloc(h, &h->d_S[0], 2 * m))) return rc;
@@ -2451,7 +2456,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     }
     {   // the column-index stream of the column-sum pass (needs adj_seg and pk: both complete on the stream by now)
         uint32_t *d_rowsum = nullptr, *d_rowbase = nullptr;
-        if ((rc = dalloc(h, &d_rowsum, n)) || (rc = dalloc(h, &d_rowbase, n)) || (rc = dalloc(h, &h->d_moff, 2 * m))) return rc;
+        if ((rc = dalloc(h, &d_rowsum, n)) || (rc = dalloc(h, &d_rowbase, n)) || (rc = dalloc_stream(h, &h->d_moff, 2 * m, 16))) return rc;
         const unsigned g16 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256));
         hipLaunchKernelGGL(k_midx_rowsum, dim3(g16), dim3(256), 0, h->stream, h->d_rowptr, h->d_adj_seg, d_rowsum, (int)n);
         hvec<uint32_t> rs((size_t)n), rb((size_t)n);
@@ -2460,7 +2465,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         uint64_t tot = 0;
         for (int64_t v = 0; v < n; ++v) { rb[v] = (uint32_t)tot; tot += rs[v]; }
         if (tot >= (1ull << 32)) return fail(DESC_ERR_TOO_LARGE, "column-index stream exceeds 2^32 entries");
-        if ((rc = dalloc(h, &h->d_midx, (size_t)tot + 8))) return rc;
+        if ((rc = dalloc_stream(h, &h->d_midx, (size_t)tot + 8, 8))) return rc;
         if ((rc = upload(h, d_rowbase, rb.data(), (size_t)n))) return rc;
         hipLaunchKernelGGL(k_midx_fill, dim3(g16), dim3(256), 0, h->stream, h->d_rowptr, h->d_adj_seg, d_rowbase, h->d_moff, (int)n);
         hipLaunchKernelGGL(k_midx_entries, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, (2 * m * 16 + 255) / 256))), dim3(256), 0, h->stream,

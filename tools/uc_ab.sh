@@ -2,7 +2,7 @@
 # streamed arrays in uncached device memory (DESC_DEBUG_UNCACHED bit mask: 1 weights, 2 S0, 4 packed words) vs ordinary
 cd /tmp && export TMPDIR=/tmp
 for wl in "$@"; do
-  for u in 0 7 1 6 0; do
+  for u in $UC_LIST; do
     export DESC_DEBUG_UNCACHED=$u
     rm -rf /tmp/ab_prof
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_prof -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 30 --warmup 5 --no-cpu-baseline --no-convergence > /dev/null 2>&1
