@@ -876,7 +876,6 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
             for (int e = 0; e < E; ++e)
                 if ((okm >> e) & 1u) {
                     if (DESC_BAND_ABLATE & 256) __builtin_nontemporal_store(ws[e], &a.w_new[(int64_t)r.c0 + rr + LPS * e]);
-                    else if (DESC_EXP & 1) __hip_atomic_store(&a.w_new[(int64_t)r.c0 + rr + LPS * e], ws[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through, the line leaves the L2
                     else a.w_new[(int64_t)r.c0 + rr + LPS * e] = ws[e];
                     if (ADAM) { a.st.adam_m_out[(int64_t)r.c0 + rr + LPS * e] = mo[e % EA]; a.st.adam_v_out[(int64_t)r.c0 + rr + LPS * e] = vo[e % EA]; }
                 }
