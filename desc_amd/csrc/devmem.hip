@@ -60,6 +60,11 @@ static hipError_t dev_alloc_impl(void** out, size_t bytes, bool uc) {
         (void)hipGetLastError();
         desc_trim_memory();
         e = raw();
+        if (e != hipSuccess && uc) {                  // no uncached memory to be had: an ordinary block does the same job, slower
+            (void)hipGetLastError();
+            uc = false;
+            e = hipMalloc(&p, bytes);
+        }
         if (e != hipSuccess) return e;
     }
     std::lock_guard<std::mutex> lk(g_mu);
