@@ -1063,9 +1063,22 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
                         }
                     }
                 }
+#ifdef DESC_COLSUM_ORDERED
+                // Order-explicit form (build with -DDESC_COLSUM_ORDERED): the four segments of an instruction add one after the other.  Third
+                // vertices are distinct inside a segment, so a 16-lane group never hits one column twice; two groups of one instruction may, and
+                // the production form below then relies on the LDS unit resolving same-address lanes of one ds_add_f64 in a fixed order (observed:
+                // the full-size tests compare two runs bit for bit).  Measured cost of the explicit form: column sums +7 % at C4, +10 % at C2
+                // (profiles/r03_experiments.txt), i.e. ~1.2 % of an iteration: not the default.
+#pragma unroll
+                for (int u = 0; u < 2 * COLSUM_U; ++u)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+                        if (sub == s4 && pv[u] != 0xFFFFu) unsafeAtomicAdd(&mine[pv[u]], wvv[u]);
+#else
 #pragma unroll
                 for (int u = 0; u < 2 * COLSUM_U; ++u)
                     if (pv[u] != 0xFFFFu) unsafeAtomicAdd(&mine[pv[u]], wvv[u]);          // ds_add_f64
+#endif
                 if (!__any(more)) break;
             }
         }
