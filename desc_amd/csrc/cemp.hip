@@ -170,14 +170,7 @@ extern "C" int desc_cemp_run_dev(const desc_device_problem* dp, const double* be
     const int64_t mc = mp * nsample;
     DevC D;
     const int32_t *d_ii = dp->d_ii, *d_jj = dp->d_jj; const double* d_rij = dp->d_rij; double *d_S0, *d_S[2];
-    {   // S0Mat is streamed once per round next to the random gathers of S: uncached memory (see build_cemp_samples_device)
-        const char* ucenv = std::getenv("DESC_DEBUG_UNCACHED");
-        const bool uc = ucenv ? (std::atoi(ucenv) & 64) != 0 : true;
-        void* q = nullptr;
-        DESC_HIP(uc ? dev_alloc_uncached(&q, sizeof(double) * (mc ? mc : 1)) : dev_alloc(&q, sizeof(double) * (mc ? mc : 1)));
-        D.p.push_back(q); d_S0 = (double*)q;
-    }
-    if ((rc = D.alloc(&d_S[0], m)) || (rc = D.alloc(&d_S[1], m))) return rc;
+    if ((rc = D.alloc(&d_S0, mc)) || (rc = D.alloc(&d_S[0], m)) || (rc = D.alloc(&d_S[1], m))) return rc;
     if (m) {
         const int g = (int)std::min<int64_t>(1024, (m + 255) / 256);
         hipLaunchKernelGGL(k_fill1, dim3(g), dim3(256), 0, 0, d_S[0], m, 1.0);     // SVec(~IndPosbin) = 1 (:103)

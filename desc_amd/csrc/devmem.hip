@@ -2,7 +2,8 @@
 // megabytes to gigabytes) costs 5-15 ms per solve in page-table work, hipMalloc of the same sizes again on the next call; a
 // MATLAB / Python session calls DESC_PGD many times on problems of the same shape.  Blocks are therefore parked on release and
 // handed out again (best fit, at most 25 % larger than asked) instead of going back to the driver, up to DESC_CACHE_MB
-// (default 8192) per process; desc_trim_memory() returns everything parked to the driver.
+// (default 8192, at most a quarter of the device memory; 0 = off) per process; desc_trim_memory() returns everything parked to the driver
+// (the MEX shims register it with mexAtExit).
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
@@ -19,8 +20,16 @@ std::mutex g_mu;
 std::vector<Block> g_parked;                         // released blocks waiting for reuse
 std::unordered_map<void*, Block> g_live;             // blocks handed out
 size_t g_parked_bytes = 0;
+// DESC_CACHE_MB if set (0 = park nothing); else 8 GiB but never more than a quarter of the device's memory: the card is shared with
+// the other libraries of the process (PyTorch in the sharded driver, other toolboxes in a MATLAB session) and with other ranks' processes.
 size_t cache_cap() {
-    static size_t cap = [] { const char* e = std::getenv("DESC_CACHE_MB"); return (size_t)(e ? std::atoll(e) : 8192) << 20; }();
+    static size_t cap = [] {
+        if (const char* e = std::getenv("DESC_CACHE_MB")) return (size_t)std::atoll(e) << 20;
+        size_t fr = 0, tot = 0;
+        size_t c = (size_t)8192 << 20;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) c = std::min(c, tot / 4); else (void)hipGetLastError();
+        return c;
+    }();
     return cap;
 }
 }  // namespace

@@ -538,17 +538,13 @@ int build_cemp_samples_device(const desc_device_problem* dp, int32_t nsample, ui
     if (max_codeg > 4 * MAX_CODEG_LDS) return fail(DESC_ERR_TOO_LARGE, "an edge has %d common neighbours: host sampler", max_codeg);
     *m_pos = mp;
     if (mp == 0) return DESC_OK;
-    // the per-sample arrays are streamed once per CEMP round next to the random gathers of S: uncached memory keeps them out of the L2
-    // (DESC_DEBUG_UNCACHED bit 64 = 0 turns it off: experiment switch of round 3)
-    const char* ucenv = getenv("DESC_DEBUG_UNCACHED");
-    const bool uc = ucenv ? (atoi(ucenv) & 64) != 0 : true;
-    auto keep = [&](int32_t** out, size_t count, bool stream = false) -> int {
+    auto keep = [&](int32_t** out, size_t count) -> int {
         void* q = nullptr;
-        DESC_HIP((stream && uc) ? dev_alloc_uncached(&q, sizeof(int32_t) * (count ? count : 1)) : dev_alloc(&q, sizeof(int32_t) * (count ? count : 1)));
+        DESC_HIP(dev_alloc(&q, sizeof(int32_t) * (count ? count : 1)));
         *out = (int32_t*)q;
         return DESC_OK;
     };
-    if ((rc = keep(o_pos, mp)) || (rc = keep(o_k, mc, true)) || (rc = keep(o_ejk, mc, true)) || (rc = keep(o_eki, mc, true))) {
+    if ((rc = keep(o_pos, mp)) || (rc = keep(o_k, mc)) || (rc = keep(o_ejk, mc)) || (rc = keep(o_eki, mc))) {
         for (int32_t** q : {o_pos, o_k, o_ejk, o_eki}) { if (*q) dev_free(*q); *q = nullptr; }
         return rc;
     }

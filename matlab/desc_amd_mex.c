@@ -43,7 +43,13 @@ static mxArray* rotations(int64_t n) {
     return mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
 }
 
+/* the library parks device and host blocks between calls (DESC_CACHE_MB / DESC_HOST_CACHE_MB): give them back when MATLAB
+ * clears the MEX file or exits */
+static void release_parked_blocks(void) { (void)desc_trim_memory(); }
+static int at_exit_registered = 0;
+
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    if (!at_exit_registered) { mexAtExit(release_parked_blocks); at_exit_registered = 1; }
     char cmd[32];
     if (nrhs < 3 || mxGetString(prhs[0], cmd, sizeof cmd)) mexErrMsgIdAndTxt("desc_amd:cmd", "first argument: 'spectral' | 'gcw' | 'cemp' | 'refine' | 'desc'");
     desc_problem prob;

@@ -32,7 +32,13 @@ static double field_or(const mxArray* s, const char* name, double dflt) {
     return (f && !mxIsEmpty(f)) ? mxGetScalar(f) : dflt;
 }
 
+/* the library parks device and host blocks between calls (DESC_CACHE_MB / DESC_HOST_CACHE_MB): give them back when MATLAB
+ * clears the MEX file or exits */
+static void release_parked_blocks(void) { (void)desc_trim_memory(); }
+static int at_exit_registered = 0;
+
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    if (!at_exit_registered) { mexAtExit(release_parked_blocks); at_exit_registered = 1; }
     if (nrhs < 3) mexErrMsgIdAndTxt("desc_amd:nargin", "usage: desc_pgd_mex(Ind0, RijMat, opt, adam_m, adam_v)");
     if (!mxIsInt32(prhs[0]) || mxGetN(prhs[0]) != 2) mexErrMsgIdAndTxt("desc_amd:Ind", "Ind0 must be m x 2 int32");
     const mwSize m = mxGetM(prhs[0]);
