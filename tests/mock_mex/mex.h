@@ -36,5 +36,6 @@ void mxSetN(mxArray*, mwSize);
 int mxSetDimensions(mxArray*, const mwSize*, mwSize);
 void mexErrMsgIdAndTxt(const char*, const char*, ...);
 int mexPrintf(const char*, ...);
+int mexAtExit(void (*exit_fcn)(void));
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]);
 #endif
