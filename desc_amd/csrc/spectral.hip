@@ -353,14 +353,6 @@ struct Dev {
         p.push_back(q); *out = (T*)q;
         return DESC_OK;
     }
-    template <class T> int alloc_stream(T** out, size_t count) {       // read once per kernel next to gathered data: uncached unless switched off
-        const char* ev = std::getenv("DESC_DEBUG_UNCACHED");
-        if (ev && !(std::atoi(ev) & 128)) return alloc(out, count);
-        void* q = nullptr;
-        DESC_HIP(dev_alloc_uncached(&q, sizeof(T) * (count ? count : 1)));
-        p.push_back(q); *out = (T*)q;
-        return DESC_OK;
-    }
 };
 
 }  // namespace
@@ -467,7 +459,7 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
     Dev D;
     const int32_t *d_rowptr = dp->d_rowptr, *d_adj = dp->d_adj; double *d_blocks, *d_X, *d_Y, *d_part;
     const int ggrid = 256;
-    if ((rc = D.alloc_stream(&d_blocks, 18 * m)) ||
+    if ((rc = D.alloc(&d_blocks, 18 * m)) ||
         (rc = D.alloc(&d_X, rows * BW)) || (rc = D.alloc(&d_Y, rows * BW)) || (rc = D.alloc(&d_part, (size_t)ggrid * 2 * BW * BW))) return rc;
     if (m) {
         Dev T;                                               // assembly inputs, released before the iteration starts
@@ -645,7 +637,7 @@ extern "C" int desc_debug_spmm_variants(const desc_device_problem* dp, int32_t r
     int rc;
     Dev D;
     double *d_blocks, *d_X, *d_Y1, *d_Y2, *d_dinv;
-    if ((rc = D.alloc_stream(&d_blocks, 18 * m)) || (rc = D.alloc(&d_X, rows * BW)) || (rc = D.alloc(&d_Y1, rows * BW)) || (rc = D.alloc(&d_Y2, rows * BW)) ||
+    if ((rc = D.alloc(&d_blocks, 18 * m)) || (rc = D.alloc(&d_X, rows * BW)) || (rc = D.alloc(&d_Y1, rows * BW)) || (rc = D.alloc(&d_Y2, rows * BW)) ||
         (rc = D.alloc(&d_dinv, n))) return rc;
     hvec<double> ones((size_t)n, 1.0), X0((size_t)rows * BW);
     for (size_t t = 0; t < X0.size(); ++t) X0[t] = (double)(int64_t)(mix64(0xC0FFEEull + t) >> 11) / 4503599627370496.0 - 1.0;

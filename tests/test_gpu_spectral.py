@@ -83,3 +83,20 @@ def test_gcw_on_device_problem_matches_dense_oracle(oracle):
     assert aligned_diff(Rs, spectral_oracle(mo.Ind, mo.RijMat))[0] < 1e-8
     R_host = GCW(mo.Ind, mo.AdjMat, mo.RijMat, S)
     assert aligned_diff(R, R_host)[0] < 1e-10
+
+
+def test_block_spmm_forms_agree():
+    """The block SpMM of the connection matrix (Spectral.m:27-37 as a sparse product) in its two device forms -- vector FMA
+    (production) and v_mfma_f64_4x4x4 (measurement variant) -- on the same operand: equal to summation-order
+    round-off; the MFMA operand layout the variant is written for must be the one the unit-vector probe finds on this GPU."""
+    from desc_amd import _lib
+    from desc_amd.algorithms import marshal_edges
+    mo = Uniform_Topology(300, 0.4, 0.2, 0.1, "uniform", seed=5)
+    n, ii, jj, rij, _ = marshal_edges(mo.Ind, mo.RijMat)
+    dp = _lib.DeviceProblem(_lib.ProblemArrays(n, ii, jj, rij), 0)
+    try:
+        v = _lib.spmm_variants(dp, reps=3)
+    finally:
+        dp.free()
+    assert v["mfma_layout"] == 1 and v["ms_valu"] > 0 and v["ms_mfma"] > 0
+    assert v["max_abs_diff"] < 1e-11
