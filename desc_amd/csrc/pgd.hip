@@ -2205,6 +2205,8 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     h->slice_len = max_local + 2 * SHARD_PARTS;     // S of the owned edges (edge order), then the workgroup partials (see k_unpack_S)
     h->slice_S = max_local;
     h->t_part = 2 * std::max<int64_t>(max_local, 1);
+    if ((int64_t)h->world * h->t_part >= (1ll << 31) - 1 || (int64_t)h->world * h->slice_len >= (1ll << 31) - 1)
+        return fail(DESC_ERR_TOO_LARGE, "exchange buffers of %d ranks x %lld edges exceed the 32-bit positions of the exchange layout", h->world, (long long)max_local);
     const int64_t mcl = h->cyc_hi - h->cyc_lo;            // local cycles
     const int64_t nsl = h->seg_hi - h->seg_lo;            // local segments
     // band sweep: the work of every workgroup as a list of pieces (plan_band_pieces)
