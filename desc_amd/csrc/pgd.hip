@@ -682,6 +682,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
                                     // 128 / 256 non-temporal stream loads / stores, 2048 gathers issued where they are used (no prefetch)
 #endif
 constexpr int BAND_ROW_CAP = 19200;          // doubles of LDS for the band rows (150 KiB of the CU's 160 KiB)
+constexpr int MAX_TAIL_PIECES = 768;         // shared tail of the band sweep: at most this many queued pieces (their partials: SHARD_PARTS - grid)
 struct alignas(16) PieceDesc { int32_t row_lo, row_len, seg_lo, seg_hi; };   // CSR slots of the band, device-order segments
 
 struct BandSweepArgs {
@@ -689,6 +690,13 @@ struct BandSweepArgs {
     const PieceDesc* pieces;
     const int32_t* piece_ptr;      // grid + 1
     int32_t row_cap;
+    unsigned long long* wg_clock;  // diagnostics (DESC_DEBUG_WGCLOCK=1; else NULL): per workgroup {start, end} of the constant 100 MHz clock
+    // Dynamic tail (round 3): the last few per cent of the sweep's work are not in any workgroup's list but in a shared queue of small pieces
+    // pieces[tail_first .. tail_first + n_tail), handed out by tickets to whichever workgroup has finished its list (the lists are balanced by
+    // a cost model; the workgroups' real times differ by +-5 %).  Every tail piece has its own pair of partials (slot gridDim.x + ticket), so
+    // the objective and |dS| sums do not depend on who took which piece.  *ticket is zeroed by the column-sum launch that precedes a sweep.
+    int32_t tail_first, n_tail;
+    int32_t* ticket;
 };
 
 __device__ __forceinline__ PieceDesc uniform_load_piece(const PieceDesc* p, int i) {
@@ -704,8 +712,8 @@ __device__ __forceinline__ EdgeInfo uniform_load_einfo(const EdgeInfo* p, int i)
     return EdgeInfo{v.x, v.y, v.z, v.w};
 }
 
-template <int LPS, int E, int STEP, int NT>
-__global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
+template <int LPS, int E, int STEP, int NT, bool XT = false>      // XT: sharded run (exchange positions {ta, tb} per segment; its own instances keep
+__global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // the extra records out of the one-GPU kernels' scalar registers)
     extern __shared__ double s_dyn[];                  // [row_cap] band rows of S_old, then the nv table
     const NodeSweepArgs& a = b.n;
     double* s_rows = s_dyn;
@@ -725,13 +733,43 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
     double obj_acc = 0.0, chg_acc = 0.0;
 
     constexpr bool VREC = SPW > 4;         // eight segments per wave: their records would not fit the SGPRs -- per-lane vector loads instead
-    struct RecRaw { int c0[VREC ? 1 : SPW], c1[VREC ? 1 : SPW]; EdgeInfo ei[VREC ? 1 : SPW]; int xa[VREC ? 1 : SPW], xb[VREC ? 1 : SPW]; int t0; };      // wave-uniform (SGPRs); VREC: this lane group's record (VGPRs)
+    struct RecRaw { int c0[VREC ? 1 : SPW], c1[VREC ? 1 : SPW]; EdgeInfo ei[VREC ? 1 : SPW]; int xa[XT ? (VREC ? 1 : SPW) : 1], xb[XT ? (VREC ? 1 : SPW) : 1]; int t0; };      // wave-uniform (SGPRs); VREC: this lane group's record (VGPRs)
     struct Rec { int c0, cnt, rbi, rbj, sa, sb, seg; };                   // this lane group's segment; sharded runs: seg = ta, sb = tb (exchange positions)
     struct Str { uint32_t pk[E]; double w[E], d[E], am[EA], av[EA]; };     // am / av: HybridGradient.m_t / v_t (Adam only)
     struct Gat { double sj[E], si[E], T1, T2, So; };
 
     const int p0 = uniform_load(b.piece_ptr, blockIdx.x), p1 = uniform_load(b.piece_ptr, blockIdx.x + 1);
-    for (int pc = p0; pc < p1; ++pc) {
+    if (b.wg_clock && tid == 0) b.wg_clock[2 * blockIdx.x] = wall_clock64();
+    __shared__ int s_ticket;
+    // deterministic workgroup partials of what has been accumulated since the last flush -> pair `slot`
+    auto flush_partials = [&](int slot) {
+        const double o1 = group_sum<64>(obj_acc), c1 = group_sum<64>(chg_acc);
+        __syncthreads();
+        if (lane == 0) { s_part[0][wv] = o1; s_part[1][wv] = c1; }
+        __syncthreads();
+        if (tid == 0) {
+            double o = 0.0, c = 0.0;
+            for (int k = 0; k < NW; ++k) { o += s_part[0][k]; c += s_part[1][k]; }
+            a.partials[2 * slot] = o;
+            a.partials[2 * slot + 1] = c;
+        }
+        obj_acc = 0.0; chg_acc = 0.0;
+    };
+    int pc = p0, ticket = -1;
+    for (;;) {
+        if (ticket < 0 && pc >= p1) {                      // own list done: its partials, then the shared tail
+            flush_partials(blockIdx.x);
+            if (b.n_tail == 0) break;
+            ticket = 0;
+        }
+        if (ticket >= 0) {
+            if (tid == 0) s_ticket = atomicAdd(b.ticket, 1);
+            __syncthreads();
+            ticket = __builtin_amdgcn_readfirstlane(s_ticket);
+            __syncthreads();
+            if (ticket >= b.n_tail) break;
+            pc = b.tail_first + ticket;
+        }
         const PieceDesc pd = uniform_load_piece(b.pieces, pc);
         __syncthreads();                                   // every wave is done with the previous band's rows
         const int nit = (pd.seg_hi - pd.seg_lo + NW * SPW - 1) / (NW * SPW);
@@ -742,8 +780,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
             if constexpr (VREC) {
                 const int t = min(q.t0 + grp, pd.seg_hi - 1);
                 q.c0[0] = a.cum[t]; q.c1[0] = a.cum[t + 1]; q.ei[0] = a.einfo[t];
-                q.xa[0] = 0; q.xb[0] = 0;
-                if (a.xt) { const int2 x = a.xt[t]; q.xa[0] = x.x; q.xb[0] = x.y; }
+                if constexpr (XT) { const int2 x = a.xt[t]; q.xa[0] = x.x; q.xb[0] = x.y; }
                 return q;
             }
 #pragma unroll
@@ -751,8 +788,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
                 const int t = min(q.t0 + s2, pd.seg_hi - 1);
                 q.c0[s2] = uniform_load(a.cum, t); q.c1[s2] = uniform_load(a.cum, t + 1);
                 q.ei[s2] = uniform_load_einfo(a.einfo, t);
-                q.xa[s2] = 0; q.xb[s2] = 0;
-                if (a.xt) { q.xa[s2] = uniform_load((const int32_t*)a.xt, 2 * t); q.xb[s2] = uniform_load((const int32_t*)a.xt, 2 * t + 1); }      // wave-uniform branch
+                if constexpr (XT) { q.xa[s2] = uniform_load((const int32_t*)a.xt, 2 * t); q.xb[s2] = uniform_load((const int32_t*)a.xt, 2 * t + 1); }
             }
             return q;
         };
@@ -760,16 +796,16 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
             Rec r{};
             if constexpr (VREC) {
                 r.c0 = q.c0[0]; r.cnt = q.t0 + grp < pd.seg_hi ? q.c1[0] - q.c0[0] : 0;
-                r.rbi = q.ei[0].rb_i - pd.row_lo; r.rbj = q.ei[0].rb_j; r.sa = q.ei[0].slot_a; r.sb = a.xt ? q.xb[0] : q.ei[0].slot_b;
-                r.seg = q.xa[0];
+                r.rbi = q.ei[0].rb_i - pd.row_lo; r.rbj = q.ei[0].rb_j; r.sa = q.ei[0].slot_a; r.sb = XT ? q.xb[0] : q.ei[0].slot_b;
+                r.seg = XT ? q.xa[0] : 0;
                 return r;
             }
 #pragma unroll
             for (int s2 = 0; s2 < SPW; ++s2)
                 if (grp == s2) {
                     r.c0 = q.c0[s2]; r.cnt = q.t0 + s2 < pd.seg_hi ? q.c1[s2] - q.c0[s2] : 0;
-                    r.rbi = q.ei[s2].rb_i - pd.row_lo; r.rbj = q.ei[s2].rb_j; r.sa = q.ei[s2].slot_a; r.sb = a.xt ? q.xb[s2] : q.ei[s2].slot_b;
-                    r.seg = q.xa[s2];
+                    r.rbi = q.ei[s2].rb_i - pd.row_lo; r.rbj = q.ei[s2].rb_j; r.sa = q.ei[s2].slot_a; r.sb = XT ? q.xb[s2] : q.ei[s2].slot_b;
+                    r.seg = XT ? q.xa[s2] : 0;
                 }
             return r;
         };
@@ -794,7 +830,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
                         : a.S_old[((DESC_BAND_ABLATE & 64) ? (r.rbj & 0x1FFFF) : r.rbj) + (int)((p >> 16) & 0x7FFFu)];   // 64: rows confined to 1 MiB (L2 hits)
                 g.si[e] = (DESC_BAND_ABLATE & 16) ? 0.5 : s_rows[r.rbi + (int)(p & 0x7FFFu)];
             }
-            const int ta = a.xt ? r.seg : r.sa, tb = r.sb;
+            const int ta = XT ? r.seg : r.sa, tb = r.sb;
             g.T1 = (DESC_BAND_ABLATE & 32) ? 0.25 : a.Tfull[ta];                      // column j of node i = sum(wijk(IKJ(mask)))  (:189)
             g.T2 = (DESC_BAND_ABLATE & 32) ? 0.25 : a.Tfull[tb];                      // column i of node j = sum(wijk(JKI(mask)))  (:190)
             g.So = (DESC_BAND_ABLATE & 16) ? 0.5 : s_rows[r.sa - pd.row_lo];
@@ -881,7 +917,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
                 }
             if (cnt > 0 && rr == 0) {
                 chg_acc += fabs(part - g.So);                                                            // :232
-                if (a.s_slice) a.s_slice[r.seg] = part;                       // sharded: k_unpack_S copies it into the CSR-aligned replica
+                if constexpr (XT) a.s_slice[r.seg] = part;                    // sharded: k_unpack_S copies it into the CSR-aligned replica
                 else { a.S_new[r.sa] = part; a.S_new[r.sb] = part; }
             }
         };
@@ -923,19 +959,10 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {
             step(g + 2, R2, S2, G0, R3, S3, G1, R1, S1);
             step(g + 3, R3, S3, G1, R0, S0, G0, R2, S2);
         }
+        if (ticket >= 0) flush_partials((int)gridDim.x + ticket);      // a tail piece: its own pair of partials
+        else ++pc;
     }
-    // deterministic workgroup partials
-    obj_acc = group_sum<64>(obj_acc);
-    chg_acc = group_sum<64>(chg_acc);
-    __syncthreads();
-    if (lane == 0) { s_part[0][wv] = obj_acc; s_part[1][wv] = chg_acc; }
-    __syncthreads();
-    if (tid == 0) {
-        double o = 0.0, c = 0.0;
-        for (int k = 0; k < NW; ++k) { o += s_part[0][k]; c += s_part[1][k]; }
-        a.partials[2 * blockIdx.x] = o;
-        a.partials[2 * blockIdx.x + 1] = c;
-    }
+    if (b.wg_clock && tid == 0) b.wg_clock[2 * blockIdx.x + 1] = wall_clock64();
 }
 
 // Sum the block partials in a fixed order, record the traces and run the early-stop
@@ -1010,9 +1037,10 @@ constexpr int COLSUM_U = 8;
 // sequentially -- instead of the 4-byte packed words of the cycles, which sit in scattered 50-byte runs next to the weights
 // (round 2: -25 % of this pass's sectors).
 __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, const int2* adj_seg, const uint32_t* moff, const uint16_t* midx, const double* w,
-                                                     double* Tfull, int n, int stride_cols, const DevState* st, const int32_t* xpos, FinArgs fin) {
+                                                     double* Tfull, int n, int stride_cols, const DevState* st, const int32_t* xpos, FinArgs fin, int32_t* tail_ticket) {
     if (blockIdx.x == gridDim.x - 1) {
         if (threadIdx.x < 64 && fin.st) finalize_wave(fin);
+        if (threadIdx.x == 0 && tail_ticket) *tail_ticket = 0;          // the sweep that follows hands out its tail pieces from 0
         return;
     }
     if (st->stop) return;
@@ -1441,7 +1469,7 @@ __global__ __launch_bounds__(256) void k_reorder_cycles(const int32_t* cum, cons
 // partials (objective, sum |dS|)].  The sweep kernels write both straight into the slice; after the all-gather
 // k_unpack_S scatters S of every edge into both of its CSR slots, and its extra last workgroup adds all ranks'
 // partials in rank order (identical sums, hence identical stop decisions, on every rank) and runs the stop rule.
-constexpr int SHARD_PARTS = 512;
+constexpr int SHARD_PARTS = 1024;           // >= band grid + tail pieces (MAX_TAIL_PIECES)
 __global__ __launch_bounds__(256) void k_unpack_S(const int32_t* spos, int64_t nslots, const double* sall, double* S_a, double* S_b, FinArgs fin) {
     if (blockIdx.x == gridDim.x - 1) {
         if (fin.t > 0 && threadIdx.x < 64) finalize_wave(fin);
@@ -1496,6 +1524,9 @@ struct desc_pgd {
     size_t band_lds = 0;
     PieceDesc* d_pieces = nullptr;
     int32_t* d_piece_ptr = nullptr;
+    unsigned long long* d_wg_clock = nullptr;   // diagnostics: DESC_DEBUG_WGCLOCK
+    int band_tail_first = 0, band_ntail = 0;    // shared tail of the band sweep (BandSweepArgs)
+    int32_t* d_ticket = nullptr;
     hvec<void*> allocs;
     int uc_default = 0;         // which streamed arrays go to uncached memory (dalloc_stream)
     // common
@@ -1690,46 +1721,50 @@ BandShape band_shape(const desc_pgd* h, bool adam) {
     return c <= 16 ? BandShape{16, 1} : c <= 32 ? BandShape{16, 2} : c <= 64 ? BandShape{16, 4} : c <= 128 ? BandShape{32, 4} : BandShape{64, 4};
 }
 bool band_adam_ok(const desc_pgd* h) { return h->band_ok && h->max_cnt <= 64; }
-template <int STEP>
+template <int STEP, bool XT>
 const void* band_kernel(const desc_pgd* h) {
     const BandShape sh = band_shape(h, STEP == DESC_STEP_HYBRID);
     if constexpr (STEP == DESC_STEP_HYBRID) {
         if (h->max_cnt > 64) return nullptr;           // 4 cycles per lane + the moments do not fit the registers: k_sweep_node (band_adam_ok)
         switch (sh.lps * 8 + sh.E) {
-            case 16 * 8 + 1: return (const void*)k_sweep_band<16, 1, STEP, 512>;
-            case 16 * 8 + 2: return (const void*)k_sweep_band<16, 2, STEP, 512>;
-            default: return (const void*)k_sweep_band<32, 2, STEP, 512>;
+            case 16 * 8 + 1: return (const void*)k_sweep_band<16, 1, STEP, 512, XT>;
+            case 16 * 8 + 2: return (const void*)k_sweep_band<16, 2, STEP, 512, XT>;
+            default: return (const void*)k_sweep_band<32, 2, STEP, 512, XT>;
         }
     } else {
         switch (sh.lps * 8 + sh.E) {
-            case 16 * 8 + 1: return (const void*)k_sweep_band<16, 1, STEP, 1024>;
-            case 16 * 8 + 2: return (const void*)k_sweep_band<16, 2, STEP, 512>;
-            case 16 * 8 + 4: return (const void*)k_sweep_band<16, 4, STEP, 512>;
-            case 8 * 8 + 4: return (const void*)k_sweep_band<8, 4, STEP, 512>;
-            case 32 * 8 + 4: return (const void*)k_sweep_band<32, 4, STEP, 512>;
-            default: return (const void*)k_sweep_band<64, 4, STEP, 512>;
+            case 16 * 8 + 1: return (const void*)k_sweep_band<16, 1, STEP, 1024, XT>;
+            case 16 * 8 + 2: return (const void*)k_sweep_band<16, 2, STEP, 512, XT>;
+            case 16 * 8 + 4: return (const void*)k_sweep_band<16, 4, STEP, 512, XT>;
+            case 8 * 8 + 4: return (const void*)k_sweep_band<8, 4, STEP, 512, XT>;
+            case 32 * 8 + 4: return (const void*)k_sweep_band<32, 4, STEP, 512, XT>;
+            default: return (const void*)k_sweep_band<64, 4, STEP, 512, XT>;
         }
     }
+}
+template <int LPS, int E, int STEP, int NT>
+void launch_band_shape(desc_pgd* h, const BandSweepArgs& b) {
+    if (b.n.xt) hipLaunchKernelGGL((k_sweep_band<LPS, E, STEP, NT, true>), dim3(h->band_grid), dim3(NT), h->band_lds, h->stream, b);
+    else hipLaunchKernelGGL((k_sweep_band<LPS, E, STEP, NT, false>), dim3(h->band_grid), dim3(NT), h->band_lds, h->stream, b);
 }
 template <int STEP>
 void launch_band(desc_pgd* h, const NodeSweepArgs& a) {
     const BandShape sh = band_shape(h, STEP == DESC_STEP_HYBRID);
-    BandSweepArgs b{a, h->d_pieces, h->d_piece_ptr, h->band_rows};
-    dim3 grid(h->band_grid);
+    BandSweepArgs b{a, h->d_pieces, h->d_piece_ptr, h->band_rows, h->d_wg_clock, h->band_tail_first, h->band_ntail, h->d_ticket};
     if constexpr (STEP == DESC_STEP_HYBRID) {
         switch (sh.lps * 8 + sh.E) {
-            case 16 * 8 + 1: hipLaunchKernelGGL((k_sweep_band<16, 1, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
-            case 16 * 8 + 2: hipLaunchKernelGGL((k_sweep_band<16, 2, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
-            default: hipLaunchKernelGGL((k_sweep_band<32, 2, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
+            case 16 * 8 + 1: launch_band_shape<16, 1, STEP, 512>(h, b); break;
+            case 16 * 8 + 2: launch_band_shape<16, 2, STEP, 512>(h, b); break;
+            default: launch_band_shape<32, 2, STEP, 512>(h, b); break;
         }
     } else {
         switch (sh.lps * 8 + sh.E) {
-            case 16 * 8 + 1: hipLaunchKernelGGL((k_sweep_band<16, 1, STEP, 1024>), grid, dim3(1024), h->band_lds, h->stream, b); break;
-            case 16 * 8 + 2: hipLaunchKernelGGL((k_sweep_band<16, 2, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
-            case 16 * 8 + 4: hipLaunchKernelGGL((k_sweep_band<16, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
-            case 8 * 8 + 4: hipLaunchKernelGGL((k_sweep_band<8, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
-            case 32 * 8 + 4: hipLaunchKernelGGL((k_sweep_band<32, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
-            default: hipLaunchKernelGGL((k_sweep_band<64, 4, STEP, 512>), grid, dim3(512), h->band_lds, h->stream, b); break;
+            case 16 * 8 + 1: launch_band_shape<16, 1, STEP, 1024>(h, b); break;
+            case 16 * 8 + 2: launch_band_shape<16, 2, STEP, 512>(h, b); break;
+            case 16 * 8 + 4: launch_band_shape<16, 4, STEP, 512>(h, b); break;
+            case 8 * 8 + 4: launch_band_shape<8, 4, STEP, 512>(h, b); break;
+            case 32 * 8 + 4: launch_band_shape<32, 4, STEP, 512>(h, b); break;
+            default: launch_band_shape<64, 4, STEP, 512>(h, b); break;
         }
     }
 }
@@ -1740,11 +1775,12 @@ void launch_sweep_node_layout(desc_pgd* h, const NodeSweepArgs& a, bool adam) {
     else launch_node<DESC_STEP_CONSTANT>(h, a);
 }
 // workgroups (= partial pairs) of the sweep kernel that serves this step kind
-int sweep_parts(const desc_pgd* h, bool adam) { return h->variant == VARIANT_NODE && (adam ? band_adam_ok(h) : h->band_ok) ? h->band_grid : h->grid; }
+int sweep_parts(const desc_pgd* h, bool adam) { return h->variant == VARIANT_NODE && (adam ? band_adam_ok(h) : h->band_ok) ? h->band_grid + h->band_ntail : h->grid; }
 
 // second half of d_partials: the objective kernel of a download writes there, so the partials of the last sweep stay intact and
 // book-keeping that sweep again (a replayed column-sum launch after a flush or a download) rewrites the same numbers
-double* obj_partials(const desc_pgd* h) { return h->d_partials + 2 * (size_t)std::max(std::max(h->grid, h->obj_grid), h->band_grid); }
+size_t parts_cap(const desc_pgd* h) { return (size_t)std::max(std::max(h->grid, h->obj_grid), h->band_grid + h->band_ntail); }
+double* obj_partials(const desc_pgd* h) { return h->d_partials + 2 * parts_cap(h); }
 FinArgs fin_args(const desc_pgd* h, const double* partials, int nparts, int t, int last_only) {
     return FinArgs{partials, h->d_state, h->d_obj, h->d_avg, h->m, h->p.stop_tol, nparts, t, h->p.patience, last_only, 0, 1, 0, 0};
 }
@@ -1768,7 +1804,7 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
         else fin.t_after = t;                                // the next column-sum launch (direct or replayed) book-keeps sweep t
         hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int)), h->stream,
                            h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, h->d_w[rd], h->d_T, (int)h->n,
-                           h->colsum_stride, h->d_state, (const int32_t*)nullptr, fin);
+                           h->colsum_stride, h->d_state, (const int32_t*)nullptr, fin, h->d_ticket);
         h->pending_fin = 0;
         NodeSweepArgs a{};
         a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
@@ -2038,12 +2074,13 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
 //    that at any moment all workgroups gather from the same block of rows.
 // Host only: no device call (also reachable through desc_debug_band_plan, which the CPU tests and sanitizer builds use).
 void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const NodePlan& P, int64_t seg_lo, int64_t seg_hi, int64_t cyc_lo, int64_t mcl,
-                      int G, hvec<PieceDesc>& pieces, hvec<int32_t>& piece_ptr, int& band_rows, bool& jmajor_out) {
+                      int G, hvec<PieceDesc>& pieces, hvec<int32_t>& piece_ptr, int& band_rows, bool& jmajor_out, int* tail_first_out = nullptr, int* n_tail_out = nullptr) {
     const hvec<int32_t>& cum2 = P.cum2;
     const int64_t n = prob->n, m = prob->m;
     band_rows = 0;
     const int64_t nbands = (int64_t)P.band_lo.size() - 1;
     hvec<hvec<PieceDesc>> per_wg((size_t)G);
+    hvec<PieceDesc> tail;                                    // shared tail pieces, j-block-major (BandSweepArgs)
     auto piece_of = [&](int64_t bd, int64_t q0, int64_t q1) {
         const int32_t row_lo = P.rowptr[P.band_lo[bd]], row_len = P.rowptr[P.band_lo[bd + 1]] - row_lo;
         band_rows = std::max(band_rows, (int)row_len);
@@ -2100,6 +2137,12 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
         if (aff_slack > 0) {
             hvec<int64_t> load((size_t)G, 0);
             hvec<int> last_wg((size_t)nbands, -1);
+            // Shared tail (round 3): the last DESC_DEBUG_TAIL per mille of the cycles (default 70) are not dealt but queued as small pieces for
+            // whichever workgroup finishes first (k_sweep_band).  Measured with DESC_DEBUG_WGCLOCK (tools/wg_clock.py): the lists are equal in the
+            // cost model to 3 %, the workgroups' real times spread +-5 % (C4: mean 1105, max 1158 us).
+            const int64_t tail_target = tail_first_out ? mcl * std::max(0, std::min(500, env_int("DESC_DEBUG_TAIL", 70))) / 1000 : 0;
+            const int64_t tail_cap = std::max<int64_t>(4096, tail_target / (MAX_TAIL_PIECES - 64));
+            int64_t dealt = 0;
             for (int64_t J = 0; J < nJ; ++J) {
                 const int64_t jlim = (J + 1) * JB;
                 for (int64_t bd = 0; bd < nbands; ++bd) {
@@ -2113,6 +2156,16 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
                         int64_t x = lo;
                         while (x < e && cum2[x + 1] - cum2[lo] <= cap) ++x;
                         if (x == lo) x = lo + 1;
+                        if (tail_target > 0 && dealt >= mcl - tail_target && (int64_t)tail.size() < MAX_TAIL_PIECES) {      // the rest of the sweep: queue
+                            x = lo;
+                            while (x < e && cum2[x + 1] - cum2[lo] <= tail_cap) ++x;
+                            if (x == lo) x = lo + 1;
+                            tail.push_back(piece_of(bd, lo, x));
+                            dealt += cum2[x] - cum2[lo];
+                            lo = x;
+                            continue;
+                        }
+                        dealt += cum2[x] - cum2[lo];
                         int wmin = 0;
                         for (int w = 1; w < G; ++w) if (load[w] < load[wmin]) wmin = w;
                         const int wl = last_wg[bd];
@@ -2159,6 +2212,8 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
         pieces.insert(pieces.end(), per_wg[b].begin(), per_wg[b].end());
         piece_ptr[b + 1] = (int32_t)pieces.size();
     }
+    if (tail_first_out) { *tail_first_out = (int)pieces.size(); *n_tail_out = (int)tail.size(); }
+    pieces.insert(pieces.end(), tail.begin(), tail.end());
     if (pieces.empty()) pieces.push_back(PieceDesc{0, 0, 0, 0});
 }
 
@@ -2214,7 +2269,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     if (h->band_ok) {
         h->band_grid = ncu;
         bool jmajor = false;
-        plan_band_pieces(prob, s, P, h->seg_lo, h->seg_hi, h->cyc_lo, mcl, h->band_grid, pieces, piece_ptr, h->band_rows, jmajor);
+        plan_band_pieces(prob, s, P, h->seg_lo, h->seg_hi, h->cyc_lo, mcl, h->band_grid, pieces, piece_ptr, h->band_rows, jmajor, &h->band_tail_first, &h->band_ntail);
         h->band_jmajor = jmajor;
         if (timing) fprintf(stderr, "[desc_amd] band sweep: %zu bands, %zu pieces over %d workgroups, %s, rows <= %d\n", P.band_lo.size() - 1, pieces.size(),
                             h->band_grid, jmajor ? "j-block-major units" : "contiguous ranges", h->band_rows);
@@ -2331,6 +2386,9 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     if (h->band_ok) {
         if ((rc = dalloc(h, &h->d_pieces, pieces.size()))) return rc;
         if ((rc = dalloc(h, &h->d_piece_ptr, piece_ptr.size()))) return rc;
+        if (env_int("DESC_DEBUG_WGCLOCK", 0) && (rc = dalloc(h, &h->d_wg_clock, 2 * (size_t)h->band_grid))) return rc;
+        if ((rc = dalloc(h, &h->d_ticket, 1))) return rc;
+        DESC_HIP(hipMemsetAsync(h->d_ticket, 0, sizeof(int32_t), h->stream));
     }
     lap("alloc");
     int32_t *d_ii = nullptr, *d_jj = nullptr, *d_adj = nullptr, *d_adj_eid = nullptr, *d_pos_edge2 = nullptr;
@@ -2413,7 +2471,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     }
     if (h->band_ok) {      // the band rows + the nv table in dynamic LDS: more than the 64 KiB default
         h->band_lds = ((size_t)h->band_rows + MAX_SEG_CYCLES + 1) * sizeof(double);
-        for (const void* kb : {band_kernel<DESC_STEP_CONSTANT>(h), band_kernel<DESC_STEP_HYBRID>(h)})
+        for (const void* kb : {band_kernel<DESC_STEP_CONSTANT, false>(h), band_kernel<DESC_STEP_HYBRID, false>(h), band_kernel<DESC_STEP_CONSTANT, true>(h), band_kernel<DESC_STEP_HYBRID, true>(h)})
             if (kb && hipFuncSetAttribute(kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->band_lds) != hipSuccess) { (void)hipGetLastError(); h->band_ok = false; }
     }
     char nm[64];
@@ -2606,7 +2664,7 @@ static int create_impl(const desc_problem* prob, const double* shared_rij, const
         if (!rc) { hipError_t e = hipStreamSynchronize(h->stream); if (e != hipSuccess) rc = fail(DESC_ERR_HIP, "upload: %s", hipGetErrorString(e)); }
     }
     if (!rc) rc = (h->variant == VARIANT_NODE) ? setup_node(h, prob, s, shared_rij) : setup_gather(h, prob, s, shared_rij);
-    if (!rc) rc = dalloc(h, &h->d_partials, 4 * (size_t)std::max(std::max(h->grid, h->obj_grid), h->band_grid));   // sweep partials, then the objective kernel's
+    if (!rc) rc = dalloc(h, &h->d_partials, 4 * parts_cap(h));   // sweep partials, then the objective kernel's
     if (rc) { free_all(h); return rc; }
     *out = h;
     return DESC_OK;
@@ -2647,7 +2705,7 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
         if (gr >= 8 && gr / 8 * 8 != h->grid) {
             dfree(h, h->d_partials); h->d_partials = nullptr;
             h->grid = gr / 8 * 8;
-            rc = dalloc(h, &h->d_partials, 4 * (size_t)std::max(std::max(h->grid, h->obj_grid), h->band_grid)); if (rc) return rc;
+            rc = dalloc(h, &h->d_partials, 4 * parts_cap(h)); if (rc) return rc;
         }
     }
     h->t_done = 0; h->t_plugin = p->t0; h->ms_pgd = 0; h->objective_done = false; h->final_obj_T = -1; h->pending_fin = 0;
@@ -2953,7 +3011,7 @@ int shard_enqueue_colsum(desc_pgd* h, hipStream_t st) {
     const bool direct = shard_direct(h);
     hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int)), st,
                        h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, h->d_w[rd], direct ? h->d_T : h->x_T, (int)h->n, h->colsum_stride, h->d_state,
-                       direct ? (const int32_t*)nullptr : h->d_xpos, FinArgs{});
+                       direct ? (const int32_t*)nullptr : h->d_xpos, FinArgs{}, h->d_ticket);
     DESC_HIP(hipGetLastError());
     return DESC_OK;
 }
@@ -3141,6 +3199,18 @@ int desc_pgd_shard_run(desc_pgd* h, const desc_params* p, desc_result* r) {
 }
 
 // 1 once the device-side patience rule has fired (synchronises the handle's stream)
+// Diagnostics (tools/wg_clock.py): {start, end} of every workgroup of the LAST band sweep on the constant 100 MHz clock, when the handle
+// was created with DESC_DEBUG_WGCLOCK=1.  Returns the number of workgroups written (0: not recorded).
+int desc_debug_wg_clock(desc_pgd* h, uint64_t* out, int32_t cap) {
+    if (!h || !out) return fail(DESC_ERR_INVALID, "NULL argument");
+    if (!h->d_wg_clock || !h->band_ok) return 0;
+    if (set_device(h)) return 0;
+    const int nwg = std::min(cap, h->band_grid);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return 0;
+    if (hipMemcpy(out, h->d_wg_clock, sizeof(uint64_t) * 2 * (size_t)nwg, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return nwg;
+}
+
 int desc_pgd_stopped(desc_pgd* h, int32_t* stopped) {
     if (!h || !stopped) return fail(DESC_ERR_INVALID, "NULL argument");
     int rc = set_device(h); if (rc) return rc;
