@@ -29,7 +29,7 @@ EXPORTS = [
     "desc_pgd_sizes", "desc_pgd_kernel_name", "desc_pgd_solve", "desc_selftest_group_sum",
     "desc_pgd_create_shard", "desc_pgd_shard_info", "desc_pgd_shard_bind", "desc_pgd_shard_colsum", "desc_pgd_shard_sweep",
     "desc_pgd_shard_finish", "desc_pgd_shard_objective", "desc_pgd_shard_set_collectives", "desc_pgd_shard_start",
-    "desc_pgd_shard_iterate", "desc_pgd_shard_run", "desc_pgd_stopped", "desc_device_synchronize", "desc_memcpy_d2h", "desc_memcpy_h2d", "desc_debug_band_plan", "desc_debug_spmm_variants", "desc_debug_wg_clock", "desc_trim_memory", "desc_spectral_run", "desc_cemp_run", "desc_refine_run",
+    "desc_pgd_shard_iterate", "desc_pgd_shard_run", "desc_pgd_stopped", "desc_device_synchronize", "desc_memcpy_d2h", "desc_memcpy_h2d", "desc_debug_band_plan", "desc_debug_spmm_variants", "desc_debug_wg_clock", "desc_debug_wg_plan", "desc_trim_memory", "desc_spectral_run", "desc_cemp_run", "desc_refine_run",
 ]
 
 I32P = C.POINTER(C.c_int32)
@@ -172,6 +172,7 @@ def load():
     L.desc_debug_band_plan.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_int32, C.c_int32, C.c_int32, I64P]
     L.desc_debug_spmm_variants.argtypes = [C.c_void_p, C.c_int32, F64P]
     L.desc_debug_wg_clock.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32]
+    L.desc_debug_wg_plan.argtypes = [C.c_void_p, I64P, C.c_int32]
     L.desc_trim_memory.restype = C.c_int64
     L.desc_trim_memory.argtypes = []
     L.desc_device_synchronize.argtypes = [C.c_int32]

@@ -2137,11 +2137,18 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
         if (aff_slack > 0) {
             hvec<int64_t> load((size_t)G, 0);
             hvec<int> last_wg((size_t)nbands, -1);
-            // Shared tail (round 3): the last DESC_DEBUG_TAIL per mille of the cycles (default 70) are not dealt but queued as small pieces for
-            // whichever workgroup finishes first (k_sweep_band).  Measured with DESC_DEBUG_WGCLOCK (tools/wg_clock.py): the lists are equal in the
-            // cost model to 3 %, the workgroups' real times spread +-5 % (C4: mean 1105, max 1158 us).
-            const int64_t tail_target = tail_first_out ? mcl * std::max(0, std::min(500, env_int("DESC_DEBUG_TAIL", 70))) / 1000 : 0;
+            // How even the lists end up (tools/wg_clock.py, DESC_DEBUG_WGCLOCK): with units of ~34 K cycles and the affinity slack the plan's
+            // cycle counts spread +-5 % at C4 (455 K .. 509 K) and the workgroups' measured times follow them (correlation 0.74; mean 1105,
+            // max 1158 us).  Two remedies, both here:
+            //  * fit to target (default): in the last FIT per mille of the cycles (DESC_DEBUG_FIT, default 100) a unit is cut where the
+            //    workgroup that takes it reaches the common target load -- the lists end level to a segment, with about one extra piece each;
+            //  * shared tail (DESC_DEBUG_TAIL per mille, default 0): the last part is queued as small pieces for whichever workgroup finishes
+            //    first (k_sweep_band).  Measured: the queue levels the end times (max - mean 4.8 % -> 1.4 %) but its ~700 small pieces each
+            //    load their band rows: the mean rises by as much (profiles/r03_experiments.txt).
+            const int64_t tail_target = tail_first_out ? mcl * std::max(0, std::min(500, env_int("DESC_DEBUG_TAIL", 0))) / 1000 : 0;
             const int64_t tail_cap = std::max<int64_t>(4096, tail_target / (MAX_TAIL_PIECES - 64));
+            const int64_t fit_from = mcl - mcl * std::max(0, std::min(500, env_int("DESC_DEBUG_FIT", 100))) / 1000;
+            int64_t fit_target = -1;                         // common final load, fixed when the fitting phase starts
             int64_t dealt = 0;
             for (int64_t J = 0; J < nJ; ++J) {
                 const int64_t jlim = (J + 1) * JB;
@@ -2165,12 +2172,32 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
                             lo = x;
                             continue;
                         }
-                        dealt += cum2[x] - cum2[lo];
                         int wmin = 0;
                         for (int w = 1; w < G; ++w) if (load[w] < load[wmin]) wmin = w;
                         const int wl = last_wg[bd];
-                        if (wl >= 0 && load[wl] <= load[wmin] + aff_slack && !per_wg[wl].empty() && per_wg[wl].back().seg_hi == (int32_t)lo &&
-                            per_wg[wl].back().row_lo == P.rowptr[P.band_lo[bd]]) {
+                        const bool merge = wl >= 0 && load[wl] <= load[wmin] + aff_slack && !per_wg[wl].empty() && per_wg[wl].back().seg_hi == (int32_t)lo &&
+                                           per_wg[wl].back().row_lo == P.rowptr[P.band_lo[bd]];
+                        const int wt = merge ? wl : wmin;
+                        if (dealt >= fit_from) {
+                            if (fit_target < 0) {            // what is left + what is dealt + a row load per workgroup, shared equally
+                                int64_t sum = 0;
+                                for (int w = 0; w < G; ++w) sum += load[w];
+                                fit_target = (sum + (mcl - dealt) + 4096 * (int64_t)G + G - 1) / G;
+                            }
+                            const int64_t room = fit_target - load[wt] - (merge ? 0 : 4096);
+                            if (room < 2048 && load[wmin] + 4096 + 2048 > fit_target) fit_target += 4096;       // everybody is full: raise the bar a little
+                            else if (room >= 2048) {
+                                int64_t y = lo;
+                                while (y < x && cum2[y + 1] - cum2[lo] <= room) ++y;
+                                if (y > lo) x = y;           // cut the unit where this workgroup reaches the target
+                                else x = lo + 1;
+                            } else {                         // the band's resident workgroup is full: the least loaded one takes the unit instead
+                                last_wg[bd] = -1;
+                                continue;
+                            }
+                        }
+                        dealt += cum2[x] - cum2[lo];
+                        if (merge) {
                             per_wg[wl].back().seg_hi = (int32_t)x;                 // same rows, contiguous segments: one longer piece
                             load[wl] += cum2[x] - cum2[lo];
                         } else {
@@ -3209,6 +3236,28 @@ int desc_debug_wg_clock(desc_pgd* h, uint64_t* out, int32_t cap) {
     if (hipStreamSynchronize(h->stream) != hipSuccess) return 0;
     if (hipMemcpy(out, h->d_wg_clock, sizeof(uint64_t) * 2 * (size_t)nwg, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return nwg;
+}
+
+// Diagnostics (tools/wg_clock.py): what the piece scheduler gave every workgroup of the band sweep -- out[4 * w + {0,1,2,3}] = cycles,
+// segments, pieces, CSR entries of the band rows its pieces load.  Returns the number of workgroups.
+int desc_debug_wg_plan(desc_pgd* h, int64_t* out, int32_t cap) {
+    return no_throw("desc_debug_wg_plan", [&]() -> int {
+    if (!h || !out) return fail(DESC_ERR_INVALID, "NULL argument");
+    if (!h->band_ok || !h->d_pieces) return 0;
+    if (set_device(h)) return 0;
+    const int G = std::min(cap, h->band_grid);
+    hvec<int32_t> pp((size_t)h->band_grid + 1), cum((size_t)h->m_pos + 1);
+    if (hipMemcpy(pp.data(), h->d_piece_ptr, sizeof(int32_t) * pp.size(), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (hipMemcpy(cum.data(), h->d_cum, sizeof(int32_t) * cum.size(), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    hvec<PieceDesc> pc((size_t)pp[h->band_grid]);
+    if (!pc.empty() && hipMemcpy(pc.data(), h->d_pieces, sizeof(PieceDesc) * pc.size(), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    for (int w = 0; w < G; ++w) {
+        int64_t cyc = 0, seg = 0, rows = 0;
+        for (int q = pp[w]; q < pp[w + 1]; ++q) { cyc += cum[pc[q].seg_hi] - cum[pc[q].seg_lo]; seg += pc[q].seg_hi - pc[q].seg_lo; rows += pc[q].row_len; }
+        out[4 * w] = cyc; out[4 * w + 1] = seg; out[4 * w + 2] = pp[w + 1] - pp[w]; out[4 * w + 3] = rows;
+    }
+    return G;
+    });
 }
 
 int desc_pgd_stopped(desc_pgd* h, int32_t* stopped) {

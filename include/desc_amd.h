@@ -349,6 +349,8 @@ int desc_debug_band_plan(const desc_problem* prob, const desc_structure* s, int3
 /* Diagnostics hook (tools/wg_clock.py): {start, end} (constant 100 MHz clock) of every workgroup of the last band sweep of a handle created
  * with DESC_DEBUG_WGCLOCK=1; returns how many workgroups were written to out[2 * cap] (0: not recorded). */
 int desc_debug_wg_clock(desc_pgd* h, uint64_t* out, int32_t cap);
+/* ... and what the piece scheduler gave each of them: out[4 * w + {0,1,2,3}] = cycles, segments, pieces, CSR entries of the band rows loaded. */
+int desc_debug_wg_plan(desc_pgd* h, int64_t* out, int32_t cap);
 
 /* Measurement hook (tools/next_rows_bench.py; SURVEY.md 8d "document the MFMA measurement rather than assume"): the 3x3-block SpMM of the
  * connection matrix (Spectral.m:27-37) with unit weights, `reps` products in its vector-FMA form and in a v_mfma_f64_4x4x4 form on the

@@ -25,4 +25,17 @@ print(f"{wl}: {n} workgroups; start spread {start.max():.1f} us; end: min {end.m
       f"duration: min {dur.min():.1f} p10 {np.percentile(dur, 10):.1f} median {np.median(dur):.1f} p90 {np.percentile(dur, 90):.1f} max {dur.max():.1f} us")
 print("ten slowest workgroups (id, end us):", [(int(i), round(float(end[i]), 1)) for i in np.argsort(-end)[:10]])
 print("ten fastest workgroups (id, end us):", [(int(i), round(float(end[i]), 1)) for i in np.argsort(end)[:10]])
+plan = np.zeros(4 * 1024, dtype=np.int64)
+g = _lib.load().desc_debug_wg_plan(solver.handle, plan.ctypes.data_as(C.POINTER(C.c_int64)), 1024)
+if g == n:
+    P = plan[:4 * n].reshape(n, 4).astype(np.float64)
+    X = np.column_stack([P[:, 0], P[:, 1], P[:, 2], P[:, 3]])
+    coef, res, rk, sv = np.linalg.lstsq(X, dur, rcond=None)
+    fit = X @ coef
+    print("plan per workgroup: cycles %.0f..%.0f, segments %.0f..%.0f, pieces %.0f..%.0f, row entries %.0f..%.0f" % (
+        P[:, 0].min(), P[:, 0].max(), P[:, 1].min(), P[:, 1].max(), P[:, 2].min(), P[:, 2].max(), P[:, 3].min(), P[:, 3].max()))
+    print("least squares  duration_us = %.3e * cycles + %.3e * segments + %.3e * pieces + %.3e * row_entries;  residual std %.1f us (duration std %.1f us)" % (
+        coef[0], coef[1], coef[2], coef[3], float(np.std(dur - fit)), float(np.std(dur))))
+    for name, col in (("cycles", 0), ("segments", 1), ("pieces", 2), ("row entries", 3)):
+        print("  corr(duration, %s) = %.2f" % (name, float(np.corrcoef(dur, P[:, col])[0, 1])))
 solver.destroy()
