@@ -2089,17 +2089,38 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
     const int jmajor_env = env_int("DESC_DEBUG_JMAJOR", -1);
     const bool jmajor = jmajor_env >= 0 ? jmajor_env != 0 : (int64_t)2 * m * 8 > (12ll << 20);      // C3 (6.4 MB): contiguous 0.167 ms, units 0.184
     jmajor_out = jmajor;
+    // what a piece costs besides its cycles -- the load of the band's rows into the LDS and the fill of the register pipeline -- in cycle
+    // units.  Measured per workgroup with DESC_DEBUG_WGCLOCK (tools/wg_clock.py, least squares of the durations on the plan): 11 us per piece
+    // at C2 (= 7600 cycles at 1.5 ns per cycle), 9 us at C3 (4800), 8-13 us at C4 (4000-6400).
+    const int64_t PC = std::max(0, env_int("DESC_DEBUG_PIECE_COST", 6144));
     if (!jmajor) {
+        // Contiguous ranges, one per workgroup, equal in cycles + PC per piece (a range that crosses a band boundary is two pieces and loads
+        // two sets of rows).  Round 2 made the ranges equal in cycles alone: at C2 / C3 the workgroups with 2-3 pieces finished 10-20 % after
+        // the others (durations 97-124 us at C2, correlation 0.86 with the piece count) and the kernel waited for them.
         int64_t q = seg_lo, bd = 0;
-        for (int b = 0; b < G; ++b) {
-            const int64_t target = cyc_lo + (b + 1 == G ? mcl : mcl * (b + 1) / G);
-            int64_t qe = q;
-            while (qe < seg_hi && (cum2[qe + 1] <= target || b + 1 == G)) ++qe;
-            while (q < qe) {
+        while (bd + 1 < nbands && P.bstart[bd + 1] <= q) ++bd;
+        for (int b = 0; b < G && q < seg_hi; ++b) {
+            // bands that still begin inside what is left: each of them costs one more piece somewhere
+            int64_t bands_left = 0;
+            for (int64_t t = bd + 1; t < nbands && P.bstart[t] < seg_hi; ++t) ++bands_left;
+            const int64_t left = (cyc_lo + mcl) - cum2[q];
+            const int64_t target = (left + PC * ((G - b) + bands_left) + (G - b) - 1) / (G - b);
+            int64_t load = 0;
+            while (q < seg_hi) {
                 while (bd + 1 < nbands && P.bstart[bd + 1] <= q) ++bd;
-                const int64_t e = std::min<int64_t>(qe, P.bstart[bd + 1]);
+                const int64_t band_end = std::min<int64_t>(seg_hi, P.bstart[bd + 1]);
+                int64_t e = band_end;
+                if (b + 1 < G) {
+                    const int64_t room = target - load - PC;
+                    if (room <= 0 && load > 0) break;                       // not even the row load fits: the next workgroup starts here
+                    int64_t lo2 = q, hi2 = band_end;                         // largest e with cycles(q..e) <= room
+                    while (lo2 < hi2) { const int64_t mid = (lo2 + hi2 + 1) >> 1; if (cum2[mid] - cum2[q] <= room) lo2 = mid; else hi2 = mid - 1; }
+                    e = std::max<int64_t>(lo2, q + 1);
+                }
                 per_wg[b].push_back(piece_of(bd, q, e));
+                load += PC + (cum2[e] - cum2[q]);
                 q = e;
+                if (b + 1 < G && load >= target) break;
             }
         }
     } else {
@@ -2182,10 +2203,10 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
                             if (fit_target < 0) {            // what is left + what is dealt + a row load per workgroup, shared equally
                                 int64_t sum = 0;
                                 for (int w = 0; w < G; ++w) sum += load[w];
-                                fit_target = (sum + (mcl - dealt) + 4096 * (int64_t)G + G - 1) / G;
+                                fit_target = (sum + (mcl - dealt) + PC * (int64_t)G + G - 1) / G;
                             }
-                            const int64_t room = fit_target - load[wt] - (merge ? 0 : 4096);
-                            if (room < 2048 && load[wmin] + 4096 + 2048 > fit_target) fit_target += 4096;       // everybody is full: raise the bar a little
+                            const int64_t room = fit_target - load[wt] - (merge ? 0 : PC);
+                            if (room < 2048 && load[wmin] + PC + 2048 > fit_target) fit_target += 4096;       // everybody is full: raise the bar a little
                             else if (room >= 2048) {
                                 int64_t y = lo;
                                 while (y < x && cum2[y + 1] - cum2[lo] <= room) ++y;
@@ -2202,7 +2223,7 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
                             load[wl] += cum2[x] - cum2[lo];
                         } else {
                             per_wg[wmin].push_back(piece_of(bd, lo, x));
-                            load[wmin] += cum2[x] - cum2[lo] + 4096;
+                            load[wmin] += cum2[x] - cum2[lo] + PC;
                             last_wg[bd] = wmin;
                         }
                         lo = x;
@@ -2226,7 +2247,7 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
                     std::pop_heap(heap.begin(), heap.end(), cmp);
                     auto& top = heap.back();
                     per_wg[top.second].push_back(piece_of(bd, lo, x));
-                    top.first += cum2[x] - cum2[lo] + 4096;  // + the row load and pipeline fill of a piece, in cycle units
+                    top.first += cum2[x] - cum2[lo] + PC;    // + the row load and pipeline fill of a piece, in cycle units
                     std::push_heap(heap.begin(), heap.end(), cmp);
                     lo = x;
                 }
