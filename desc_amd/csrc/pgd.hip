@@ -2092,7 +2092,9 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
     // what a piece costs besides its cycles -- the load of the band's rows into the LDS and the fill of the register pipeline -- in cycle
     // units.  Measured per workgroup with DESC_DEBUG_WGCLOCK (tools/wg_clock.py, least squares of the durations on the plan): 11 us per piece
     // at C2 (= 7600 cycles at 1.5 ns per cycle), 9 us at C3 (4800), 8-13 us at C4 (4000-6400).
-    const int64_t PC = std::max(0, env_int("DESC_DEBUG_PIECE_COST", 6144));
+    // Adopted: 6144 for the contiguous ranges (C2 sweep 130 -> 117 us, C3 121.5 -> 111 us against equal-cycle ranges; 4096 / 8192 within 2 %),
+    // 4096 for the j-block-major units (C4: 1205 vs 1212 us at 6144 / 8192) -- profiles/r03_piece_cost.txt.
+    const int64_t PC = std::max(0, env_int("DESC_DEBUG_PIECE_COST", jmajor ? 4096 : 6144));
     if (!jmajor) {
         // Contiguous ranges, one per workgroup, equal in cycles + PC per piece (a range that crosses a band boundary is two pieces and loads
         // two sets of rows).  Round 2 made the ranges equal in cycles alone: at C2 / C3 the workgroups with 2-3 pieces finished 10-20 % after
