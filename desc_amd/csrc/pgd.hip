@@ -2163,14 +2163,15 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
             // How even the lists end up (tools/wg_clock.py, DESC_DEBUG_WGCLOCK): with units of ~34 K cycles and the affinity slack the plan's
             // cycle counts spread +-5 % at C4 (455 K .. 509 K) and the workgroups' measured times follow them (correlation 0.74; mean 1105,
             // max 1158 us).  Two remedies, both here:
-            //  * fit to target (default): in the last FIT per mille of the cycles (DESC_DEBUG_FIT, default 100) a unit is cut where the
-            //    workgroup that takes it reaches the common target load -- the lists end level to a segment, with about one extra piece each;
+            //  * fit to target (DESC_DEBUG_FIT per mille, default 0): in the last part of the cycles a unit is cut where the workgroup that takes
+            //    it reaches the common target load -- the lists end level to a segment.  Measured: no gain at C4, C5 slightly worse; what is left
+            //    of the spread is not in the plan (even XCDs run 1.5 % slower than odd ones: profiles/r03_experiments.txt);
             //  * shared tail (DESC_DEBUG_TAIL per mille, default 0): the last part is queued as small pieces for whichever workgroup finishes
             //    first (k_sweep_band).  Measured: the queue levels the end times (max - mean 4.8 % -> 1.4 %) but its ~700 small pieces each
             //    load their band rows: the mean rises by as much (profiles/r03_experiments.txt).
             const int64_t tail_target = tail_first_out ? mcl * std::max(0, std::min(500, env_int("DESC_DEBUG_TAIL", 0))) / 1000 : 0;
             const int64_t tail_cap = std::max<int64_t>(4096, tail_target / (MAX_TAIL_PIECES - 64));
-            const int64_t fit_from = mcl - mcl * std::max(0, std::min(500, env_int("DESC_DEBUG_FIT", 100))) / 1000;
+            const int64_t fit_from = mcl - mcl * std::max(0, std::min(500, env_int("DESC_DEBUG_FIT", 0))) / 1000;
             int64_t fit_target = -1;                         // common final load, fixed when the fitting phase starts
             int64_t dealt = 0;
             for (int64_t J = 0; J < nJ; ++J) {
