@@ -1037,7 +1037,7 @@ constexpr int COLSUM_U = 8;
 // sequentially -- instead of the 4-byte packed words of the cycles, which sit in scattered 50-byte runs next to the weights
 // (round 2: -25 % of this pass's sectors).
 __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, const int2* adj_seg, const uint32_t* moff, const uint16_t* midx, const double* w,
-                                                     double* Tfull, int n, int stride_cols, const DevState* st, const int32_t* xpos, FinArgs fin, int32_t* tail_ticket) {
+                                                     double* Tfull, int n, int stride_cols, const DevState* st, const int32_t* xpos, FinArgs fin, int32_t* tail_ticket, const int32_t* node_order) {
     if (blockIdx.x == gridDim.x - 1) {
         if (threadIdx.x < 64 && fin.st) finalize_wave(fin);
         if (threadIdx.x == 0 && tail_ticket) *tail_ticket = 0;          // the sweep that follows hands out its tail pieces from 0
@@ -1049,7 +1049,8 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
     int* seg_cf = seg_base + stride_cols;             // slot_record: {first contributing cycle, their number (| flag)}
     uint32_t* seg_mo = (uint32_t*)(seg_cf + stride_cols);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int v = blockIdx.x; v < n; v += gridDim.x - 1) {
+    for (int vi = blockIdx.x; vi < n; vi += gridDim.x - 1) {
+        const int v = node_order ? node_order[vi] : vi;       // longest rows first: the dispatcher hands workgroups out in index order
         const int r0 = rowptr[v], deg = rowptr[v + 1] - r0;
         if (deg == 0) continue;
         for (int t = threadIdx.x; t < 4 * stride_cols; t += 256) acc[t] = 0.0;
@@ -1527,6 +1528,7 @@ struct desc_pgd {
     unsigned long long* d_wg_clock = nullptr;   // diagnostics: DESC_DEBUG_WGCLOCK
     int band_tail_first = 0, band_ntail = 0;    // shared tail of the band sweep (BandSweepArgs)
     int32_t* d_ticket = nullptr;
+    int32_t* d_node_order = nullptr;            // column sums: nodes by descending degree (one workgroup each, dispatched in index order)
     hvec<void*> allocs;
     int uc_default = 0;         // which streamed arrays go to uncached memory (dalloc_stream)
     // common
@@ -1804,7 +1806,7 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
         else fin.t_after = t;                                // the next column-sum launch (direct or replayed) book-keeps sweep t
         hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int)), h->stream,
                            h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, h->d_w[rd], h->d_T, (int)h->n,
-                           h->colsum_stride, h->d_state, (const int32_t*)nullptr, fin, h->d_ticket);
+                           h->colsum_stride, h->d_state, (const int32_t*)nullptr, fin, h->d_ticket, h->d_node_order);
         h->pending_fin = 0;
         NodeSweepArgs a{};
         a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
@@ -2515,6 +2517,13 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     h->obj_grid = (int)std::min<int64_t>(SHARD_PARTS, std::max<int64_t>(1, (nsl + 3) / 4));     // sharded runs: its partials travel in the all-gather slice
     h->colsum_stride = (h->max_deg + 1) | 1;                 // odd stride: the 4 copies start on different banks
     h->colsum_grid = (int)std::max<int64_t>(1, n);            // one node per workgroup: the dispatcher balances
+    if (n > 0 && env_int("DESC_DEBUG_NODE_ORDER", 1)) {       // ... longest rows first, so that the last workgroups of the launch are the short ones
+        hvec<int32_t> ord((size_t)n);
+        for (int64_t v = 0; v < n; ++v) ord[v] = (int32_t)v;
+        std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return P.rowptr[x + 1] - P.rowptr[x] > P.rowptr[y + 1] - P.rowptr[y]; });
+        if ((rc = dalloc(h, &h->d_node_order, (size_t)n)) || (rc = upload(h, h->d_node_order, ord.data(), (size_t)n))) return rc;
+        DESC_HIP(hipStreamSynchronize(h->stream));
+    }
     {
         const size_t lds = (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int));
         if (lds > 64 * 1024)
@@ -3062,7 +3071,7 @@ int shard_enqueue_colsum(desc_pgd* h, hipStream_t st) {
     const bool direct = shard_direct(h);
     hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int)), st,
                        h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, h->d_w[rd], direct ? h->d_T : h->x_T, (int)h->n, h->colsum_stride, h->d_state,
-                       direct ? (const int32_t*)nullptr : h->d_xpos, FinArgs{}, h->d_ticket);
+                       direct ? (const int32_t*)nullptr : h->d_xpos, FinArgs{}, h->d_ticket, h->d_node_order);
     DESC_HIP(hipGetLastError());
     return DESC_OK;
 }
