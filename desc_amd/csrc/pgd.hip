@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
     uint32_t* seg_mo = (uint32_t*)(seg_cf + stride_cols);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int vi = blockIdx.x; vi < n; vi += gridDim.x - 1) {
-        const int v = node_order ? node_order[vi] : vi;       // longest rows first: the dispatcher hands workgroups out in index order
+        const int v = node_order ? node_order[vi] : vi;       // the dispatcher hands workgroups out in index order: see setup_node for the order
         const int r0 = rowptr[v], deg = rowptr[v + 1] - r0;
         if (deg == 0) continue;
         for (int t = threadIdx.x; t < 4 * stride_cols; t += 256) acc[t] = 0.0;
@@ -1528,7 +1528,7 @@ struct desc_pgd {
     unsigned long long* d_wg_clock = nullptr;   // diagnostics: DESC_DEBUG_WGCLOCK
     int band_tail_first = 0, band_ntail = 0;    // shared tail of the band sweep (BandSweepArgs)
     int32_t* d_ticket = nullptr;
-    int32_t* d_node_order = nullptr;            // column sums: nodes by descending degree (one workgroup each, dispatched in index order)
+    int32_t* d_node_order = nullptr;            // column sums: the order the nodes are gone through (one workgroup each, dispatched in index order)
     hvec<void*> allocs;
     int uc_default = 0;         // which streamed arrays go to uncached memory (dalloc_stream)
     // common
@@ -2517,10 +2517,19 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     h->obj_grid = (int)std::min<int64_t>(SHARD_PARTS, std::max<int64_t>(1, (nsl + 3) / 4));     // sharded runs: its partials travel in the all-gather slice
     h->colsum_stride = (h->max_deg + 1) | 1;                 // odd stride: the 4 copies start on different banks
     h->colsum_grid = (int)std::max<int64_t>(1, n);            // one node per workgroup: the dispatcher balances
-    if (n > 0 && env_int("DESC_DEBUG_NODE_ORDER", 1)) {       // ... longest rows first, so that the last workgroups of the launch are the short ones
+    // ... in REVERSE node order (round 3).  The sweep before it ends with the last j-blocks, i.e. the weights of the segments with the largest
+    // j are the freshest lines in the L2s, and the sweep after it begins with the first j-blocks, i.e. gathers T2 of the smallest j first: going
+    // through the nodes from n-1 down to 0 the pass starts on what the sweep just wrote and ends on what the next sweep reads first.  C4
+    // (profiles/r03_node_order.txt, alternating in one call): column sums 238 -> 232 us, the SWEEP 1193 -> 1129 us (-5.4 %); a hashed
+    // shuffle: sweep -4 % but column sums +4 %; longest row first (the scheduling argument): erratic; C5, C2, C3: within noise.
+    // DESC_DEBUG_NODE_ORDER: 0 ascending (round 2), 1 longest row first, 2 reverse (default), 3 hashed shuffle.
+    if (n > 0 && env_int("DESC_DEBUG_NODE_ORDER", 2)) {
         hvec<int32_t> ord((size_t)n);
         for (int64_t v = 0; v < n; ++v) ord[v] = (int32_t)v;
-        std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return P.rowptr[x + 1] - P.rowptr[x] > P.rowptr[y + 1] - P.rowptr[y]; });
+        const int mode = env_int("DESC_DEBUG_NODE_ORDER", 2);
+        if (mode == 2) std::reverse(ord.begin(), ord.end());
+        else if (mode == 3) std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return mix64((uint64_t)x) < mix64((uint64_t)y); });
+        else std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return P.rowptr[x + 1] - P.rowptr[x] > P.rowptr[y + 1] - P.rowptr[y]; });
         if ((rc = dalloc(h, &h->d_node_order, (size_t)n)) || (rc = upload(h, h->d_node_order, ord.data(), (size_t)n))) return rc;
         DESC_HIP(hipStreamSynchronize(h->stream));
     }
