@@ -90,6 +90,12 @@ void build_csr(int64_t n, int64_t m, const int32_t* ii, const int32_t* jj, hvec<
 // device-resident structures (structure_device.hip)
 int structure_ensure_host(desc_structure* s);      // copy the per-cycle arrays to the host if they live on the device
 void structure_free_device(desc_structure* s);
+// desc_pgd_solve: the rotations (72 B per edge, the one large host -> device copy of a call) go up on a helper thread while the structure is
+// built from the edge list; the solver handle is then created on that device copy.  upload_rij: *d_rij = a device block holding prob->rij
+// (NULL and an error code if there is no device, no memory or the copy failed: the caller carries on without it); release_rij frees it.
+int upload_rij(const desc_problem* prob, int32_t device, double** d_rij);
+void release_rij(double* d_rij, int32_t device);
+int pgd_create_with_rij(const desc_problem* prob, const double* d_rij, const desc_structure* s, int32_t device, desc_pgd** out);
 // CEMP.m:44-65 on the device: nsample cycles per edge-with-cycles, with replacement.  The four arrays are
 // hipMalloc'ed on `device` (caller frees); DESC_ERR_TOO_LARGE when a codegree exceeds the LDS staging budget.
 int build_cemp_samples_device(const desc_device_problem* dp, int32_t nsample, uint64_t seed, int64_t* m_pos,

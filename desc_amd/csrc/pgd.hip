@@ -677,6 +677,34 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
 //   the gathers of S({j,k}), T1, T2 (+ LDS reads)     1 iteration ahead (2 sets),
 // issued in the order gathers -> stream -> arithmetic -> stores: loads and stores retire through one in-order
 // counter on gfx950, so everything an iteration waits for was issued before the previous iteration's stores.
+#ifndef DESC_EXP                    // experiment switches of the current round (tools/build_exp.sh builds A/B libraries); 0 = production
+#define DESC_EXP 0
+#endif
+// BUFFER instructions (round 3).  The band sweep and the column sums address global memory as `descriptor in SGPRs + 32-bit byte offset per
+// lane` (buffer_load / buffer_store ... offen) instead of a 64-bit address per lane (global_load / global_store): half the address data per
+// instruction on the way to the address unit -- the busiest unit of the CU in this kernel (TA_BUSY 76 % at C4, section 5 of DESIGN.md) -- and no
+// 64-bit address arithmetic (v_lshl_add_u64, sign extensions: 12 % of the VALU instructions of an iteration).  Measured, rocprofv3 averages in
+// one call (profiles/r03_buffer_instructions.txt): only the S({j,k}) gathers C4 1171 -> 1119 us; + T1/T2 and the S stores 1122; + the three
+// streams and the weight stores 1084-1091 (-7.2 %); C5 1737 -> 1670-1682, C3 105.0 -> 100.4, C2 110.8 -> 107.8.  Cache-policy bits on the
+// gathers (same file): nt 1873 us, sc1 / sc0 sc1 1253 us -- no.  Offsets are 32 bits: the descriptors of the per-cycle arrays are rebuilt per
+// piece with the piece's first cycle as base (any m_cycle), the CSR-aligned arrays (2m doubles) must stay below 4 GiB (setup_node: else no band sweep).
+// Out-of-range offsets read 0 and store nothing (num_records) instead of faulting.  DESC_BUF=0 builds the round-2 forms (A/B).
+#ifndef DESC_BUF
+#define DESC_BUF 1
+#endif
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+template <class T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const T* p, uint32_t bytes = 0xFFFFFFFFu) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);          // raw buffer (stride 0), 32-bit data format
+}
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rs, uint32_t off) {
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+    double d; __builtin_memcpy(&d, &v, 8); return d;
+}
+__device__ __forceinline__ uint32_t buf_load_u32(__amdgpu_buffer_rsrc_t rs, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0); }
+__device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t rs, uint32_t off, double d) {
+    u32x2_t v; __builtin_memcpy(&v, &d, 8);
+    __builtin_amdgcn_raw_buffer_store_b64(v, rs, (int)off, 0, 0);
+}
 #ifndef DESC_BAND_ABLATE            // diagnostic builds only (tools/build_ablate.sh): 1 S({j,k}) from the LDS too, 2 no arithmetic,
 #define DESC_BAND_ABLATE 0          // 4 one threshold pass, 8 no stores, 16 no LDS gathers, 32 no T1/T2 loads, 64 S({j,k}) rows confined to 1 MiB,
                                     // 128 / 256 non-temporal stream loads / stores, 2048 gathers issued where they are used (no prefetch)
@@ -739,7 +767,8 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
     struct Gat { double sj[E], si[E], T1, T2, So; };
 
     const int p0 = uniform_load(b.piece_ptr, blockIdx.x), p1 = uniform_load(b.piece_ptr, blockIdx.x + 1);
-    if (b.wg_clock && tid == 0) b.wg_clock[2 * blockIdx.x] = wall_clock64();
+    unsigned long long wg_c0 = 0;
+    if (b.wg_clock && tid == 0) { b.wg_clock[2 * blockIdx.x] = wall_clock64(); wg_c0 = clock64(); }
     __shared__ int s_ticket;
     // deterministic workgroup partials of what has been accumulated since the last flush -> pair `slot`
     auto flush_partials = [&](int slot) {
@@ -755,6 +784,9 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
         }
         obj_acc = 0.0; chg_acc = 0.0;
     };
+#if DESC_BUF
+    const __amdgpu_buffer_rsrc_t rs_S = make_rsrc(a.S_old), rs_T = make_rsrc(a.Tfull), rs_Sn = make_rsrc(a.S_new);      // CSR-aligned: 2m doubles < 4 GiB
+#endif
     int pc = p0, ticket = -1;
     for (;;) {
         if (ticket < 0 && pc >= p1) {                      // own list done: its partials, then the shared tail
@@ -773,6 +805,13 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
         const PieceDesc pd = uniform_load_piece(b.pieces, pc);
         __syncthreads();                                   // every wave is done with the previous band's rows
         const int nit = (pd.seg_hi - pd.seg_lo + NW * SPW - 1) / (NW * SPW);
+        // the piece's cycles are one contiguous range of the per-cycle arrays: Rec::c0 counts from its start
+        const int c_lo = uniform_load(a.cum, pd.seg_lo);
+#if DESC_BUF
+        const uint32_t c_len = (uint32_t)(uniform_load(a.cum, pd.seg_hi) - c_lo) + 8u;           // + the 16-byte tail the arrays are padded by
+        const __amdgpu_buffer_rsrc_t rs_pk = make_rsrc(a.pk + c_lo, c_len * 4u), rs_w = make_rsrc(a.w_old + c_lo, c_len * 8u),
+                                     rs_d = make_rsrc(a.S0 + c_lo, c_len * 8u), rs_wn = make_rsrc(a.w_new + c_lo, c_len * 8u);
+#endif
 
         auto load_raw = [&](int it) -> RecRaw {            // past the end: the piece's last segment, cnt = 0
             RecRaw q;
@@ -795,7 +834,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
         auto land = [&](const RecRaw& q) -> Rec {
             Rec r{};
             if constexpr (VREC) {
-                r.c0 = q.c0[0]; r.cnt = q.t0 + grp < pd.seg_hi ? q.c1[0] - q.c0[0] : 0;
+                r.c0 = q.c0[0] - c_lo; r.cnt = q.t0 + grp < pd.seg_hi ? q.c1[0] - q.c0[0] : 0;
                 r.rbi = q.ei[0].rb_i - pd.row_lo; r.rbj = q.ei[0].rb_j; r.sa = q.ei[0].slot_a; r.sb = XT ? q.xb[0] : q.ei[0].slot_b;
                 r.seg = XT ? q.xa[0] : 0;
                 return r;
@@ -803,7 +842,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
 #pragma unroll
             for (int s2 = 0; s2 < SPW; ++s2)
                 if (grp == s2) {
-                    r.c0 = q.c0[s2]; r.cnt = q.t0 + s2 < pd.seg_hi ? q.c1[s2] - q.c0[s2] : 0;
+                    r.c0 = q.c0[s2] - c_lo; r.cnt = q.t0 + s2 < pd.seg_hi ? q.c1[s2] - q.c0[s2] : 0;
                     r.rbi = q.ei[s2].rb_i - pd.row_lo; r.rbj = q.ei[s2].rb_j; r.sa = q.ei[s2].slot_a; r.sb = XT ? q.xb[s2] : q.ei[s2].slot_b;
                     r.seg = XT ? q.xa[s2] : 0;
                 }
@@ -813,10 +852,17 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
             Str x;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const int64_t c = (int64_t)r.c0 + min(rr + LPS * e, max(r.cnt, 1) - 1);
+                const int cr = r.c0 + min(rr + LPS * e, max(r.cnt, 1) - 1);
+                const int64_t c = (int64_t)c_lo + cr;
                 if (DESC_BAND_ABLATE & 128) {       // streamed once: non-temporal, so that the j-rows of S keep their place in the L2
                     x.pk[e] = __builtin_nontemporal_load(&a.pk[c]); x.w[e] = __builtin_nontemporal_load(&a.w_old[c]); x.d[e] = __builtin_nontemporal_load(&a.S0[c]);
-                } else { x.pk[e] = a.pk[c]; x.w[e] = a.w_old[c]; x.d[e] = a.S0[c]; }
+                } else {
+#if DESC_BUF
+                    x.pk[e] = buf_load_u32(rs_pk, (uint32_t)cr * 4u); x.w[e] = buf_load_f64(rs_w, (uint32_t)cr * 8u); x.d[e] = buf_load_f64(rs_d, (uint32_t)cr * 8u);
+#else
+                    x.pk[e] = a.pk[c]; x.w[e] = a.w_old[c]; x.d[e] = a.S0[c];
+#endif
+                }
                 if (ADAM) { x.am[e % EA] = a.st.adam_m[c]; x.av[e % EA] = a.st.adam_v[c]; }
             }
             return x;
@@ -826,19 +872,38 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const uint32_t p = x.pk[e];
+#if DESC_BUF
+                g.sj[e] = buf_load_f64(rs_S, (uint32_t)(r.rbj + (int)((p >> 16) & 0x7FFFu)) * 8u);
+#else
                 g.sj[e] = (DESC_BAND_ABLATE & 1) ? s_rows[((p >> 16) & 0x7FFFu) + (lane & 7)]
                         : a.S_old[((DESC_BAND_ABLATE & 64) ? (r.rbj & 0x1FFFF) : r.rbj) + (int)((p >> 16) & 0x7FFFu)];   // 64: rows confined to 1 MiB (L2 hits)
+#endif
                 g.si[e] = (DESC_BAND_ABLATE & 16) ? 0.5 : s_rows[r.rbi + (int)(p & 0x7FFFu)];
             }
             const int ta = XT ? r.seg : r.sa, tb = r.sb;
+#if DESC_BUF && (DESC_EXP & 2)              // experiment: T1 and T2 in ONE load instruction (even lanes T1, odd lanes T2), exchanged inside the quads afterwards
+            g.T1 = buf_load_f64(rs_T, (uint32_t)((lane & 1) ? tb : ta) * 8u);
+            g.T2 = 0.0;
+#elif DESC_BUF
+            g.T1 = buf_load_f64(rs_T, (uint32_t)ta * 8u);
+            g.T2 = buf_load_f64(rs_T, (uint32_t)tb * 8u);
+#else
             g.T1 = (DESC_BAND_ABLATE & 32) ? 0.25 : a.Tfull[ta];                      // column j of node i = sum(wijk(IKJ(mask)))  (:189)
             g.T2 = (DESC_BAND_ABLATE & 32) ? 0.25 : a.Tfull[tb];                      // column i of node j = sum(wijk(JKI(mask)))  (:190)
+#endif
             g.So = (DESC_BAND_ABLATE & 16) ? 0.5 : s_rows[r.sa - pd.row_lo];
             return g;
         };
         // arithmetic + stores of one segment group (DESC_PGD.m:193-233), everything in registers
-        auto compute = [&](const Rec& r, const Str& x, const Gat& g) {
+        auto compute = [&](const Rec& r, const Str& x, const Gat& g0) {
             const int cnt = r.cnt;
+#if DESC_BUF && (DESC_EXP & 2)
+            Gat g = g0;
+            g.T1 = dpp_mov_f64<0xA0>(g0.T1);        // quad_perm:[0,0,2,2]: the even lane's value = T1
+            g.T2 = dpp_mov_f64<0xF5>(g0.T1);        // quad_perm:[1,1,3,3]: the odd lane's value = T2
+#else
+            const Gat& g = g0;
+#endif
             double ws[E], mo[EA], vo[EA];
             uint32_t okm = 0;
             double part = 0.0;
@@ -911,14 +976,31 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
 #pragma unroll
             for (int e = 0; e < E; ++e)
                 if ((okm >> e) & 1u) {
-                    if (DESC_BAND_ABLATE & 256) __builtin_nontemporal_store(ws[e], &a.w_new[(int64_t)r.c0 + rr + LPS * e]);
-                    else a.w_new[(int64_t)r.c0 + rr + LPS * e] = ws[e];
-                    if (ADAM) { a.st.adam_m_out[(int64_t)r.c0 + rr + LPS * e] = mo[e % EA]; a.st.adam_v_out[(int64_t)r.c0 + rr + LPS * e] = vo[e % EA]; }
+                    const int64_t c = (int64_t)c_lo + r.c0 + rr + LPS * e;
+                    if (DESC_BAND_ABLATE & 256) __builtin_nontemporal_store(ws[e], &a.w_new[c]);
+                    else {
+#if DESC_BUF
+                        buf_store_f64(rs_wn, (uint32_t)(r.c0 + rr + LPS * e) * 8u, ws[e]);
+#else
+                        a.w_new[c] = ws[e];
+#endif
+                    }
+                    if (ADAM) { a.st.adam_m_out[c] = mo[e % EA]; a.st.adam_v_out[c] = vo[e % EA]; }
                 }
+#if DESC_BUF && (DESC_EXP & 1)              // experiment: both slots of S in ONE store instruction (lane 0 of the group: slot (i,j), lane 1: slot (j,i))
+            if (!XT && cnt > 0 && rr < 2) buf_store_f64(rs_Sn, (uint32_t)(rr == 0 ? r.sa : r.sb) * 8u, part);
+#endif
             if (cnt > 0 && rr == 0) {
                 chg_acc += fabs(part - g.So);                                                            // :232
                 if constexpr (XT) a.s_slice[r.seg] = part;                    // sharded: k_unpack_S copies it into the CSR-aligned replica
-                else { a.S_new[r.sa] = part; a.S_new[r.sb] = part; }
+                else {
+#if DESC_BUF && (DESC_EXP & 1)
+#elif DESC_BUF
+                    buf_store_f64(rs_Sn, (uint32_t)r.sa * 8u, part); buf_store_f64(rs_Sn, (uint32_t)r.sb * 8u, part);
+#else
+                    a.S_new[r.sa] = part; a.S_new[r.sb] = part;
+#endif
+                }
             }
         };
 
@@ -962,7 +1044,10 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
         if (ticket >= 0) flush_partials((int)gridDim.x + ticket);      // a tail piece: its own pair of partials
         else ++pc;
     }
-    if (b.wg_clock && tid == 0) b.wg_clock[2 * blockIdx.x + 1] = wall_clock64();
+    if (b.wg_clock && tid == 0) {
+        b.wg_clock[2 * blockIdx.x + 1] = wall_clock64();
+        b.wg_clock[2 * gridDim.x + blockIdx.x] = clock64() - wg_c0;          // shader-clock cycles of the same interval: the clock the box ran at
+    }
 }
 
 // Sum the block partials in a fixed order, record the traces and run the early-stop
@@ -1026,9 +1111,6 @@ __global__ __launch_bounds__(64) void k_finalize(FinArgs f) { finalize_wave(f); 
 // fixed order at the end -> bitwise reproducible.  Loads of COLSUM_U segments are in
 // flight per wave at once.
 constexpr int COLSUM_U = 8;
-#ifndef DESC_EXP                    // experiment switches of the current round (tools/build_exp.sh builds A/B libraries); 0 = production
-#define DESC_EXP 0
-#endif
 // The LAST workgroup of the launch does no column at all: it runs the bookkeeping of the previous sweep (traces,
 // stop rule) that used to be a separate one-wave launch per iteration.  If it sets the stop flag while the
 // node workgroups of this launch are running, they finish a T that nobody reads: the sweep that follows returns at once.
@@ -1085,7 +1167,7 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
                         for (int h2 = 0; h2 < 2; ++h2) {
                             const int q = l16 + 16 * (2 * round + h2);
                             if (q < nact) {
-                                const int64_t c = (int64_t)seg_base[tt] + q;
+                                const int64_t c = (int64_t)seg_base[tt] + q;          // (as buffer loads, like the band sweep's: no change, 239.1 vs 239.0 us at C4)
                                 pv[2 * u + h2] = midx[(size_t)seg_mo[tt] + q];
                                 wvv[2 * u + h2] = w[c];
                             }
@@ -2292,7 +2374,8 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     }
     // (tiny problems stay on k_sweep_node: with < 2 M cycles a 1024-thread workgroup per CU is mostly pipeline fill -- C1: 31 vs 20 us)
     const int force_band = env_int("DESC_DEBUG_VARIANT", 0);
-    h->band_ok = force_band != VARIANT_NODE && h->max_cnt <= MAX_SEG_CYCLES && h->max_deg <= BAND_ROW_CAP && (h->m_cycle >= (2 << 20) || force_band == 3);
+    h->band_ok = force_band != VARIANT_NODE && h->max_cnt <= MAX_SEG_CYCLES && h->max_deg <= BAND_ROW_CAP && (h->m_cycle >= (2 << 20) || force_band == 3) &&
+                 (int64_t)2 * m * 8 < (1ll << 32);          // 32-bit byte offsets into the CSR-aligned arrays (buffer instructions): m < 2.7e8 edges
     if ((rc = make_node_plan(prob, s, h->max_deg, h->world, h->max_cnt <= 32 ? 32 : h->max_cnt <= 128 ? 16 : 8, h->band_ok ? BAND_ROW_CAP : 0, P))) return rc;   // 8 waves x 64/lps segments
     h->band = P.band;
     lap("plan");
@@ -2427,9 +2510,9 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     if ((rc = dalloc_stream(h, &h->d_adj_seg, 2 * m, 16))) return rc;
     if ((rc = dalloc(h, &h->d_src_start, mp))) return rc;
     if ((rc = dalloc(h, &h->d_eslot, m))) return rc;
-    if ((rc = dalloc(h, &h->d_S[0], 2 * m))) return rc;
-    if ((rc = dalloc(h, &h->d_S[1], 2 * m))) return rc;
-    if ((rc = dalloc(h, &h->d_T, 2 * m))) return rc;
+    if ((rc = dalloc_stream(h, &h->d_S[0], 2 * m, 32))) return rc;      // bits 32 / 64: experiments (profiles/r03_experiments.txt), never default
+    if ((rc = dalloc_stream(h, &h->d_S[1], 2 * m, 32))) return rc;
+    if ((rc = dalloc_stream(h, &h->d_T, 2 * m, 64))) return rc;
     if ((rc = dalloc(h, &h->d_Svec, m))) return rc;
     if ((rc = dalloc(h, &h->d_chunk_desc, chunk_desc.size()))) return rc;
     if ((rc = dalloc(h, &h->d_rank_seg, (size_t)h->world + 1))) return rc;
@@ -2439,7 +2522,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     if (h->band_ok) {
         if ((rc = dalloc(h, &h->d_pieces, pieces.size()))) return rc;
         if ((rc = dalloc(h, &h->d_piece_ptr, piece_ptr.size()))) return rc;
-        if (env_int("DESC_DEBUG_WGCLOCK", 0) && (rc = dalloc(h, &h->d_wg_clock, 2 * (size_t)h->band_grid))) return rc;
+        if (env_int("DESC_DEBUG_WGCLOCK", 0) && (rc = dalloc(h, &h->d_wg_clock, 3 * (size_t)h->band_grid))) return rc;
         if ((rc = dalloc(h, &h->d_ticket, 1))) return rc;
         DESC_HIP(hipMemsetAsync(h->d_ticket, 0, sizeof(int32_t), h->stream));
     }
@@ -2740,6 +2823,14 @@ static int create_impl(const desc_problem* prob, const double* shared_rij, const
 }
 
 void desc_pgd_destroy(desc_pgd* h) { free_all(h); }
+
+}  // extern "C"
+namespace desc {
+int pgd_create_with_rij(const desc_problem* prob, const double* d_rij, const desc_structure* s, int32_t device, desc_pgd** out) {
+    return create_impl(prob, d_rij, s, device, 0, 1, out);
+}
+}  // namespace desc
+extern "C" {
 
 int desc_pgd_sizes(const desc_pgd* h, int64_t* m, int64_t* m_pos, int64_t* m_cycle, int32_t* max_cnt) {
     if (!h) return fail(DESC_ERR_INVALID, "NULL handle");
@@ -3277,6 +3368,8 @@ int desc_debug_wg_clock(desc_pgd* h, uint64_t* out, int32_t cap) {
     const int nwg = std::min(cap, h->band_grid);
     if (hipStreamSynchronize(h->stream) != hipSuccess) return 0;
     if (hipMemcpy(out, h->d_wg_clock, sizeof(uint64_t) * 2 * (size_t)nwg, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (2 * (int64_t)cap >= 3 * (int64_t)h->band_grid && nwg == h->band_grid &&          // room in out[2 * cap] for a third word per workgroup: its shader-clock cycles, at out[2 * nwg + w]
+        hipMemcpy(out + 2 * (size_t)nwg, h->d_wg_clock + 2 * (size_t)nwg, sizeof(uint64_t) * (size_t)nwg, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return nwg;
 }
 

@@ -9,6 +9,39 @@
 
 using namespace desc;
 
+namespace desc {
+// The caller's rotation array is pinned in place for the duration of the copy when it is large: a registered buffer is copied
+// by DMA at PCIe speed, a pageable one is staged through the runtime's bounce buffers (DESC_UPLOAD_PIN=0 disables).
+static hipError_t copy_rij(double* d_rij, const double* rij, int64_t m) {
+    if (m <= 0) return hipSuccess;
+    const char* pin_env = std::getenv("DESC_UPLOAD_PIN");
+    const bool pin = m >= (1 << 18) && !(pin_env && std::atoi(pin_env) == 0);
+    bool pinned = false;
+    if (pin) { pinned = hipHostRegister((void*)rij, sizeof(double) * 9 * m, hipHostRegisterDefault) == hipSuccess; if (!pinned) (void)hipGetLastError(); }
+    const hipError_t e = hipMemcpy(d_rij, rij, sizeof(double) * 9 * m, hipMemcpyHostToDevice);
+    if (pinned) (void)hipHostUnregister((void*)rij);
+    return e;
+}
+
+int upload_rij(const desc_problem* prob, int32_t device, double** d_rij) {
+    *d_rij = nullptr;
+    if (!prob || !prob->rij || prob->m <= 0) return DESC_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { (void)hipGetLastError(); return DESC_ERR_HIP; }
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return DESC_ERR_HIP; }
+    void* q = nullptr;
+    if (dev_alloc(&q, sizeof(double) * 9 * (size_t)prob->m) != hipSuccess) { (void)hipGetLastError(); return DESC_ERR_HIP; }
+    if (copy_rij((double*)q, prob->rij, prob->m) != hipSuccess) { (void)hipGetLastError(); dev_free(q); return DESC_ERR_HIP; }
+    *d_rij = (double*)q;
+    return DESC_OK;
+}
+void release_rij(double* d_rij, int32_t device) {
+    if (!d_rij) return;
+    (void)hipSetDevice(device);
+    dev_free(d_rij);
+}
+}  // namespace desc
+
 extern "C" {
 
 int desc_problem_upload(const desc_problem* prob, int32_t device, desc_device_problem** out) {
@@ -43,14 +76,7 @@ int desc_problem_upload(const desc_problem* prob, int32_t device, desc_device_pr
         build_csr(n, m, prob->ind_i, prob->ind_j, dp->rowptr, adj, adj_eid);
         return;
     }
-    // the caller's rotation array is pinned in place for the duration of the copy when it is large: a registered buffer is copied
-    // by DMA at PCIe speed, a pageable one is staged through the runtime's bounce buffers (DESC_UPLOAD_PIN=0 disables)
-    const char* pin_env = std::getenv("DESC_UPLOAD_PIN");
-    const bool pin = m >= (1 << 18) && !(pin_env && std::atoi(pin_env) == 0);
-    bool pinned = false;
-    if (pin) { pinned = hipHostRegister((void*)prob->rij, sizeof(double) * 9 * m, hipHostRegisterDefault) == hipSuccess; if (!pinned) (void)hipGetLastError(); }
-    if (m) e = hipMemcpy(dp->d_rij, prob->rij, sizeof(double) * 9 * m, hipMemcpyHostToDevice);
-    if (pinned) (void)hipHostUnregister((void*)prob->rij);
+    e = copy_rij(dp->d_rij, prob->rij, m);
     if (m && e == hipSuccess) e = hipMemcpy(dp->d_ii, prob->ind_i, sizeof(int32_t) * m, hipMemcpyHostToDevice);
     if (m && e == hipSuccess) e = hipMemcpy(dp->d_jj, prob->ind_j, sizeof(int32_t) * m, hipMemcpyHostToDevice);
     });

@@ -347,7 +347,8 @@ int desc_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes);
 int desc_debug_band_plan(const desc_problem* prob, const desc_structure* s, int32_t world, int32_t rank, int32_t grid, int64_t* stats);
 
 /* Diagnostics hook (tools/wg_clock.py): {start, end} (constant 100 MHz clock) of every workgroup of the last band sweep of a handle created
- * with DESC_DEBUG_WGCLOCK=1; returns how many workgroups were written to out[2 * cap] (0: not recorded). */
+ * with DESC_DEBUG_WGCLOCK=1; returns how many workgroups were written to out[2 * cap] (0: not recorded).  When all G workgroups fit and
+ * 2 * cap >= 3 * G, out[2 * G + w] = shader-clock cycles workgroup w ran for (cycles / duration = the clock frequency of the launch). */
 int desc_debug_wg_clock(desc_pgd* h, uint64_t* out, int32_t cap);
 /* ... and what the piece scheduler gave each of them: out[4 * w + {0,1,2,3}] = cycles, segments, pieces, CSR entries of the band rows loaded. */
 int desc_debug_wg_plan(desc_pgd* h, int64_t* out, int32_t cap);

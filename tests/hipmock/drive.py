@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 os.environ["DESC_DEBUG_GUARD"] = "1"
 os.environ["DESC_CACHE_MB"] = "0"        # every "device" block fresh from calloc: what a kernel would have produced reads back as zeros
+os.environ["DESC_DEBUG_OVERLAP_UPLOAD"] = "2"      # desc_pgd_solve: the helper-thread upload of the rotations also on these small graphs
 
 import numpy as np  # noqa: E402
 

@@ -23,6 +23,10 @@ start, end = t[:, 0] - t0, t[:, 1] - t0
 dur = end - start
 print(f"{wl}: {n} workgroups; start spread {start.max():.1f} us; end: min {end.min():.1f} mean {end.mean():.1f} max {end.max():.1f} us; "
       f"duration: min {dur.min():.1f} p10 {np.percentile(dur, 10):.1f} median {np.median(dur):.1f} p90 {np.percentile(dur, 90):.1f} max {dur.max():.1f} us")
+cyc = buf[2 * n:3 * n].astype(np.float64)
+if cyc.max() > 0:
+    mhz = cyc / np.maximum(dur, 1e-9)
+    print(f"shader clock over each workgroup's run (cycles / duration): mean {mhz.mean():.0f} MHz, min {mhz.min():.0f}, max {mhz.max():.0f}; by blockIdx % 8: {[round(float(mhz[x::8].mean())) for x in range(8)]}")
 print("mean duration by blockIdx % 8 (the XCD a workgroup lands on, round-robin dispatch):", [round(float(dur[x::8].mean()), 1) for x in range(8)])
 print("ten slowest workgroups (id, end us):", [(int(i), round(float(end[i]), 1)) for i in np.argsort(-end)[:10]])
 print("ten fastest workgroups (id, end us):", [(int(i), round(float(end[i]), 1)) for i in np.argsort(end)[:10]])
