@@ -881,12 +881,10 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
                 g.si[e] = (DESC_BAND_ABLATE & 16) ? 0.5 : s_rows[r.rbi + (int)(p & 0x7FFFu)];
             }
             const int ta = XT ? r.seg : r.sa, tb = r.sb;
-#if DESC_BUF && (DESC_EXP & 2)              // experiment: T1 and T2 in ONE load instruction (even lanes T1, odd lanes T2), exchanged inside the quads afterwards
+#if DESC_BUF             // T1 and T2 in ONE load instruction (even lanes T1, odd lanes T2), exchanged inside the quads where they are used (compute);
+                        // this and the single S store: C4 1059.5 -> 1045.8 / 1083 -> 1059 us, C2 within noise (profiles/r03_buffer_instructions.txt)
             g.T1 = buf_load_f64(rs_T, (uint32_t)((lane & 1) ? tb : ta) * 8u);
             g.T2 = 0.0;
-#elif DESC_BUF
-            g.T1 = buf_load_f64(rs_T, (uint32_t)ta * 8u);
-            g.T2 = buf_load_f64(rs_T, (uint32_t)tb * 8u);
 #else
             g.T1 = (DESC_BAND_ABLATE & 32) ? 0.25 : a.Tfull[ta];                      // column j of node i = sum(wijk(IKJ(mask)))  (:189)
             g.T2 = (DESC_BAND_ABLATE & 32) ? 0.25 : a.Tfull[tb];                      // column i of node j = sum(wijk(JKI(mask)))  (:190)
@@ -897,7 +895,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
         // arithmetic + stores of one segment group (DESC_PGD.m:193-233), everything in registers
         auto compute = [&](const Rec& r, const Str& x, const Gat& g0) {
             const int cnt = r.cnt;
-#if DESC_BUF && (DESC_EXP & 2)
+#if DESC_BUF
             Gat g = g0;
             g.T1 = dpp_mov_f64<0xA0>(g0.T1);        // quad_perm:[0,0,2,2]: the even lane's value = T1
             g.T2 = dpp_mov_f64<0xF5>(g0.T1);        // quad_perm:[1,1,3,3]: the odd lane's value = T2
@@ -987,17 +985,14 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
                     }
                     if (ADAM) { a.st.adam_m_out[c] = mo[e % EA]; a.st.adam_v_out[c] = vo[e % EA]; }
                 }
-#if DESC_BUF && (DESC_EXP & 1)              // experiment: both slots of S in ONE store instruction (lane 0 of the group: slot (i,j), lane 1: slot (j,i))
+#if DESC_BUF             // both slots of S in ONE store instruction (lane 0 of the group: slot (i,j), lane 1: slot (j,i)); `part` is the same in every lane
             if (!XT && cnt > 0 && rr < 2) buf_store_f64(rs_Sn, (uint32_t)(rr == 0 ? r.sa : r.sb) * 8u, part);
 #endif
             if (cnt > 0 && rr == 0) {
                 chg_acc += fabs(part - g.So);                                                            // :232
                 if constexpr (XT) a.s_slice[r.seg] = part;                    // sharded: k_unpack_S copies it into the CSR-aligned replica
                 else {
-#if DESC_BUF && (DESC_EXP & 1)
-#elif DESC_BUF
-                    buf_store_f64(rs_Sn, (uint32_t)r.sa * 8u, part); buf_store_f64(rs_Sn, (uint32_t)r.sb * 8u, part);
-#else
+#if !DESC_BUF
                     a.S_new[r.sa] = part; a.S_new[r.sb] = part;
 #endif
                 }
