@@ -51,6 +51,8 @@ struct desc_structure {
     // (desc_structure_get, the gather layout).
     bool host_cycles = true;
     int dev = -1;
+    void* ev_fill = nullptr;                  // hipEvent_t recorded behind the kernel that fills d_k / d_tau / d_ktau: the device builder returns while it
+                                              // runs (the host plans the solver's layout meanwhile); consumers on other streams wait for it
     int32_t *d_k = nullptr;
     unsigned long long* d_tau = nullptr;      // m, indexed by edge id (defined for edges with cycles)
     int32_t* d_ktau = nullptr;                // m

@@ -760,7 +760,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
     if (tid <= MAX_SEG_CYCLES) s_nv[tid] = tid <= a.max_cnt ? a.nv_tab[tid] : 0.0;
     double obj_acc = 0.0, chg_acc = 0.0;
 
-    constexpr bool VREC = SPW > 4;         // eight segments per wave: their records would not fit the SGPRs -- per-lane vector loads instead
+    constexpr bool VREC = SPW > 4;         // (for every shape, as buffer loads: C4 +4.7 %, C5 +3.6 %, C2 +2 % -- the scalar loads keep the records out of the address unit) eight segments per wave: their records would not fit the SGPRs -- per-lane vector loads instead
     struct RecRaw { int c0[VREC ? 1 : SPW], c1[VREC ? 1 : SPW]; EdgeInfo ei[VREC ? 1 : SPW]; int xa[XT ? (VREC ? 1 : SPW) : 1], xb[XT ? (VREC ? 1 : SPW) : 1]; int t0; };      // wave-uniform (SGPRs); VREC: this lane group's record (VGPRs)
     struct Rec { int c0, cnt, rbi, rbj, sa, sb, seg; };                   // this lane group's segment; sharded runs: seg = ta, sb = tb (exchange positions)
     struct Str { uint32_t pk[E]; double w[E], d[E], am[EA], av[EA]; };     // am / av: HybridGradient.m_t / v_t (Adam only)
@@ -786,6 +786,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
     };
 #if DESC_BUF
     const __amdgpu_buffer_rsrc_t rs_S = make_rsrc(a.S_old), rs_T = make_rsrc(a.Tfull), rs_Sn = make_rsrc(a.S_new);      // CSR-aligned: 2m doubles < 4 GiB
+    const __amdgpu_buffer_rsrc_t rs_cum = make_rsrc(a.cum), rs_ei = make_rsrc(a.einfo);          // per-lane records (VREC shapes only; C3 -1 %)
 #endif
     int pc = p0, ticket = -1;
     for (;;) {
@@ -818,7 +819,17 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
             q.t0 = pd.seg_lo + (it * NW + wv) * SPW;
             if constexpr (VREC) {
                 const int t = min(q.t0 + grp, pd.seg_hi - 1);
+#if DESC_BUF
+                {
+                    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+                    const u32x2_t cc = __builtin_amdgcn_raw_buffer_load_b64(rs_cum, t * 4, 0, 0);
+                    const u32x4_t ee = __builtin_amdgcn_raw_buffer_load_b128(rs_ei, t * 16, 0, 0);
+                    q.c0[0] = (int)cc.x; q.c1[0] = (int)cc.y;
+                    q.ei[0].rb_i = (int)ee.x; q.ei[0].rb_j = (int)ee.y; q.ei[0].slot_a = (int)ee.z; q.ei[0].slot_b = (int)ee.w;
+                }
+#else
                 q.c0[0] = a.cum[t]; q.c1[0] = a.cum[t + 1]; q.ei[0] = a.einfo[t];
+#endif
                 if constexpr (XT) { const int2 x = a.xt[t]; q.xa[0] = x.x; q.xb[0] = x.y; }
                 return q;
             }
@@ -914,9 +925,11 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
                 const double nv = cnt > 0 ? s_nv[cnt] : 0.0;
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
+                    // idle lanes (ok false) hold a copy of the segment's last cycle (load_stream clamps): what they compute from it is finite and
+                    // discarded below (ws[e] = 0, no part in any sum), so only the sums mask them
                     const bool ok = rr + LPS * e < cnt;
-                    const uint32_t p = ok ? x.pk[e] : 0u;
-                    const double w = ok ? x.w[e] : 0.0, d = ok ? x.d[e] : 0.0;
+                    const uint32_t p = x.pk[e];
+                    const double w = ok ? x.w[e] : 0.0, d = x.d[e];
                     if (ok) okm |= 1u << e;
                     const double ss = g.sj[e] + g.si[e];                                                 // S(jk)+S(ki)
                     obj_acc += w * ss;                                                                   // :233, one sweep late
@@ -2081,11 +2094,13 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
     // contiguous range of pos_edge and one stable counting sort by j per band (bands in parallel)
     // gives the order in O(m_pos + bands * n)
     P.order.resize((size_t)mp);
+    P.cum2.assign((size_t)mp + 1, 0);
     P.bstart.assign((size_t)nb + 1, mp);       // first position of every band in pos_edge
     {
-        int64_t l = 0;
+        int64_t l = 0;                         // pos_edge is sorted by (i, j): the first edge with i >= band_lo[b], by binary search from the previous band's start
         for (int64_t b = 0; b <= nb; ++b) {
-            while (l < mp && ii[pe[l]] < P.band_lo[b]) ++l;
+            const int32_t want = P.band_lo[b];
+            l = std::partition_point(pe + l, pe + mp, [&](int32_t e) { return ii[e] < want; }) - pe;
             P.bstart[b] = l;
         }
     }
@@ -2097,14 +2112,14 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
             std::fill(cnt.begin(), cnt.end(), 0);
             for (int64_t l = lo; l < hi; ++l) cnt[jj[pe[l]] + 1]++;
             for (int64_t v = 0; v < n; ++v) cnt[v + 1] += cnt[v];
-            for (int64_t l = lo; l < hi; ++l) P.order[lo + cnt[jj[pe[l]]]++] = (int32_t)l;
+            for (int64_t l = lo; l < hi; ++l) {
+                const int64_t q = lo + cnt[jj[pe[l]]]++;
+                P.order[q] = (int32_t)l;
+                P.cum2[q + 1] = (int32_t)(s->cum_ind[l + 1] - s->cum_ind[l]);        // cycle count of the segment at device position q: summed below
+            }
         }
     }, mp >= (1 << 18) ? 1 : nb + 1);          // small problems: one thread
-    P.cum2.assign((size_t)mp + 1, 0);
-    for (int64_t q = 0; q < mp; ++q) {
-        const int32_t l = P.order[q];
-        P.cum2[q + 1] = P.cum2[q] + (int32_t)(s->cum_ind[l + 1] - s->cum_ind[l]);
-    }
+    for (int64_t q = 0; q < mp; ++q) P.cum2[q + 1] += P.cum2[q];
     // Several ranks: a rank owns whole bands (its exchange layout is indexed by node ranges, k_xpos); the cuts go to the band boundaries
     // that split the cycles most evenly (a band is ~0.4 % of the work at C4), and chunks do not straddle them.
     hvec<int64_t> cut_seg;                                   // device position of the first segment of every rank, + mp
@@ -2133,8 +2148,9 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
         for (int64_t q = 0; q < mp;) {     // chunks: <= CHUNK_CAP cycles and <= CHUNK_SEG segments
             while (rnext < world && cut_seg[rnext] <= q) P.rank_chunk[rnext++] = (int64_t)P.chunk_seg.size() - 1;
             const int64_t stop = rnext < world ? cut_seg[rnext] : mp;
-            int64_t e = q;
-            while (e < stop && e - q < max_seg && P.cum2[e + 1] - P.cum2[q] <= CHUNK_CAP) ++e;
+            const int64_t lim = std::min<int64_t>(stop, q + max_seg);         // last segment boundary within CHUNK_CAP cycles: binary search (cum2 increases strictly)
+            const int64_t e = (int64_t)(std::upper_bound(P.cum2.begin() + q, P.cum2.begin() + lim + 1, (int64_t)P.cum2[q] + CHUNK_CAP,
+                                                         [](int64_t v, int32_t c) { return v < (int64_t)c; }) - P.cum2.begin()) - 1;
             q = e;                          // max_cnt <= MAX_SEG_CYCLES <= CHUNK_CAP: always advances
             P.chunk_seg.push_back((int32_t)q);
         }
@@ -2164,6 +2180,11 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
         const int32_t row_lo = P.rowptr[P.band_lo[bd]], row_len = P.rowptr[P.band_lo[bd + 1]] - row_lo;
         band_rows = std::max(band_rows, (int)row_len);
         return PieceDesc{row_lo, row_len, (int32_t)q0, (int32_t)q1};
+    };
+    // largest x in [lo, e] with cycles(lo..x) <= room (cum2 increases strictly: a binary search instead of a walk over the segments)
+    auto reach = [&](int64_t lo, int64_t e, int64_t room) {
+        return (int64_t)(std::upper_bound(cum2.begin() + lo, cum2.begin() + e + 1, (int64_t)cum2[lo] + room,
+                                          [](int64_t v, int32_t c) { return v < (int64_t)c; }) - cum2.begin()) - 1;
     };
     const int jmajor_env = env_int("DESC_DEBUG_JMAJOR", -1);
     const bool jmajor = jmajor_env >= 0 ? jmajor_env != 0 : (int64_t)2 * m * 8 > (12ll << 20);      // C3 (6.4 MB): contiguous 0.167 ms, units 0.184
@@ -2263,12 +2284,10 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
                     const int64_t e = a0;
                     cur[bd] = e;
                     while (lo < e) {
-                        int64_t x = lo;
-                        while (x < e && cum2[x + 1] - cum2[lo] <= cap) ++x;
+                        int64_t x = reach(lo, e, cap);
                         if (x == lo) x = lo + 1;
                         if (tail_target > 0 && dealt >= mcl - tail_target && (int64_t)tail.size() < MAX_TAIL_PIECES) {      // the rest of the sweep: queue
-                            x = lo;
-                            while (x < e && cum2[x + 1] - cum2[lo] <= tail_cap) ++x;
+                            x = reach(lo, e, tail_cap);
                             if (x == lo) x = lo + 1;
                             tail.push_back(piece_of(bd, lo, x));
                             dealt += cum2[x] - cum2[lo];
@@ -2290,8 +2309,7 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
                             const int64_t room = fit_target - load[wt] - (merge ? 0 : PC);
                             if (room < 2048 && load[wmin] + PC + 2048 > fit_target) fit_target += 4096;       // everybody is full: raise the bar a little
                             else if (room >= 2048) {
-                                int64_t y = lo;
-                                while (y < x && cum2[y + 1] - cum2[lo] <= room) ++y;
+                                const int64_t y = reach(lo, x, room);
                                 if (y > lo) x = y;           // cut the unit where this workgroup reaches the target
                                 else x = lo + 1;
                             } else {                         // the band's resident workgroup is full: the least loaded one takes the unit instead
@@ -2323,8 +2341,7 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
                 const int64_t e = a0;
                 cur[bd] = e;
                 while (lo < e) {                             // split units above the cap
-                    int64_t x = lo;
-                    while (x < e && cum2[x + 1] - cum2[lo] <= cap) ++x;
+                    int64_t x = reach(lo, e, cap);
                     if (x == lo) x = lo + 1;
                     std::pop_heap(heap.begin(), heap.end(), cmp);
                     auto& top = heap.back();
@@ -2538,6 +2555,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     else if ((rc = dalloc(h, &d_rij, 9 * (size_t)m))) return rc;
     hvec<int32_t> rank_seg32(h->rank_seg.begin(), h->rank_seg.end());
     int32_t* d_devpos = nullptr;
+    if (dev_cycles && s->ev_fill) DESC_HIP(hipStreamWaitEvent(h->stream, (hipEvent_t)s->ev_fill, 0));       // the structure's sampled cycles may still be on their way
     if (dev_cycles) {
         int32_t* d_order = nullptr;
         if ((rc = dalloc(h, &d_devpos, m)) || (rc = dalloc(h, &d_order, mp))) return rc;

@@ -333,7 +333,8 @@ __global__ void k_iota(int32_t* p, int64_t n) {
 
 struct DevBuf {
     hvec<void*> p;
-    ~DevBuf() { for (void* q : p) dev_free(q); }
+    ~DevBuf() { release(); }
+    void release() { for (void* q : p) dev_free(q); p.clear(); }
     template <class T> int alloc(T** out, size_t count) {
         void* q = nullptr;
         DESC_HIP(dev_alloc(&q, sizeof(T) * (count ? count : 1)));
@@ -349,9 +350,9 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
     auto t_lap = t0;
     const char* tenv = getenv("DESC_DEBUG_TIMING");
     const bool timing = tenv && atoi(tenv) != 0;
-    auto lap = [&](const char* what) {
+    auto lap = [&](const char* what, bool wait = true) {
         if (!timing) return;
-        (void)hipDeviceSynchronize();
+        if (wait) (void)hipDeviceSynchronize();
         auto now = std::chrono::steady_clock::now();
         fprintf(stderr, "[desc_amd] structure_device %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_lap).count());
         t_lap = now;
@@ -488,11 +489,20 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
             DESC_HIP(hipFuncSetAttribute((const void*)k_fill_cycles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const char* tenv2 = getenv("DESC_DEBUG_EXACT_SELECT");     // tests: force the exact (tie-safe) ranking path
         const unsigned g = (unsigned)std::min<int64_t>(8192, (mp + 3) / 4);
+        D.release();                   // (waits for the device: everything above has been copied back already) -- nothing below may block on the fill
         hipLaunchKernelGGL(k_fill_cycles, dim3(g), dim3(256), lds, 0, s->d_pos, s->d_cum, s->d_ii, s->d_jj, d_bits, s->d_k, s->d_tau, s->d_ktau,
                            mp, (int)words, (int)n_sample, seed, cap, (tenv2 && atoi(tenv2) != 0) ? 1 : 0);
         DESC_HIP(hipGetLastError());
-        DESC_HIP(hipDeviceSynchronize());
-        lap("fill");
+        // The sampled cycles (5.8 ms of kernel at C4) are not waited for: the caller goes on to plan the solver's layout on the host (11 ms at
+        // C4) while they are drawn.  Whoever reads d_k / d_tau / d_ktau on another stream waits for ev_fill (setup_node); the exports to the
+        // host use the NULL stream like the kernel and are ordered behind it.  DESC_DEBUG_SYNC_FILL=1: wait here (A/B, timing laps).
+        hipEvent_t ev = nullptr;
+        DESC_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        s->ev_fill = (void*)ev;
+        DESC_HIP(hipEventRecord(ev, 0));
+        const char* sf = getenv("DESC_DEBUG_SYNC_FILL");
+        if (sf && atoi(sf) != 0) DESC_HIP(hipDeviceSynchronize());
+        lap("fill (launched)", false);
     }
     s->ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return DESC_OK;
@@ -592,6 +602,7 @@ int structure_ensure_host(desc_structure* s) {
 void structure_free_device(desc_structure* s) {
     if (!s || s->dev < 0) return;
     (void)hipSetDevice(s->dev);
+    if (s->ev_fill) { (void)hipEventSynchronize((hipEvent_t)s->ev_fill); (void)hipEventDestroy((hipEvent_t)s->ev_fill); s->ev_fill = nullptr; }
     for (void* q : {(void*)s->d_k, (void*)s->d_tau, (void*)s->d_ktau, (void*)s->d_rowptr, (void*)s->d_adj, (void*)s->d_adj_eid, (void*)s->d_ii,
                     (void*)s->d_jj, (void*)s->d_pos, (void*)s->d_cum, (void*)s->d_poe, (void*)s->d_bits, (void*)s->d_rank})
         dev_free(q);
