@@ -812,6 +812,11 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
         const uint32_t c_len = (uint32_t)(uniform_load(a.cum, pd.seg_hi) - c_lo) + 8u;           // + the 16-byte tail the arrays are padded by
         const __amdgpu_buffer_rsrc_t rs_pk = make_rsrc(a.pk + c_lo, c_len * 4u), rs_w = make_rsrc(a.w_old + c_lo, c_len * 8u),
                                      rs_d = make_rsrc(a.S0 + c_lo, c_len * 8u), rs_wn = make_rsrc(a.w_new + c_lo, c_len * 8u);
+        __amdgpu_buffer_rsrc_t rs_am = rs_w, rs_av = rs_w, rs_amo = rs_wn, rs_avo = rs_wn;       // Adam moments (HybridGradient.m:28-35), read and written per cycle
+        if constexpr (ADAM) {
+            rs_am = make_rsrc(a.st.adam_m + c_lo, c_len * 8u); rs_av = make_rsrc(a.st.adam_v + c_lo, c_len * 8u);
+            rs_amo = make_rsrc(a.st.adam_m_out + c_lo, c_len * 8u); rs_avo = make_rsrc(a.st.adam_v_out + c_lo, c_len * 8u);
+        }
 #endif
 
         auto load_raw = [&](int it) -> RecRaw {            // past the end: the piece's last segment, cnt = 0
@@ -874,7 +879,11 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
                     x.pk[e] = a.pk[c]; x.w[e] = a.w_old[c]; x.d[e] = a.S0[c];
 #endif
                 }
+#if DESC_BUF
+                if (ADAM) { x.am[e % EA] = buf_load_f64(rs_am, (uint32_t)cr * 8u); x.av[e % EA] = buf_load_f64(rs_av, (uint32_t)cr * 8u); }
+#else
                 if (ADAM) { x.am[e % EA] = a.st.adam_m[c]; x.av[e % EA] = a.st.adam_v[c]; }
+#endif
             }
             return x;
         };
@@ -996,7 +1005,11 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
                         a.w_new[c] = ws[e];
 #endif
                     }
+#if DESC_BUF
+                    if (ADAM) { buf_store_f64(rs_amo, (uint32_t)(r.c0 + rr + LPS * e) * 8u, mo[e % EA]); buf_store_f64(rs_avo, (uint32_t)(r.c0 + rr + LPS * e) * 8u, vo[e % EA]); }
+#else
                     if (ADAM) { a.st.adam_m_out[c] = mo[e % EA]; a.st.adam_v_out[c] = vo[e % EA]; }
+#endif
                 }
 #if DESC_BUF             // both slots of S in ONE store instruction (lane 0 of the group: slot (i,j), lane 1: slot (j,i)); `part` is the same in every lane
             if (!XT && cnt > 0 && rr < 2) buf_store_f64(rs_Sn, (uint32_t)(rr == 0 ? r.sa : r.sb) * 8u, part);
