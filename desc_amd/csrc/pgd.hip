@@ -786,6 +786,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
     };
 #if DESC_BUF
     const __amdgpu_buffer_rsrc_t rs_S = make_rsrc(a.S_old), rs_T = make_rsrc(a.Tfull), rs_Sn = make_rsrc(a.S_new);      // CSR-aligned: 2m doubles < 4 GiB
+    const __amdgpu_buffer_rsrc_t rs_sl = XT ? make_rsrc(a.s_slice) : rs_Sn;                        // sharded runs: this rank's all-gather slice
     const __amdgpu_buffer_rsrc_t rs_cum = make_rsrc(a.cum), rs_ei = make_rsrc(a.einfo);          // per-lane records (VREC shapes only; C3 -1 %)
 #endif
     int pc = p0, ticket = -1;
@@ -1016,8 +1017,13 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
 #endif
             if (cnt > 0 && rr == 0) {
                 chg_acc += fabs(part - g.So);                                                            // :232
-                if constexpr (XT) a.s_slice[r.seg] = part;                    // sharded: k_unpack_S copies it into the CSR-aligned replica
-                else {
+                if constexpr (XT) {                                           // sharded: k_unpack_S copies it into the CSR-aligned replica
+#if DESC_BUF
+                    buf_store_f64(rs_sl, (uint32_t)r.seg * 8u, part);
+#else
+                    a.s_slice[r.seg] = part;
+#endif
+                } else {
 #if !DESC_BUF
                     a.S_new[r.sa] = part; a.S_new[r.sb] = part;
 #endif
@@ -1039,7 +1045,13 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
             for (int base = 0; base < pd.row_len; base += RL * NT) {
                 double v[RL];
 #pragma unroll
-                for (int u = 0; u < RL; ++u) v[u] = a.S_old[pd.row_lo + min(base + u * NT + tid, pd.row_len - 1)];
+                for (int u = 0; u < RL; ++u) {
+#if DESC_BUF
+                    v[u] = buf_load_f64(rs_S, (uint32_t)(pd.row_lo + min(base + u * NT + tid, pd.row_len - 1)) * 8u);
+#else
+                    v[u] = a.S_old[pd.row_lo + min(base + u * NT + tid, pd.row_len - 1)];
+#endif
+                }
 #pragma unroll
                 for (int u = 0; u < RL; ++u) if (base + u * NT + tid < pd.row_len) s_rows[base + u * NT + tid] = v[u];
             }
@@ -1131,6 +1143,11 @@ __global__ __launch_bounds__(64) void k_finalize(FinArgs f) { finalize_wave(f); 
 // round-robin; third vertices inside a segment are distinct), copies are added in a
 // fixed order at the end -> bitwise reproducible.  Loads of COLSUM_U segments are in
 // flight per wave at once.
+// Round 3, what bounds it (profiles/r03_colsum_bound.txt): with the LDS adds replaced by plain stores or removed altogether the kernel takes
+// 227.3 / 224.7 us instead of 227.0 at C4 -- the adds are free, the time is the scattered ~100-byte runs of `w` (one per incident segment,
+// ~3 TB/s of real traffic).  A flat variant (a node's contributing cycles as ONE contiguous range of two static streams, column + cycle
+// index, every lane of every load busy, no segment records) was built and measured: 250 vs 228 us at C4, 29.7 vs 27.0 at C2, 404 vs 392 at
+// C5 -- its 4 extra bytes per entry cost more than the idle lanes of the 16-lanes-per-segment form; removed again.
 constexpr int COLSUM_U = 8;
 // The LAST workgroup of the launch does no column at all: it runs the bookkeeping of the previous sweep (traces,
 // stop rule) that used to be a separate one-wave launch per iteration.  If it sets the stop flag while the

@@ -12,7 +12,7 @@ import csv, sys
 a, wl, f = sys.argv[1:4]
 out = []
 for r in csv.DictReader(open(f)):
-    if "k_colsum_node" in r["Name"] or "k_sweep_band" in r["Name"]:
+    if "k_colsum" in r["Name"] or "k_sweep_band" in r["Name"]:
         out.append("%s avg %.1f us" % (r["Name"].split("(")[0].replace("void desc::", "").replace("desc::", ""), float(r["AverageNs"]) / 1e3))
 print("%s value=%-5s %s" % (wl, a, "; ".join(out)))
 PY
