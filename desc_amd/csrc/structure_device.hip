@@ -440,7 +440,7 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
     s->pos_edge.resize((size_t)mp);
     s->cum_ind.assign((size_t)mp + 1, 0);
     s->max_cnt = std::min(max_codeg, n_sample);
-    hvec<int32_t> cum32((size_t)mp + 1, 0), pos_of_edge((size_t)std::max<int64_t>(m, 1), -1);
+    hvec<int32_t> cum32((size_t)mp + 1, 0), pos_of_edge((size_t)std::max<int64_t>(m, 1));     // both filled by the second threaded pass below
     {   // compaction of the edges with cycles + prefix sum of their cycle counts, in chunks (threads for large m)
         unsigned hw = std::thread::hardware_concurrency();
         const int T = m >= (1 << 20) ? (int)std::max(1u, std::min(hw, 16u)) : 1;
@@ -458,18 +458,19 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
             int64_t l = c_pos[t], c = c_cyc[t];
             for (int64_t e = a; e < b; ++e) {
                 const int32_t cd = s->codeg[e];
-                if (cd <= 0) continue;
+                if (cd <= 0) { pos_of_edge[e] = -1; continue; }
                 s->pos_edge[l] = (int32_t)e; pos_of_edge[e] = (int32_t)l;
                 c += std::min(cd, n_sample);
                 s->cum_ind[++l] = c;
+                cum32[l] = (int32_t)std::min<int64_t>(c, INT32_MAX);          // (m_cycle < 2^31 - 1 is checked right below)
             }
         });
+        if (m == 0) pos_of_edge[0] = -1;
     }
     s->m_cycle = s->cum_ind[mp];
     if (s->m_cycle >= (1ll << 31) - 1) return fail(DESC_ERR_TOO_LARGE, "m_cycle = %lld exceeds 2^31-2", (long long)s->m_cycle);
     if (max_codeg > MAX_CODEG_LDS)
         return fail(DESC_ERR_TOO_LARGE, "an edge has %d common neighbours (> %d): use DESC_BUILD_HOST", max_codeg, MAX_CODEG_LDS);
-    for (int64_t l = 0; l <= mp; ++l) cum32[l] = (int32_t)s->cum_ind[l];
     lap("host median/cum");
     const int64_t mc = s->m_cycle;
     s->k.clear(); s->e_jk.clear(); s->e_ki.clear(); s->ikj.clear(); s->jki.clear();
