@@ -2095,6 +2095,14 @@ struct NodePlan {
 // sweep keeps them in the LDS); row_cap == 0: bands of a fixed number of nodes sized for the L2 (k_sweep_node).
 int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_deg, int world, int max_seg, int row_cap, NodePlan& P) {
     const int64_t mp = s->m_pos, n = prob->n, m = prob->m;
+    const bool timing = env_int("DESC_DEBUG_TIMING", 0) > 1;
+    auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[desc_amd] node plan %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_lap).count());
+        t_lap = now;
+    };
     const int32_t* ii = prob->ind_i; const int32_t* jj = prob->ind_j; const int32_t* pe = s->pos_edge.data();
     if ((int64_t)s->rowptr_host.size() == n + 1) P.rowptr = s->rowptr_host;      // the device builder already made them
     else {
@@ -2134,6 +2142,7 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
             P.bstart[b] = l;
         }
     }
+    lap("bands + starts");
     host_parallel(nb, [&](int64_t b0, int64_t b1) {
         hvec<int32_t> cnt((size_t)n + 1);
         for (int64_t b = b0; b < b1; ++b) {
@@ -2149,7 +2158,9 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
             }
         }
     }, mp >= (1 << 18) ? 1 : nb + 1);          // small problems: one thread
+    lap("per-band sorts");
     for (int64_t q = 0; q < mp; ++q) P.cum2[q + 1] += P.cum2[q];
+    lap("prefix sums");
     // Several ranks: a rank owns whole bands (its exchange layout is indexed by node ranges, k_xpos); the cuts go to the band boundaries
     // that split the cycles most evenly (a band is ~0.4 % of the work at C4), and chunks do not straddle them.
     hvec<int64_t> cut_seg;                                   // device position of the first segment of every rank, + mp
@@ -2187,6 +2198,7 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
         const int64_t nch = (int64_t)P.chunk_seg.size() - 1;
         while (rnext <= world) P.rank_chunk[rnext++] = nch;
     }
+    lap("chunks");
     return DESC_OK;
 }
 
@@ -2202,6 +2214,14 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
                       int G, hvec<PieceDesc>& pieces, hvec<int32_t>& piece_ptr, int& band_rows, bool& jmajor_out, int* tail_first_out = nullptr, int* n_tail_out = nullptr) {
     const hvec<int32_t>& cum2 = P.cum2;
     const int64_t n = prob->n, m = prob->m;
+    const bool timing = env_int("DESC_DEBUG_TIMING", 0) > 1;
+    auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[desc_amd] band plan %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_lap).count());
+        t_lap = now;
+    };
     band_rows = 0;
     const int64_t nbands = (int64_t)P.band_lo.size() - 1;
     hvec<hvec<PieceDesc>> per_wg((size_t)G);
@@ -2384,6 +2404,7 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
         }
     }
     pieces.clear();
+    lap("units dealt");
     piece_ptr.assign((size_t)G + 1, 0);
     for (int b = 0; b < G; ++b) {
         pieces.insert(pieces.end(), per_wg[b].begin(), per_wg[b].end());
