@@ -701,6 +701,21 @@ __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rs, uint32
     double d; __builtin_memcpy(&d, &v, 8); return d;
 }
 __device__ __forceinline__ uint32_t buf_load_u32(__amdgpu_buffer_rsrc_t rs, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0); }
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buf_load_f64x2(__amdgpu_buffer_rsrc_t rs, uint32_t off, double& a0, double& a1) {      // 16 bytes, 8-byte aligned
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+    const u32x2_t lo = {v.x, v.y}, hi = {v.z, v.w};
+    __builtin_memcpy(&a0, &lo, 8); __builtin_memcpy(&a1, &hi, 8);
+}
+__device__ __forceinline__ void buf_load_u32x2(__amdgpu_buffer_rsrc_t rs, uint32_t off, uint32_t& a0, uint32_t& a1) {
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+    a0 = v.x; a1 = v.y;
+}
+__device__ __forceinline__ void buf_store_f64x2(__amdgpu_buffer_rsrc_t rs, uint32_t off, double d0, double d1) {
+    u32x2_t lo, hi; __builtin_memcpy(&lo, &d0, 8); __builtin_memcpy(&hi, &d1, 8);
+    const u32x4_t v = {lo.x, lo.y, hi.x, hi.y};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off, 0, 0);
+}
 __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t rs, uint32_t off, double d) {
     u32x2_t v; __builtin_memcpy(&v, &d, 8);
     __builtin_amdgcn_raw_buffer_store_b64(v, rs, (int)off, 0, 0);
@@ -763,6 +778,17 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
     constexpr bool VREC = SPW > 4;         // (for every shape, as buffer loads: C4 +4.7 %, C5 +3.6 %, C2 +2 % -- the scalar loads keep the records out of the address unit) eight segments per wave: their records would not fit the SGPRs -- per-lane vector loads instead
     struct RecRaw { int c0[VREC ? 1 : SPW], c1[VREC ? 1 : SPW]; EdgeInfo ei[VREC ? 1 : SPW]; int xa[XT ? (VREC ? 1 : SPW) : 1], xb[XT ? (VREC ? 1 : SPW) : 1]; int t0; };      // wave-uniform (SGPRs); VREC: this lane group's record (VGPRs)
     struct Rec { int c0, cnt, rbi, rbj, sa, sb, seg; };                   // this lane group's segment; sharded runs: seg = ta, sb = tb (exchange positions)
+    // Which cycles of its segment a lane owns.  Round 2: rr + LPS * e (every stream instruction reads one contiguous run of 8-byte words).
+    // Round 3 (PAIR): the adjacent pairs 2 rr + 2 LPS * (e / 2) + {0, 1}, so that the 8-byte streams (old weights, S0, Adam moments) are read
+    // 16 bytes per lane: the CU's address unit takes 16.4 cycles for a contiguous 8-byte-per-lane load and 16.3 for a 16-byte one
+    // (tools/probes/gather_probe.hip, profiles/r03_gather_probe.txt), i.e. half the cycles per byte.  The packed words become 8-byte loads
+    // (16.4 cycles for two cycles' worth instead of 2 x 6.2), the weight stores 16-byte stores (43.6 = 2 x 21.9: no change).
+    // Only the shapes the BASELINE workloads run (LPS <= 16); the long-segment shapes keep the round-2 map.
+#ifndef DESC_PAIR
+#define DESC_PAIR 1
+#endif
+    constexpr bool PAIR = DESC_PAIR && DESC_BUF && (E % 2 == 0) && LPS <= 16 && !(DESC_BAND_ABLATE & (128 | 256));
+    auto cidx = [&](int e) { return PAIR ? 2 * rr + (e & 1) + 2 * LPS * (e >> 1) : rr + LPS * e; };
     struct Str { uint32_t pk[E]; double w[E], d[E], am[EA], av[EA]; };     // am / av: HybridGradient.m_t / v_t (Adam only)
     struct Gat { double sj[E], si[E], T1, T2, So; };
 
@@ -827,7 +853,6 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
                 const int t = min(q.t0 + grp, pd.seg_hi - 1);
 #if DESC_BUF
                 {
-                    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
                     const u32x2_t cc = __builtin_amdgcn_raw_buffer_load_b64(rs_cum, t * 4, 0, 0);
                     const u32x4_t ee = __builtin_amdgcn_raw_buffer_load_b128(rs_ei, t * 16, 0, 0);
                     q.c0[0] = (int)cc.x; q.c1[0] = (int)cc.y;
@@ -867,6 +892,24 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
         };
         auto load_stream = [&](const Rec& r) -> Str {      // unconditional: idle lanes repeat a valid cycle of the segment
             Str x;
+#if DESC_BUF
+            if constexpr (PAIR) {
+#pragma unroll
+                for (int h = 0; h < E / 2; ++h) {
+                    // the pair's first cycle, clamped into the segment; its second one may lie past the segment's end (an odd count, idle lanes):
+                    // that is the next segment's first cycle or the arrays' padding -- readable, masked in compute; its packed word is replaced by
+                    // the first one's, so that the gathers formed from it stay inside rows i and j
+                    const int first = min(2 * rr + 2 * LPS * h, max(r.cnt, 1) - 1);
+                    const uint32_t cr = (uint32_t)(r.c0 + first);
+                    buf_load_u32x2(rs_pk, cr * 4u, x.pk[2 * h], x.pk[2 * h + 1]);
+                    buf_load_f64x2(rs_w, cr * 8u, x.w[2 * h], x.w[2 * h + 1]);
+                    buf_load_f64x2(rs_d, cr * 8u, x.d[2 * h], x.d[2 * h + 1]);
+                    if (ADAM) { buf_load_f64x2(rs_am, cr * 8u, x.am[(2 * h) % EA], x.am[(2 * h + 1) % EA]); buf_load_f64x2(rs_av, cr * 8u, x.av[(2 * h) % EA], x.av[(2 * h + 1) % EA]); }
+                    if (first + 1 >= r.cnt) x.pk[2 * h + 1] = x.pk[2 * h];
+                }
+                return x;
+            }
+#endif
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int cr = r.c0 + min(rr + LPS * e, max(r.cnt, 1) - 1);
@@ -928,7 +971,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
             double part = 0.0;
             if (DESC_BAND_ABLATE & 2) {
 #pragma unroll
-                for (int e = 0; e < E; ++e) { const bool ok = rr + LPS * e < cnt; if (ok) okm |= 1u << e; ws[e] = x.w[e] + g.sj[e] + g.si[e] + x.d[e] + (double)(x.pk[e] & 1u) + g.T1 + g.T2; }
+                for (int e = 0; e < E; ++e) { const bool ok = cidx(e) < cnt; if (ok) okm |= 1u << e; ws[e] = x.w[e] + g.sj[e] + g.si[e] + x.d[e] + (double)(x.pk[e] & 1u) + g.T1 + g.T2; }
                 part = ws[0];
             } else
             if (__ballot(cnt > 0) != 0ull) {               // wave-uniform; no memory operation inside
@@ -937,7 +980,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
                 for (int e = 0; e < E; ++e) {
                     // idle lanes (ok false) hold a copy of the segment's last cycle (load_stream clamps): what they compute from it is finite and
                     // discarded below (ws[e] = 0, no part in any sum), so only the sums mask them
-                    const bool ok = rr + LPS * e < cnt;
+                    const bool ok = cidx(e) < cnt;
                     const uint32_t p = x.pk[e];
                     const double w = ok ? x.w[e] : 0.0, d = x.d[e];
                     if (ok) okm |= 1u << e;
@@ -994,6 +1037,22 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
                 part = group_sum<LPS>(sn);                                                               // :229
             }
             if (DESC_BAND_ABLATE & 8) { obj_acc += ws[0] + ws[E - 1] + part; return; }
+#if DESC_BUF
+            if constexpr (PAIR) {                      // 16-byte stores of the pairs; the last pair of an odd segment: its first cycle alone
+#pragma unroll
+                for (int h = 0; h < E / 2; ++h) {
+                    const uint32_t off = (uint32_t)(r.c0 + cidx(2 * h)) * 8u;
+                    const bool ok0 = (okm >> (2 * h)) & 1u, ok1 = (okm >> (2 * h + 1)) & 1u;
+                    if (ok1) {
+                        buf_store_f64x2(rs_wn, off, ws[2 * h], ws[2 * h + 1]);
+                        if (ADAM) { buf_store_f64x2(rs_amo, off, mo[(2 * h) % EA], mo[(2 * h + 1) % EA]); buf_store_f64x2(rs_avo, off, vo[(2 * h) % EA], vo[(2 * h + 1) % EA]); }
+                    } else if (ok0) {
+                        buf_store_f64(rs_wn, off, ws[2 * h]);
+                        if (ADAM) { buf_store_f64(rs_amo, off, mo[(2 * h) % EA]); buf_store_f64(rs_avo, off, vo[(2 * h) % EA]); }
+                    }
+                }
+            } else
+#endif
 #pragma unroll
             for (int e = 0; e < E; ++e)
                 if ((okm >> e) & 1u) {
@@ -1042,6 +1101,22 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
         {
             // up to 19 loads in flight per thread: one batch for 1024 threads, two for 512 (38 at once cost the 64 x 4 instance 3.5 %)
             constexpr int RL = (BAND_ROW_CAP + 1023) / 1024;
+#if DESC_BUF && DESC_PAIR
+            // 16 bytes per lane (half the address-unit cycles per byte, see PAIR): thread t takes the doubles 2 t, 2 t + 1 of every batch of 2 NT
+            constexpr int RL2 = (RL + 1) / 2;
+            for (int base = 0; base < pd.row_len; base += 2 * RL2 * NT) {
+                double v0[RL2], v1[RL2];
+#pragma unroll
+                for (int u = 0; u < RL2; ++u)
+                    buf_load_f64x2(rs_S, (uint32_t)(pd.row_lo + min(base + 2 * (u * NT + tid), max(pd.row_len - 2, 0))) * 8u, v0[u], v1[u]);
+#pragma unroll
+                for (int u = 0; u < RL2; ++u) {
+                    const int t0 = base + 2 * (u * NT + tid);
+                    if (t0 + 1 < pd.row_len) { s_rows[t0] = v0[u]; s_rows[t0 + 1] = v1[u]; }
+                    else if (t0 < pd.row_len) s_rows[t0] = pd.row_len >= 2 ? v1[u] : v0[u];      // the row's last double: the clamped load ended on it
+                }
+            }
+#else
             for (int base = 0; base < pd.row_len; base += RL * NT) {
                 double v[RL];
 #pragma unroll
@@ -1055,6 +1130,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
 #pragma unroll
                 for (int u = 0; u < RL; ++u) if (base + u * NT + tid < pd.row_len) s_rows[base + u * NT + tid] = v[u];
             }
+#endif
         }
         __syncthreads();
         G0 = issue_gathers(R0, S0);
