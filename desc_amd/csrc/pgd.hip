@@ -1224,7 +1224,8 @@ __global__ __launch_bounds__(64) void k_finalize(FinArgs f) { finalize_wave(f); 
 // 227.3 / 224.7 us instead of 227.0 at C4 -- the adds are free, the time is the scattered ~100-byte runs of `w` (one per incident segment,
 // ~3 TB/s of real traffic).  A flat variant (a node's contributing cycles as ONE contiguous range of two static streams, column + cycle
 // index, every lane of every load busy, no segment records) was built and measured: 250 vs 228 us at C4, 29.7 vs 27.0 at C2, 404 vs 392 at
-// C5 -- its 4 extra bytes per entry cost more than the idle lanes of the 16-lanes-per-segment form; removed again.
+// C5 -- its 4 extra bytes per entry cost more than the idle lanes of the 16-lanes-per-segment form; removed again.  Two adjacent cycles per lane
+// (16-byte loads, what gained 4-5 % in the band sweep): 309 vs 238 us -- half as many independent requests in flight per wave; removed too.
 constexpr int COLSUM_U = 8;
 // The LAST workgroup of the launch does no column at all: it runs the bookkeeping of the previous sweep (traces,
 // stop rule) that used to be a separate one-wave launch per iteration.  If it sets the stop flag while the
