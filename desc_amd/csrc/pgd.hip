@@ -783,11 +783,13 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
     // 16 bytes per lane: the CU's address unit takes 16.4 cycles for a contiguous 8-byte-per-lane load and 16.3 for a 16-byte one
     // (tools/probes/gather_probe.hip, profiles/r03_gather_probe.txt), i.e. half the cycles per byte.  The packed words become 8-byte loads
     // (16.4 cycles for two cycles' worth instead of 2 x 6.2), the weight stores 16-byte stores (43.6 = 2 x 21.9: no change).
-    // Only the shapes the BASELINE workloads run (LPS <= 16); the long-segment shapes keep the round-2 map.
+    // Only the constant / piecewise-step shapes for segments of up to 64 cycles (LPS <= 16: what the BASELINE workloads run).  Measured on the others:
+    // unsampled C5 (<64,4>) 8.05 -> 7.89 ms; the Adam instances (<32,2> at C2 / C4) no gain (2.19 -> 2.27 ms at C4, 0.251 -> 0.267 at C2) -- both
+    // keep the round-2 map, and with it results bitwise equal to k_sweep_node's (which two tests assert).
 #ifndef DESC_PAIR
 #define DESC_PAIR 1
 #endif
-    constexpr bool PAIR = DESC_PAIR && DESC_BUF && (E % 2 == 0) && LPS <= 16 && !(DESC_BAND_ABLATE & (128 | 256));
+    constexpr bool PAIR = DESC_PAIR && DESC_BUF && (E % 2 == 0) && LPS <= 16 && !ADAM && !(DESC_BAND_ABLATE & (128 | 256));
     // (four adjacent cycles per lane -- the packed words as ONE 16-byte load -- measured on top: C4 1025-1054 vs 989-1034 us, C2 +3 %: not adopted)
     auto cidx = [&](int e) { return PAIR ? 2 * rr + (e & 1) + 2 * LPS * (e >> 1) : rr + LPS * e; };
     struct Str { uint32_t pk[E]; double w[E], d[E], am[EA], av[EA]; };     // am / av: HybridGradient.m_t / v_t (Adam only)
