@@ -19,6 +19,11 @@ namespace desc {
 hipError_t dev_alloc(void** out, size_t bytes);
 hipError_t dev_alloc_uncached(void** out, size_t bytes);      // MTYPE UC block (same cache, never handed out as an ordinary one)
 void dev_free(void* p);
+void dev_free_idle(void* p);                                   // the same without the device synchronisation: the caller has just synchronised
+// Streams are pooled like blocks: creating and destroying a HIP stream costs 1-2 ms each (a hardware queue), more than the whole PGD loop of
+// the reference's demo-size graphs (C1: 1.7 ms of 6.3 ms per solve).  stream_release: the stream must be idle.
+hipError_t stream_acquire(hipStream_t* out);
+void stream_release(hipStream_t s);
 
 // One DPP-moved copy of a double (two 32-bit v_mov_b32_dpp).  All four controls used
 // here are permutations of the full wave, so every lane is written and no `old` value

@@ -87,6 +87,10 @@ void dev_free(void* p) {
     // hipFree waits for the device before it releases a block; a parked block may be handed out again at once, so the same
     // guarantee is kept here (idle device: microseconds)
     (void)hipDeviceSynchronize();
+    dev_free_idle(p);
+}
+void dev_free_idle(void* p) {
+    if (!p) return;
     Block b{};
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -106,6 +110,33 @@ void dev_free(void* p) {
     if (cur != b.dev) (void)hipSetDevice(cur);
 }
 
+
+// ---- streams
+namespace {
+struct PooledStream { int dev; hipStream_t s; };
+std::vector<PooledStream> g_streams;                 // idle non-blocking streams (at most 8 are kept)
+}  // namespace
+hipError_t stream_acquire(hipStream_t* out) {
+    *out = nullptr;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (size_t i = 0; i < g_streams.size(); ++i)
+            if (g_streams[i].dev == dev) { *out = g_streams[i].s; g_streams[i] = g_streams.back(); g_streams.pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+void stream_release(hipStream_t s) {
+    if (!s) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_streams.size() < 8) { g_streams.push_back(PooledStream{dev, s}); return; }
+    } else (void)hipGetLastError();
+    (void)hipStreamDestroy(s);
+}
 
 // ---- host blocks (hostmem.h)
 namespace {
@@ -173,6 +204,14 @@ size_t host_block_trim() {
 
 extern "C" int64_t desc_trim_memory(void) {
     (void)desc::host_block_trim();
+    {
+        std::vector<desc::PooledStream> ss;
+        { std::lock_guard<std::mutex> lk(desc::g_mu); ss.swap(desc::g_streams); }
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        for (const desc::PooledStream& q : ss) { (void)hipSetDevice(q.dev); (void)hipStreamDestroy(q.s); }
+        (void)hipSetDevice(cur);
+    }
     std::vector<desc::Block> blocks;
     {
         std::lock_guard<std::mutex> lk(desc::g_mu);

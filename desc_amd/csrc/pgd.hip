@@ -1834,12 +1834,13 @@ int64_t local_cycles(const desc_pgd* h) { return h->variant == VARIANT_NODE ? h-
 void free_all(desc_pgd* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    for (void* q : h->allocs) dev_free(q);
+    (void)hipDeviceSynchronize();                              // once for all blocks and both streams (dev_free would wait per block)
+    for (void* q : h->allocs) dev_free_idle(q);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     for (hipEvent_t e : {h->ev_col, h->ev_rs, h->ev_sw, h->ev_done}) if (e) (void)hipEventDestroy(e);
-    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
-    if (h->stream && !h->borrowed_stream) (void)hipStreamDestroy(h->stream);
+    stream_release(h->comm_stream);
+    if (!h->borrowed_stream) stream_release(h->stream);
     delete h;
 }
 
@@ -2935,7 +2936,7 @@ static int create_impl(const desc_problem* prob, const double* shared_rij, const
     }
     int rc = DESC_OK;
     hipError_t he = hipSetDevice(device);
-    if (he == hipSuccess) he = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (he == hipSuccess) he = stream_acquire(&h->stream);
     if (he != hipSuccess) { rc = fail(DESC_ERR_HIP, "device %d: %s", device, hipGetErrorString(he)); free_all(h); return rc; }
 
     // variant: NODE unless the packed per-cycle word or the LDS column copies do not fit
@@ -3297,7 +3298,7 @@ int desc_pgd_shard_bind(desc_pgd* h, double* T_send, double* T_recv, double* sal
     } else if (!T_send || !T_recv || !sall) return fail(DESC_ERR_INVALID, "NULL exchange buffer");
     h->x_T = T_send; h->x_Trecv = T_recv; h->x_sall = sall;
     if (hip_stream) {          // run on the caller's stream so collectives and kernels are ordered
-        if (h->stream) (void)hipStreamDestroy(h->stream);
+        if (h->stream) { (void)hipStreamSynchronize(h->stream); stream_release(h->stream); }
         h->stream = (hipStream_t)hip_stream;
         h->borrowed_stream = true;
     }
@@ -3415,7 +3416,7 @@ int desc_pgd_shard_set_collectives(desc_pgd* h, const desc_collectives* c) {
     h->force_coll = env_int("DESC_DEBUG_FORCE_COLLECTIVES", 0) != 0 && h->coll.reduce_scatter && h->coll.all_gather;
     if (!h->x_sall && (rc = desc_pgd_shard_bind(h, nullptr, nullptr, nullptr, nullptr))) return rc;
     if (!h->comm_stream) {
-        DESC_HIP(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        DESC_HIP(stream_acquire(&h->comm_stream));
         for (hipEvent_t* e : {&h->ev_col, &h->ev_rs, &h->ev_sw, &h->ev_done}) DESC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     return DESC_OK;
