@@ -2397,10 +2397,12 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
             //  * fit to target (DESC_DEBUG_FIT per mille, default 0): in the last part of the cycles a unit is cut where the workgroup that takes
             //    it reaches the common target load -- the lists end level to a segment.  Measured: no gain at C4, C5 slightly worse; what is left
             //    of the spread is not in the plan (even XCDs run 1.5 % slower than odd ones: profiles/r03_experiments.txt);
-            //  * shared tail (DESC_DEBUG_TAIL per mille, default 0): the last part is queued as small pieces for whichever workgroup finishes
-            //    first (k_sweep_band).  Measured: the queue levels the end times (max - mean 4.8 % -> 1.4 %) but its ~700 small pieces each
-            //    load their band rows: the mean rises by as much (profiles/r03_experiments.txt).
-            const int64_t tail_target = tail_first_out ? mcl * std::max(0, std::min(500, env_int("DESC_DEBUG_TAIL", 0))) / 1000 : 0;
+            //  * shared tail (DESC_DEBUG_TAIL per mille, default 20): the last part is queued as small pieces for whichever workgroup finishes
+            //    first (k_sweep_band).  First measured with 10 % of the cycles in the queue: it levels the end times (max - mean 4.8 % -> 1.4 %) but
+            //    its ~700 small pieces each load their band rows and the mean rises by as much (profiles/r03_experiments.txt).  With the final
+            //    kernel and 1.5-4 % in the queue: C4 996-1014 -> 984-999 us, C5 1585-1596 -> 1569-1580 (about -1 %, profiles/r03_piece_cost.txt):
+            //    2 % is the default.
+            const int64_t tail_target = tail_first_out ? mcl * std::max(0, std::min(500, env_int("DESC_DEBUG_TAIL", 20))) / 1000 : 0;
             const int64_t tail_cap = std::max<int64_t>(4096, tail_target / (MAX_TAIL_PIECES - 64));
             const int64_t fit_from = mcl - mcl * std::max(0, std::min(500, env_int("DESC_DEBUG_FIT", 0))) / 1000;
             int64_t fit_target = -1;                         // common final load, fixed when the fitting phase starts

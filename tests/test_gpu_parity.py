@@ -67,6 +67,24 @@ def test_uniform_constant_step(lib, oracle, n, p, seed, variant):
     check(out, ref, s0, S0)
 
 
+@pytest.mark.parametrize("tail", ["0", "20", "300"])
+def test_band_sweep_j_block_units_and_shared_tail(lib, oracle, tail, monkeypatch):
+    """The j-block-major unit scheduler (forced onto a small graph: narrow j-blocks, many units per workgroup) with and without the shared tail
+    of small pieces that whichever workgroup finishes first takes by ticket (DESC_DEBUG_TAIL, per mille of the cycles): which workgroup
+    sweeps a segment changes nothing in S_vec and w; the objective's workgroup partials are per piece, so its sums too are the same."""
+    monkeypatch.setenv("DESC_DEBUG_JMAJOR", "1")
+    monkeypatch.setenv("DESC_DEBUG_JBLOCK", "24")
+    monkeypatch.setenv("DESC_DEBUG_TAIL", tail)
+    mo, nn, ii, jj, rij = make_problem("uniform", n=300, p=0.5, q=0.2, sigma=0.1, seed=21)
+    st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=5, iters=60, lr=0.01)
+    arrays, s0, out = run_gpu(lib, nn, ii, jj, rij, c_params(60, lr=0.01, seed=5), variant="band")
+    assert "band" in out["kernel"]
+    check(out, ref, s0, S0)
+    monkeypatch.setenv("DESC_DEBUG_TAIL", "0")
+    _, _, plain = run_gpu(lib, nn, ii, jj, rij, c_params(60, lr=0.01, seed=5), variant="band")
+    assert np.array_equal(out["S_vec"], plain["S_vec"]) and np.array_equal(out["w"], plain["w"])
+
+
 @pytest.mark.parametrize("variant", ["band", "node", "gather"])
 def test_nonuniform_self_consistent(lib, oracle, variant):
     mo, nn, ii, jj, rij = make_problem("nonuniform", n=150, p=0.4, seed=6, crpt_type="self-consistent")
