@@ -65,31 +65,6 @@ __global__ __launch_bounds__(256) void k_cemp_round(const int32_t* pos_edge, con
                                                     const double* S_old, double* S_new, int m_pos, int nsample, double beta) {
     const int lane = threadIdx.x & 63;
     const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
-    if (nsample <= 64) {
-        // the usual case (CEMP.m's default: 50 samples): one lane per sample, and CEMP_EW edges per wave and pass -- their index loads are all issued
-        // before the first gather, their gathers before the first use: one edge at a time leaves the wave with two or three loads in flight and
-        // the kernel bound by the latency of the S gathers (1.82 ms per round at C4 for 2 GB of streams)
-        constexpr int CEMP_EW = 4;
-        for (int64_t l0 = wid * CEMP_EW; l0 < m_pos; l0 += nw * CEMP_EW) {
-            int e1[CEMP_EW], e2[CEMP_EW]; double d0[CEMP_EW], s1[CEMP_EW], s2[CEMP_EW];
-            const bool on = lane < nsample;
-#pragma unroll
-            for (int u = 0; u < CEMP_EW; ++u) {
-                const int64_t l = min(l0 + u, (int64_t)m_pos - 1), c = l * nsample + (on ? lane : 0);
-                e1[u] = e_ki[c]; e2[u] = e_jk[c]; d0[u] = S0[c];
-            }
-#pragma unroll
-            for (int u = 0; u < CEMP_EW; ++u) { s1[u] = S_old[e1[u]]; s2[u] = S_old[e2[u]]; }
-#pragma unroll
-            for (int u = 0; u < CEMP_EW; ++u) {
-                const double w = on ? exp(-beta * (s1[u] + s2[u])) : 0.0;               // :118-120
-                const double wsum = group_sum<64>(w);
-                const double acc = group_sum<64>((w / wsum) * d0[u]);                    // :122-125
-                if (lane == 0 && l0 + u < m_pos) S_new[pos_edge[l0 + u]] = acc;
-            }
-        }
-        return;
-    }
     for (int64_t l = wid; l < m_pos; l += nw) {
         if (nsample <= 4 * 64) {                       // weights stay in registers: one pass over the samples
             double wr[4] = {0.0, 0.0, 0.0, 0.0}, dr[4] = {0.0, 0.0, 0.0, 0.0};
