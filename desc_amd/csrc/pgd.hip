@@ -940,7 +940,8 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
             for (int e = 0; e < E; ++e) {
                 const uint32_t p = x.pk[e];
 #if DESC_BUF
-                g.sj[e] = buf_load_f64(rs_S, (uint32_t)(r.rbj + (int)((p >> 16) & 0x7FFFu)) * 8u);
+                g.sj[e] = (DESC_BAND_ABLATE & 1) ? s_rows[((p >> 16) & 0x7FFFu) + (lane & 7)]
+                        : buf_load_f64(rs_S, (uint32_t)(((DESC_BAND_ABLATE & 64) ? (r.rbj & 0x1FFFF) : r.rbj) + (int)((p >> 16) & 0x7FFFu)) * 8u);   // 64: rows confined to 1 MiB (L2 hits)
 #else
                 g.sj[e] = (DESC_BAND_ABLATE & 1) ? s_rows[((p >> 16) & 0x7FFFu) + (lane & 7)]
                         : a.S_old[((DESC_BAND_ABLATE & 64) ? (r.rbj & 0x1FFFF) : r.rbj) + (int)((p >> 16) & 0x7FFFu)];   // 64: rows confined to 1 MiB (L2 hits)
@@ -950,7 +951,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
             const int ta = XT ? r.seg : r.sa, tb = r.sb;
 #if DESC_BUF             // T1 and T2 in ONE load instruction (even lanes T1, odd lanes T2), exchanged inside the quads where they are used (compute);
                         // this and the single S store: C4 1059.5 -> 1045.8 / 1083 -> 1059 us, C2 within noise (profiles/r03_buffer_instructions.txt)
-            g.T1 = buf_load_f64(rs_T, (uint32_t)((lane & 1) ? tb : ta) * 8u);
+            g.T1 = (DESC_BAND_ABLATE & 32) ? 0.25 : buf_load_f64(rs_T, (uint32_t)((lane & 1) ? tb : ta) * 8u);
             g.T2 = 0.0;
 #else
             g.T1 = (DESC_BAND_ABLATE & 32) ? 0.25 : a.Tfull[ta];                      // column j of node i = sum(wijk(IKJ(mask)))  (:189)
