@@ -7,7 +7,7 @@ for wl in "$@"; do
   for lib in $LIBS; do
     export DESC_AMD_LIB=$GRAFT_REPO_ROOT/$lib
     rm -rf /tmp/ab_prof
-    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_prof -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 30 --warmup 5 --no-cpu-baseline --no-convergence > /dev/null 2>&1
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_prof -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps ${STEPS:-30} --warmup ${WARMUP:-5} --no-cpu-baseline --no-convergence > /dev/null 2>&1
     f=$(find /tmp/ab_prof -name "*kernel_stats.csv" | head -1)
     python3 - "$(basename $lib)" "$wl" "$f" <<'PY'
 import csv, sys
