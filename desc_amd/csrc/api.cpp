@@ -47,11 +47,18 @@ void desc_params_default(desc_params* p) {
     p->build_where = DESC_BUILD_DEVICE;
 }
 
+static int structure_build_checked(const desc_problem* prob, int32_t n_sample_min, uint64_t seed, int32_t where, int32_t device, desc_structure** out,
+                                   bool validated);
 int desc_structure_build(const desc_problem* prob, int32_t n_sample_min, uint64_t seed,
                          int32_t where, int32_t device, desc_structure** out) {
+    return structure_build_checked(prob, n_sample_min, seed, where, device, out, false);
+}
+// validated: the caller (desc_pgd_solve) has just run validate_problem on this edge list
+static int structure_build_checked(const desc_problem* prob, int32_t n_sample_min, uint64_t seed, int32_t where, int32_t device, desc_structure** out,
+                                   bool validated) {
     if (!out) return fail(DESC_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    int rc = validate_problem(prob, false);
+    int rc = validated ? DESC_OK : validate_problem(prob, false);
     if (rc) return rc;
     if (n_sample_min < 1) return fail(DESC_ERR_INVALID, "n_sample_min must be >= 1");
     desc_structure* s = new (std::nothrow) desc_structure();
@@ -158,9 +165,9 @@ int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* 
     try {
     run_threads(overlap_upload ? 2 : 1, [&](int share) {
         if (share == 1) { (void)upload_rij(prob, p->device, &d_rij); return; }      // failed: d_rij stays NULL, the handle uploads for itself
-        rc = desc_structure_build(prob, p->n_sample_min > 0 ? p->n_sample_min : 30, p->seed, p->build_where, p->device, &s);
+        rc = structure_build_checked(prob, p->n_sample_min > 0 ? p->n_sample_min : 30, p->seed, p->build_where, p->device, &s, true);
         if (rc == DESC_ERR_TOO_LARGE && p->build_where == DESC_BUILD_DEVICE)      // device budget exceeded: host builder
-            rc = desc_structure_build(prob, p->n_sample_min > 0 ? p->n_sample_min : 30, p->seed, DESC_BUILD_HOST, p->device, &s);
+            rc = structure_build_checked(prob, p->n_sample_min > 0 ? p->n_sample_min : 30, p->seed, DESC_BUILD_HOST, p->device, &s, true);
     });
     } catch (...) { release_rij(d_rij, p->device); if (s) { structure_free_device(s); delete s; } throw; }
     if (rc) { release_rij(d_rij, p->device); return rc; }

@@ -210,15 +210,33 @@ int validate_problem(const desc_problem* prob, bool need_rij) {
     if (need_rij && prob->m > 0 && !prob->rij) return fail(DESC_ERR_INVALID, "rij is NULL");
     if (prob->m >= (1ll << 30)) return fail(DESC_ERR_TOO_LARGE, "m = %lld exceeds 2^30-1", (long long)prob->m);
     if (prob->n >= (1ll << 31)) return fail(DESC_ERR_TOO_LARGE, "n = %lld exceeds 2^31-1", (long long)prob->n);
-    for (int64_t e = 0; e < prob->m; ++e) {
-        int32_t i = prob->ind_i[e], j = prob->ind_j[e];
+    // first offending row, if any (large edge lists: the rows are checked in chunks by several threads, the smallest offending row is reported --
+    // the same one a sequential scan finds)
+    const int64_t m = prob->m;
+    auto first_bad = [&](int64_t a, int64_t b) -> int64_t {
+        for (int64_t e = a; e < b; ++e) {
+            const int32_t i = prob->ind_i[e], j = prob->ind_j[e];
+            if (i < 0 || j >= prob->n || i >= j) return e;
+            if (e > 0) {
+                const int32_t pi = prob->ind_i[e - 1], pj = prob->ind_j[e - 1];
+                if (pi > i || (pi == i && pj >= j)) return e;
+            }
+        }
+        return -1;
+    };
+    int64_t bad = -1;
+    if (m >= (1 << 20)) {
+        const int T = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 8u));
+        std::vector<int64_t> found((size_t)T, -1);
+        run_threads(T, [&](int t) { found[(size_t)t] = first_bad(m * t / T, m * (t + 1) / T); });
+        for (int t = 0; t < T && bad < 0; ++t) bad = found[(size_t)t];
+    } else bad = first_bad(0, m);
+    if (bad >= 0) {
+        const int64_t e = bad;
+        const int32_t i = prob->ind_i[e], j = prob->ind_j[e];
         if (i < 0 || j >= prob->n || i >= j)
             return fail(DESC_ERR_INVALID, "edge %lld = (%d,%d): need 0 <= i < j < n = %lld", (long long)e, i, j, (long long)prob->n);
-        if (e > 0) {
-            int32_t pi = prob->ind_i[e - 1], pj = prob->ind_j[e - 1];
-            if (pi > i || (pi == i && pj >= j))
-                return fail(DESC_ERR_INVALID, "Ind is not strictly sorted by (i,j) at row %lld (DESC_PGD.m:5 requires it)", (long long)e);
-        }
+        return fail(DESC_ERR_INVALID, "Ind is not strictly sorted by (i,j) at row %lld (DESC_PGD.m:5 requires it)", (long long)e);
     }
     return DESC_OK;
 }

@@ -109,6 +109,22 @@ def test_structure_rejects_bad_input(lib):
         lib.Structure.build(lib.ProblemArrays(3, np.array([0, 0], dtype=np.int32), np.array([1, 1], dtype=np.int32)))  # duplicate
 
 
+def test_large_edge_list_reports_the_first_offending_row(lib):
+    """Edge lists of 2^20 rows and more are validated in chunks by several threads: the row reported is the first offending one, as in a
+    sequential scan (two defects planted, in different chunks)."""
+    n = 1600
+    iu, ju = np.triu_indices(n, 1)
+    ii = iu.astype(np.int32)[:1_200_000].copy(); jj = ju.astype(np.int32)[:1_200_000].copy()
+    assert len(ii) >= 1 << 20
+    ii[[900_000, 900_001]] = ii[[900_001, 900_000]]; jj[[900_000, 900_001]] = jj[[900_001, 900_000]]      # unsorted at row 900001 ...
+    jj[300_000] = ii[300_000]                                                                             # ... and i == j at row 300000: reported
+    with pytest.raises(lib.DescError, match=r"edge 300000 = .*i < j"):
+        lib.Structure.build(lib.ProblemArrays(n, ii, jj))
+    jj[300_000] = ju[300_000]
+    with pytest.raises(lib.DescError, match="sorted by \\(i,j\\) at row 900001"):
+        lib.Structure.build(lib.ProblemArrays(n, ii, jj))
+
+
 def test_structure_edge_cases(lib):
     # tree: no triangles; median([]) = NaN -> n_sample = 30 (DESC_PGD.m:43)
     a = lib.Structure.build(lib.ProblemArrays(5, np.array([0, 1, 2, 2], dtype=np.int32), np.array([1, 2, 3, 4], dtype=np.int32))).arrays()
