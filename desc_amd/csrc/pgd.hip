@@ -1237,6 +1237,7 @@ constexpr int COLSUM_U = 8;
 // kernel consumes them (node-major, then incident segment, then contributing cycle; `moff` = start of a CSR slot's run), read
 // sequentially -- instead of the 4-byte packed words of the cycles, which sit in scattered 50-byte runs next to the weights
 // (round 2: -25 % of this pass's sectors).
+template <int CL>
 __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, const int2* adj_seg, const uint32_t* moff, const uint16_t* midx, const double* w,
                                                      double* Tfull, int n, int stride_cols, const DevState* st, const int32_t* xpos, FinArgs fin, int32_t* tail_ticket, const int32_t* node_order) {
     if (blockIdx.x == gridDim.x - 1) {
@@ -1268,23 +1269,28 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
         // with more than 16 contributing cycles take further passes.  Every load of a batch is
         // issued before any result is touched (a use between loads would make the compiler wait
         // for each one).
-        const int sub = lane >> 4, l16 = lane & 15;
-        for (int g0 = wv; 4 * g0 < deg; g0 += 4 * COLSUM_U) {      // groups of 4 consecutive segments, dealt to waves round-robin
+        // CL lanes per segment, i.e. 2 CL slots per segment and round.  16 is right when a segment has 12-25 contributing cycles per endpoint
+        // (C2, C3, C4); with ~9 (C5: 30 sampled cycles, 30 % of them with a sampled mirror) half of a 16-lane group's loads and adds are
+        // idle: 8 lanes and 8 segments per instruction there -- C5 389.5 -> 370 us; at C4 / C3 / C2 the narrower groups cost +2.6 / +2.7 / +15 %
+        // (second rounds), so the host picks by the average run length (setup_node).
+        constexpr int SPI = 64 / CL;          // segments per wave instruction
+        const int sub = lane / CL, l16 = lane % CL;
+        for (int g0 = wv; SPI * g0 < deg; g0 += 4 * COLSUM_U) {      // groups of SPI consecutive segments, dealt to waves round-robin
             // pieces 0 and 1 (contributing cycles 0..31 of each segment) are loaded together;
             // segments with more take further rounds
-            for (int round = 0; round < MAX_SEG_CYCLES / 32; ++round) {
+            for (int round = 0; round < MAX_SEG_CYCLES / (2 * CL); ++round) {
                 uint32_t pv[2 * COLSUM_U]; double wvv[2 * COLSUM_U];
                 bool more = false;
 #pragma unroll
                 for (int u = 0; u < COLSUM_U; ++u) {
-                    const int tt = 4 * (g0 + 4 * u) + sub;
+                    const int tt = SPI * (g0 + 4 * u) + sub;
                     pv[2 * u] = 0xFFFFu; pv[2 * u + 1] = 0xFFFFu; wvv[2 * u] = 0.0; wvv[2 * u + 1] = 0.0;
                     if (tt < deg) {
                         const int nact = seg_cf[tt] & 0x1FF;
-                        more |= nact > 32 * (round + 1);
+                        more |= nact > 2 * CL * (round + 1);
 #pragma unroll
                         for (int h2 = 0; h2 < 2; ++h2) {
-                            const int q = l16 + 16 * (2 * round + h2);
+                            const int q = l16 + CL * (2 * round + h2);
                             if (q < nact) {
                                 const int64_t c = (int64_t)seg_base[tt] + q;          // (as buffer loads, like the band sweep's: no change, 239.1 vs 239.0 us at C4)
                                 pv[2 * u + h2] = midx[(size_t)seg_mo[tt] + q];
@@ -1302,7 +1308,7 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
 #pragma unroll
                 for (int u = 0; u < 2 * COLSUM_U; ++u)
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4)
+                    for (int s4 = 0; s4 < SPI; ++s4)
                         if (sub == s4 && pv[u] != 0xFFFFu) unsafeAtomicAdd(&mine[pv[u]], wvv[u]);
 #else
 #pragma unroll
@@ -1719,7 +1725,7 @@ struct desc_pgd {
     bool band_jmajor = false;   // band sweep: j-block-major units (large graphs) instead of contiguous ranges
     int grid = 0;               // sweep grid (multiple of 8)
     int obj_grid = 0;
-    int colsum_grid = 0, colsum_stride = 0;
+    int colsum_grid = 0, colsum_stride = 0, colsum_cl = 16;     // colsum_cl: lanes per segment in k_colsum_node (8 when the runs are short)
     int band = 0;
     bool band_ok = false;       // k_sweep_band applies (segments <= 64 cycles, rows fit the LDS)
     int band_grid = 0, band_rows = 0;
@@ -2006,7 +2012,12 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
         FinArgs fin = fin_args(h, h->d_partials, captured ? sweep_parts(h, adam) : h->pending_parts, h->pending_fin, 0);
         if (captured) { fin.t = 0; fin.dev_t = 1; }          // which sweep to book-keep: DevState.next_fin, at replay time
         else fin.t_after = t;                                // the next column-sum launch (direct or replayed) book-keeps sweep t
-        hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int)), h->stream,
+        if (h->colsum_cl == 8)
+            hipLaunchKernelGGL(k_colsum_node<8>, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int)), h->stream,
+                               h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, h->d_w[rd], h->d_T, (int)h->n,
+                               h->colsum_stride, h->d_state, (const int32_t*)nullptr, fin, h->d_ticket, h->d_node_order);
+        else
+        hipLaunchKernelGGL(k_colsum_node<16>, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int)), h->stream,
                            h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, h->d_w[rd], h->d_T, (int)h->n,
                            h->colsum_stride, h->d_state, (const int32_t*)nullptr, fin, h->d_ticket, h->d_node_order);
         h->pending_fin = 0;
@@ -2767,7 +2778,10 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     {
         const size_t lds = (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int));
         if (lds > 64 * 1024)
-            DESC_HIP(hipFuncSetAttribute((const void*)k_colsum_node, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        {
+            DESC_HIP(hipFuncSetAttribute((const void*)k_colsum_node<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            DESC_HIP(hipFuncSetAttribute((const void*)k_colsum_node<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
     }
     if (h->band_ok) {      // the band rows + the nv table in dynamic LDS: more than the 64 KiB default
         h->band_lds = ((size_t)h->band_rows + MAX_SEG_CYCLES + 1) * sizeof(double);
@@ -2838,6 +2852,12 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         for (int64_t v = 0; v < n; ++v) { rb[v] = (uint32_t)tot; tot += rs[v]; }
         if (tot >= (1ull << 32)) return fail(DESC_ERR_TOO_LARGE, "column-index stream exceeds 2^32 entries");
         if ((rc = dalloc_stream(h, &h->d_midx, (size_t)tot + 8, 8))) return rc;
+        {   // average run length (contributing cycles per segment and endpoint) decides the lanes per segment of the column sums
+            const double avg_run = nsl > 0 ? (double)tot / (2.0 * (double)nsl) : 0.0;
+            const int forced_cl = env_int("DESC_DEBUG_COLSUM_CL", 0);
+            h->colsum_cl = forced_cl == 8 || forced_cl == 16 ? forced_cl : (avg_run > 0.0 && avg_run <= 10.5 ? 8 : 16);
+            if (timing) fprintf(stderr, "[desc_amd] column sums: %.2f contributing cycles per segment and endpoint on average -> %d lanes per segment\n", avg_run, h->colsum_cl);
+        }
         if ((rc = upload(h, d_rowbase, rb.data(), (size_t)n))) return rc;
         hipLaunchKernelGGL(k_midx_fill, dim3(g16), dim3(256), 0, h->stream, h->d_rowptr, h->d_adj_seg, d_rowbase, h->d_moff, (int)n);
         hipLaunchKernelGGL(k_midx_entries, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, (2 * m * 16 + 255) / 256))), dim3(256), 0, h->stream,
@@ -3317,7 +3337,12 @@ bool shard_direct(const desc_pgd* h) { return h->world == 1 && !h->force_coll &&
 int shard_enqueue_colsum(desc_pgd* h, hipStream_t st) {
     const int rd = h->t_done & 1;
     const bool direct = shard_direct(h);
-    hipLaunchKernelGGL(k_colsum_node, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int)), st,
+    if (h->colsum_cl == 8)
+        hipLaunchKernelGGL(k_colsum_node<8>, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int)), st,
+                           h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, h->d_w[rd], direct ? h->d_T : h->x_T, (int)h->n, h->colsum_stride, h->d_state,
+                           direct ? (const int32_t*)nullptr : h->d_xpos, FinArgs{}, h->d_ticket, h->d_node_order);
+    else
+    hipLaunchKernelGGL(k_colsum_node<16>, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int)), st,
                        h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, h->d_w[rd], direct ? h->d_T : h->x_T, (int)h->n, h->colsum_stride, h->d_state,
                        direct ? (const int32_t*)nullptr : h->d_xpos, FinArgs{}, h->d_ticket, h->d_node_order);
     DESC_HIP(hipGetLastError());
