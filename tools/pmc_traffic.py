@@ -38,10 +38,13 @@ def main():
     a = ap.parse_args()
     fetch, write = per_kernel(a.fetch_dir, "FETCH_SIZE"), per_kernel(a.write_dir, "WRITE_SIZE")
     entry, total = {}, 0.0
+    # instances of the per-process warm-up problem (a handful of launches: another template instance of the same kernel) are not part of an iteration
+    launches = {k: max(len(fetch.get(k, [])), len(write.get(k, []))) for k in set(fetch) | set(write)}
+    most = max(launches.values(), default=0)
     for kname in sorted(set(fetch) | set(write)):
         short = kname.split("<")[0].split("(")[0].replace("void ", "").replace("desc::", "").strip()
         fac = next((v for k, v in ITER_KERNELS.items() if short.startswith(k)), None)
-        if fac is None:
+        if fac is None or launches[kname] * 4 < most:
             continue
         fr = sum(fetch.get(kname, [0])) / max(1, len(fetch.get(kname, [0]))) * 1024.0
         wr = sum(write.get(kname, [0])) / max(1, len(write.get(kname, [0]))) * 1024.0
@@ -49,10 +52,6 @@ def main():
                                      "launches_sampled": len(fetch.get(kname, []))})
         e["fetch_raw_bytes"] += fr; e["write_bytes"] += wr; e["traffic_bytes"] += fac * fr + wr
         total += fac * fr + wr
-    # kernels of the per-process warm-up problem (a handful of launches) are not part of an iteration
-    most = max((e["launches_sampled"] for e in entry.values()), default=0)
-    for k in [k for k, e in entry.items() if e["launches_sampled"] * 4 < most]:
-        total -= entry[k]["traffic_bytes"]; del entry[k]
     entry["per_iteration_bytes"] = total
     # upper bound: the same x2 for the column-sum kernel's short scattered runs (uncalibrated width)
     entry["per_iteration_bytes_upper"] = sum(2.0 * e["fetch_raw_bytes"] + e["write_bytes"] for e in entry.values() if isinstance(e, dict))
