@@ -45,6 +45,7 @@ WORKLOADS = {
     "C5": dict(kind="uniform", n=10000, p=0.1, q=0.3, sigma=0.1, model="uniform", seed=4),
 }
 HBM_PEAK_GBS = 8000.0     # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_COPY_GBS = 6290.0     # measured device-to-device copy rate, same guide: what a kernel that only streams can reach
 
 
 def describe(name):
@@ -72,7 +73,9 @@ def generate(name):
 
 
 def cpu_baseline(nn, ii, jj, rij, arrays, budget_s=20.0, max_iters=50, threads=None):
-    """Time the oracle's C/OpenMP restatement of the same sweep on this host (threads=None: min(16, granted CPUs))."""
+    """Time the oracle's C/OpenMP restatement of the same sweep on this host (threads=None: every CPU granted to this process --
+    affinity mask cut down by the cgroup quota, oracle.granted_cpus()).  Also returns the oracle's result: main() compares the GPU's
+    S_vec after the same number of iterations with it (`parity_vs_cpu`)."""
     from oracle import oracle as O
     O.build()
     L = O.lib()
@@ -98,9 +101,25 @@ def cpu_baseline(nn, ii, jj, rij, arrays, budget_s=20.0, max_iters=50, threads=N
             model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
     except OSError:
         pass
+    g = O.granted_cpus()
     return dict(value=iters / dt, unit="iters/s", cores=cores, kind="port",
                 sample=f"{iters} PGD iterations of the same workload (oracle/desc_oracle.c, OpenMP)",
+                cpus_granted=g["granted"], cpus_in_affinity_mask=g["affinity"], cgroup_cpu_quota=g["cgroup_quota"],
                 host_cpus=os.cpu_count(), cpu_model=model), ref, iters
+
+
+def parity_vs_cpu(lib, prob, ref, iters, seed, n_sample_min=30):
+    """The north star's acceptance figure, stated: mean / max |S_vec(GPU) - S_vec(CPU oracle)| after the same `iters` iterations
+    of the same workload on the same cycle structure (the oracle ran on the structure the GPU built; one desc_pgd_solve call
+    rebuilds it from the same seed).  BASELINE.md plan item 4; SURVEY.md 8c bound: max <= 1e-10."""
+    p = lib.default_params()
+    p.iters = iters; p.lr = 0.01; p.seed = seed; p.patience = (1 << 31) - 1; p.n_sample_min = n_sample_min
+    out = lib.solve(prob, p)
+    d = np.abs(out["S_vec"] - ref["S_vec"])
+    do = np.abs(out["obj"] - ref["obj"][:out["iters_run"]]) / np.maximum(np.abs(ref["obj"][:out["iters_run"]]), 1e-300)
+    return {"iters": int(iters), "mean_abs": float(d.mean()), "max_abs": float(d.max()), "objective_max_rel": float(do.max()),
+            "what": "S_vec of the HIP path vs oracle/desc_oracle.c (OpenMP) after the same iterations, same structure",
+            "north_star_bound_mean_abs": 1e-6, "test_bound_max_abs": 1e-10}
 
 
 def literal_baseline(budget_iters=4):
@@ -182,6 +201,7 @@ def measure(lib, name, K, W, seed, convergence, keep_arrays, n_sample_min=30):
     out = solver.download()
     m_cycle, m_pos, m = solver.m_cycle, solver.m_pos, solver.m
     kname = solver.kernel_name()
+    lay = solver.layout_stats()
     conv = None
     if convergence:
         # wall-clock to the reference's own stopping rule (DESC_PGD.m:243-256: objective decrease < 1e-5 for 30
@@ -211,11 +231,23 @@ def measure(lib, name, K, W, seed, convergence, keep_arrays, n_sample_min=30):
     bytes_per_launch = 72.0 * m_cycle + 12.0 * m_pos
     achieved = bytes_per_launch / (ms_kernel * 1e-3) / 1e9 if ms_kernel else 0.0
     traffic, traffic_src = load_traffic(name)
+    # What THIS layout has to stream per iteration at the very least: the sweep's 28 bytes per cycle (old and new
+    # weight, S0, packed word), the column sums' 10 bytes per (cycle, endpoint) whose mirror was sampled (weight + 16-bit column index),
+    # 12 bytes per segment (record + new S).  The 72-byte count above prices four 8-byte gathers per cycle that the band layout serves from
+    # the LDS and the caches: on graphs that fit the caches `frac` can therefore exceed 1 -- it is the contract's figure, not an HBM fraction.
+    floor_bytes = 28.0 * m_cycle + 10.0 * lay.get("colsum_entries", 0) + 12.0 * m_pos if ("node" in kname or "band" in kname) else bytes_per_launch
+    sec = ms_kernel * 1e-3 if ms_kernel else float("inf")
     res = dict(
-        name=name, mo=mo, nn=nn, ii=ii, jj=jj, rij=rij, arrays=arrays, dt=dt, out=out, m=m, m_pos=m_pos, m_cycle=m_cycle,
+        name=name, mo=mo, nn=nn, ii=ii, jj=jj, rij=rij, prob=prob, arrays=arrays, dt=dt, out=out, m=m, m_pos=m_pos, m_cycle=m_cycle,
         n_sample=int(sizes["n_sample"]),
         roofline={"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                   "traffic": traffic, "traffic_source": traffic_src,
+                  "frac_traffic": (traffic / sec / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                  "frac_of_copy_peak": (traffic / sec / 1e9 / HBM_COPY_GBS) if traffic else None, "copy_peak": HBM_COPY_GBS,
+                  "floor_bytes": floor_bytes, "floor_ms_at_copy_peak": floor_bytes / (HBM_COPY_GBS * 1e9) * 1e3,
+                  "note": "frac = 72-byte algorithmic count / kernel time / 8 TB/s (the contract's figure; it prices gathers the band layout serves "
+                          "from LDS and caches, so it can exceed 1 on cache-resident graphs); frac_traffic = PMC-measured HBM bytes over the same time",
+                  "layout": lay,
                   "kernel": ("k_colsum_node + " + kname + "0> (one iteration = both launches)") if ("node" in kname or "band" in kname) else kname,
                   "bytes_per_launch": bytes_per_launch, "kernel_ms": ms_kernel},
         setup_ms={"generate": t_gen * 1e3, "structure_device": t_struct * 1e3, "upload_layout_cycle_d": t_create * 1e3},
@@ -336,6 +368,7 @@ def main():
         cb, ref, it = cpu_baseline(r["nn"], r["ii"], r["jj"], r["rij"], r["arrays"], budget_s=12.0, max_iters=10 if name in ("C4", "C5") else 50)
         line["cpu_baseline"] = cb
         line["gpu_over_cpu"] = line["value"] / cb["value"]
+        line["parity_vs_cpu"] = parity_vs_cpu(_lib, r["prob"], ref, it, args.seed, nsm)
         r["arrays"] = None
     else:
         line["cpu_baseline"] = None
@@ -346,9 +379,10 @@ def main():
                "m_cycle": x["m_cycle"], "m_pos": x["m_pos"], "n_sample": x["n_sample"], "roofline": x["roofline"],
                "setup_ms": x["setup_ms"], "end_to_end": x["end_to_end"], "to_patience_exit_lr1": x["conv"], "mean_abs_err_vs_truth": x["err"]}
         if not args.no_cpu_baseline:
-            cb2, _, _ = cpu_baseline(x["nn"], x["ii"], x["jj"], x["rij"], x["arrays"], budget_s=6.0, max_iters=50)
+            cb2, ref2, it2 = cpu_baseline(x["nn"], x["ii"], x["jj"], x["rij"], x["arrays"], budget_s=6.0, max_iters=50)
             sec["cpu_baseline"] = cb2
             sec["gpu_over_cpu"] = sec["value"] / cb2["value"]
+            sec["parity_vs_cpu"] = parity_vs_cpu(_lib, x["prob"], ref2, it2, args.seed)
             # SURVEY.md 8d's other two data points (reported, never the target): the same port on one thread, and
             # the interpreted literal restatement on C1
             one, _, _ = cpu_baseline(x["nn"], x["ii"], x["jj"], x["rij"], x["arrays"], budget_s=5.0, max_iters=6, threads=1)

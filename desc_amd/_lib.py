@@ -26,10 +26,10 @@ EXPORTS = [
     "desc_sample_key", "desc_params_default",
     "desc_pgd_create", "desc_pgd_destroy", "desc_pgd_run", "desc_pgd_run_traced", "desc_pgd_reset", "desc_pgd_iterate",
     "desc_pgd_iterate_timed", "desc_pgd_sync", "desc_pgd_download", "desc_pgd_get_s0",
-    "desc_pgd_sizes", "desc_pgd_kernel_name", "desc_pgd_solve", "desc_selftest_group_sum",
+    "desc_pgd_sizes", "desc_pgd_layout_stats", "desc_pgd_kernel_name", "desc_pgd_solve", "desc_selftest_group_sum",
     "desc_pgd_create_shard", "desc_pgd_shard_info", "desc_pgd_shard_bind", "desc_pgd_shard_colsum", "desc_pgd_shard_sweep",
     "desc_pgd_shard_finish", "desc_pgd_shard_objective", "desc_pgd_shard_set_collectives", "desc_pgd_shard_start",
-    "desc_pgd_shard_iterate", "desc_pgd_shard_run", "desc_pgd_stopped", "desc_device_synchronize", "desc_memcpy_d2h", "desc_memcpy_h2d", "desc_debug_band_plan", "desc_debug_spmm_variants", "desc_debug_wg_clock", "desc_debug_wg_plan", "desc_trim_memory", "desc_spectral_run", "desc_cemp_run", "desc_refine_run",
+    "desc_pgd_shard_iterate", "desc_pgd_shard_run", "desc_pgd_stopped", "desc_device_synchronize", "desc_memcpy_d2h", "desc_memcpy_h2d", "desc_debug_band_plan", "desc_debug_spmm_variants", "desc_debug_wg_clock", "desc_debug_wg_plan", "desc_debug_last_sweep", "desc_debug_shard_layout", "desc_trim_memory", "desc_spectral_run", "desc_cemp_run", "desc_refine_run",
 ]
 
 I32P = C.POINTER(C.c_int32)
@@ -173,6 +173,10 @@ def load():
     L.desc_debug_spmm_variants.argtypes = [C.c_void_p, C.c_int32, F64P]
     L.desc_debug_wg_clock.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32]
     L.desc_debug_wg_plan.argtypes = [C.c_void_p, I64P, C.c_int32]
+    L.desc_pgd_layout_stats.argtypes = [C.c_void_p, I64P, C.c_int32]
+    L.desc_debug_last_sweep.restype = C.c_char_p
+    L.desc_debug_last_sweep.argtypes = [C.c_void_p]
+    L.desc_debug_shard_layout.argtypes = [C.c_void_p, I32P, I32P, I32P, I32P]
     L.desc_trim_memory.restype = C.c_int64
     L.desc_trim_memory.argtypes = []
     L.desc_device_synchronize.argtypes = [C.c_int32]
@@ -362,6 +366,26 @@ class Solver:
 
     def kernel_name(self):
         return load().desc_pgd_kernel_name(self.handle).decode()
+
+    def layout_stats(self):
+        out = np.zeros(6, dtype=np.int64)
+        k = load().desc_pgd_layout_stats(self.handle, ptr(out, I64P), 6)
+        if k < 0:
+            check(k)
+        return dict(zip(("colsum_entries", "pieces", "bands", "piece_row_entries", "cycles", "segments"), (int(x) for x in out[:k])))
+
+    def last_sweep(self):
+        """Name + template arguments of the sweep kernel launched last (diagnostics)."""
+        return load().desc_debug_last_sweep(self.handle).decode()
+
+    def shard_layout(self):
+        """The exchange layout (diagnostics): xpos, spos (2m each), xt and slot_ab ((owned segments, 2) each)."""
+        info = self.shard_info()
+        nsl = int(info.seg_hi - info.seg_lo)
+        xpos, spos = out_buffer(2 * self.m, np.int32), out_buffer(2 * self.m, np.int32)
+        xt, sab = out_buffer(2 * nsl, np.int32), out_buffer(2 * nsl, np.int32)
+        check(load().desc_debug_shard_layout(self.handle, ptr(xpos, I32P), ptr(spos, I32P), ptr(xt, I32P), ptr(sab, I32P)))
+        return dict(xpos=xpos[:2 * self.m], spos=spos[:2 * self.m], xt=xt[:2 * nsl].reshape(-1, 2), slot_ab=sab[:2 * nsl].reshape(-1, 2))
 
     def s0(self):
         out = out_buffer(self.m_cycle)

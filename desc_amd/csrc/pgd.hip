@@ -404,6 +404,10 @@ struct NodeSweepArgs {
     int32_t nchunks;
     int32_t max_cnt;
     int32_t ablate;
+    uint32_t csr_bytes;        // bytes of the CSR-aligned arrays (S_old, S_new, Tfull of a one-rank run: 2m doubles) -- num_records of their buffer descriptors
+    uint32_t t_bytes;          // bytes of Tfull (sharded runs: this rank's part of the reduce-scattered sums)
+    uint32_t slice_bytes;      // bytes of s_slice (sharded runs)
+    uint32_t seg_count;        // segments in cum / einfo / xt (device order, all ranks): cum has seg_count + 1 entries
 };
 
 struct StreamRegs { uint4 pk; double2 w, d; };   // one 16-byte vector of each streamed array
@@ -814,9 +818,10 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
         obj_acc = 0.0; chg_acc = 0.0;
     };
 #if DESC_BUF
-    const __amdgpu_buffer_rsrc_t rs_S = make_rsrc(a.S_old), rs_T = make_rsrc(a.Tfull), rs_Sn = make_rsrc(a.S_new);      // CSR-aligned: 2m doubles < 4 GiB
-    const __amdgpu_buffer_rsrc_t rs_sl = XT ? make_rsrc(a.s_slice) : rs_Sn;                        // sharded runs: this rank's all-gather slice
-    const __amdgpu_buffer_rsrc_t rs_cum = make_rsrc(a.cum), rs_ei = make_rsrc(a.einfo);          // per-lane records (VREC shapes only; C3 -1 %)
+    // num_records = the arrays' real lengths: an offset past the end reads 0 / stores nothing instead of touching a neighbouring block
+    const __amdgpu_buffer_rsrc_t rs_S = make_rsrc(a.S_old, a.csr_bytes), rs_T = make_rsrc(a.Tfull, a.t_bytes), rs_Sn = make_rsrc(a.S_new, a.csr_bytes);      // CSR-aligned: 2m doubles < 4 GiB
+    const __amdgpu_buffer_rsrc_t rs_sl = XT ? make_rsrc(a.s_slice, a.slice_bytes) : rs_Sn;                        // sharded runs: this rank's all-gather slice
+    const __amdgpu_buffer_rsrc_t rs_cum = make_rsrc(a.cum, (a.seg_count + 1u) * 4u), rs_ei = make_rsrc(a.einfo, a.seg_count * 16u);          // per-lane records (VREC shapes only; C3 -1 %)
 #endif
     int pc = p0, ticket = -1;
     for (;;) {
@@ -1726,6 +1731,8 @@ struct desc_pgd {
     int grid = 0;               // sweep grid (multiple of 8)
     int obj_grid = 0;
     int colsum_grid = 0, colsum_stride = 0, colsum_cl = 16;     // colsum_cl: lanes per segment in k_colsum_node (8 when the runs are short)
+    int64_t colsum_entries = 0;                                  // (cycle, endpoint) pairs the column sums read: cycles whose mirror was sampled, per endpoint
+    int64_t n_pieces = 0, n_bands = 0, piece_row_entries = 0;    // band sweep plan: pieces, bands, CSR entries of band rows loaded per sweep
     int band = 0;
     bool band_ok = false;       // k_sweep_band applies (segments <= 64 cycles, rows fit the LDS)
     int band_grid = 0, band_rows = 0;
@@ -1791,6 +1798,7 @@ struct desc_pgd {
     double ms_upload = 0, ms_cycle_d = 0, ms_pgd = 0;
     int ablate = 0;             // diagnostics (DESC_DEBUG_ABLATE)
     std::string kname;
+    std::string last_sweep;     // the sweep instance launched last, with its template arguments (desc_debug_last_sweep: tests assert which kernel ran)
     // GRAPH_ITERS iterations (column sums + sweep each) captured once per reset as a hipGraph and replayed: the launches of a
     // replay carry no iteration number (DevState.next_fin), so one executable graph serves the whole run.  Constant step only.
     hipGraphExec_t graph_exec = nullptr;
@@ -1896,6 +1904,7 @@ StepArgs make_step(desc_pgd* h, bool* adam, int rd, int wr) {
 template <int STEP>
 void launch_gather(desc_pgd* h, const SweepArgs& a) {
     dim3 grid(h->grid), block(256);
+    { char nm[64]; if (h->G) snprintf(nm, sizeof nm, "k_sweep<%d,%d>", h->G, STEP); else snprintf(nm, sizeof nm, "k_sweep_big<%d>", STEP); h->last_sweep = nm; }
     switch (h->G) {
         case 16: hipLaunchKernelGGL((k_sweep<16, STEP>), grid, block, 0, h->stream, a); break;
         case 32: hipLaunchKernelGGL((k_sweep<32, STEP>), grid, block, 0, h->stream, a); break;
@@ -1906,6 +1915,11 @@ void launch_gather(desc_pgd* h, const SweepArgs& a) {
 template <int STEP>
 void launch_node(desc_pgd* h, const NodeSweepArgs& a) {
     dim3 grid(h->grid), block(SWEEP_THREADS);
+    {
+        int L = h->lps, E = h->G;
+        if (!((L == 16 && (E == 1 || E == 2)) || (L == 32 && (E == 2 || E == 4)))) { L = 64; E = 4; }      // the switch's default
+        char nm[64]; snprintf(nm, sizeof nm, "k_sweep_node<%d,%d,%d>%s", L, E, STEP, a.xt ? " sharded" : ""); h->last_sweep = nm;
+    }
     switch (h->lps * 8 + h->G) {              // lps lanes per segment, G = cycles per lane (E)
         case 16 * 8 + 1: hipLaunchKernelGGL((k_sweep_node<16, 1, STEP>), grid, block, 0, h->stream, a); break;
         case 16 * 8 + 2: hipLaunchKernelGGL((k_sweep_node<16, 2, STEP>), grid, block, 0, h->stream, a); break;
@@ -1954,6 +1968,7 @@ const void* band_kernel(const desc_pgd* h) {
 }
 template <int LPS, int E, int STEP, int NT>
 void launch_band_shape(desc_pgd* h, const BandSweepArgs& b) {
+    { char nm[64]; snprintf(nm, sizeof nm, "k_sweep_band<%d,%d,%d,%d,%s>", LPS, E, STEP, NT, b.n.xt ? "XT" : "one-rank"); h->last_sweep = nm; }
     if (b.n.xt) hipLaunchKernelGGL((k_sweep_band<LPS, E, STEP, NT, true>), dim3(h->band_grid), dim3(NT), h->band_lds, h->stream, b);
     else hipLaunchKernelGGL((k_sweep_band<LPS, E, STEP, NT, false>), dim3(h->band_grid), dim3(NT), h->band_lds, h->stream, b);
 }
@@ -2025,6 +2040,7 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
         a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
         a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->d_T; a.xt = nullptr; a.nv_tab = h->d_nv; a.partials = h->d_partials;
         a.state = h->d_state; a.st = st; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks; a.max_cnt = h->max_cnt; a.ablate = h->ablate;
+        a.csr_bytes = (uint32_t)(16 * h->m); a.t_bytes = a.csr_bytes; a.slice_bytes = 0; a.seg_count = (uint32_t)h->m_pos;
         launch_sweep_node_layout(h, a, adam);
     } else {
         SweepArgs a{};
@@ -2510,6 +2526,13 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
     if (pieces.empty()) pieces.push_back(PieceDesc{0, 0, 0, 0});
 }
 
+// LDS budget of a band's rows.  DESC_DEBUG_ROW_CAP (tests only) shrinks it -- never below the longest row -- so that a small graph is cut into
+// many bands: piece boundaries, the ranks' whole-band ranges and the exchange layout of world = 8 are then exercised at oracle sizes.
+int band_row_cap(int max_deg) {
+    const int v = env_int("DESC_DEBUG_ROW_CAP", 0);
+    return v > 0 ? std::min(BAND_ROW_CAP, std::max(v, std::max(max_deg, 2))) : BAND_ROW_CAP;
+}
+
 int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, const double* shared_rij) {
     const int64_t n = h->n, m = h->m, mp = h->m_pos;
     auto t0 = std::chrono::steady_clock::now();
@@ -2534,7 +2557,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     const int force_band = env_int("DESC_DEBUG_VARIANT", 0);
     h->band_ok = force_band != VARIANT_NODE && h->max_cnt <= MAX_SEG_CYCLES && h->max_deg <= BAND_ROW_CAP && (h->m_cycle >= (2 << 20) || force_band == 3) &&
                  (int64_t)2 * m * 8 < (1ll << 32);          // 32-bit byte offsets into the CSR-aligned arrays (buffer instructions): m < 2.7e8 edges
-    if ((rc = make_node_plan(prob, s, h->max_deg, h->world, h->max_cnt <= 32 ? 32 : h->max_cnt <= 128 ? 16 : 8, h->band_ok ? BAND_ROW_CAP : 0, P))) return rc;   // 8 waves x 64/lps segments
+    if ((rc = make_node_plan(prob, s, h->max_deg, h->world, h->max_cnt <= 32 ? 32 : h->max_cnt <= 128 ? 16 : 8, h->band_ok ? band_row_cap(h->max_deg) : 0, P))) return rc;   // 8 waves x 64/lps segments
     h->band = P.band;
     lap("plan");
     const hvec<int32_t>& cum2 = P.cum2;
@@ -2565,6 +2588,8 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         bool jmajor = false;
         plan_band_pieces(prob, s, P, h->seg_lo, h->seg_hi, h->cyc_lo, mcl, h->band_grid, pieces, piece_ptr, h->band_rows, jmajor, &h->band_tail_first, &h->band_ntail);
         h->band_jmajor = jmajor;
+        h->n_pieces = (int64_t)pieces.size(); h->n_bands = (int64_t)P.band_lo.size() - 1;
+        for (const PieceDesc& pd : pieces) h->piece_row_entries += pd.row_len;
         if (timing) fprintf(stderr, "[desc_amd] band sweep: %zu bands, %zu pieces over %d workgroups, %s, rows <= %d\n", P.band_lo.size() - 1, pieces.size(),
                             h->band_grid, jmajor ? "j-block-major units" : "contiguous ranges", h->band_rows);
     }
@@ -2668,9 +2693,9 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     if ((rc = dalloc_stream(h, &h->d_adj_seg, 2 * m, 16))) return rc;
     if ((rc = dalloc(h, &h->d_src_start, mp))) return rc;
     if ((rc = dalloc(h, &h->d_eslot, m))) return rc;
-    if ((rc = dalloc_stream(h, &h->d_S[0], 2 * m, 32))) return rc;      // bits 32 / 64: experiments (profiles/r03_experiments.txt), never default
-    if ((rc = dalloc_stream(h, &h->d_S[1], 2 * m, 32))) return rc;
-    if ((rc = dalloc_stream(h, &h->d_T, 2 * m, 64))) return rc;
+    if ((rc = dalloc_stream(h, &h->d_S[0], 2 * m + 2, 32))) return rc;      // bits 32 / 64: experiments (profiles/r03_experiments.txt), never default; + 2: a 16-byte row load may end one double past 2m
+    if ((rc = dalloc_stream(h, &h->d_S[1], 2 * m + 2, 32))) return rc;
+    if ((rc = dalloc_stream(h, &h->d_T, 2 * m + 2, 64))) return rc;
     if ((rc = dalloc(h, &h->d_Svec, m))) return rc;
     if ((rc = dalloc(h, &h->d_chunk_desc, chunk_desc.size()))) return rc;
     if ((rc = dalloc(h, &h->d_rank_seg, (size_t)h->world + 1))) return rc;
@@ -2851,6 +2876,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         uint64_t tot = 0;
         for (int64_t v = 0; v < n; ++v) { rb[v] = (uint32_t)tot; tot += rs[v]; }
         if (tot >= (1ull << 32)) return fail(DESC_ERR_TOO_LARGE, "column-index stream exceeds 2^32 entries");
+        h->colsum_entries = (int64_t)tot;
         if ((rc = dalloc_stream(h, &h->d_midx, (size_t)tot + 8, 8))) return rc;
         {   // average run length (contributing cycles per segment and endpoint) decides the lanes per segment of the column sums
             const double avg_run = nsl > 0 ? (double)tot / (2.0 * (double)nsl) : 0.0;
@@ -3358,7 +3384,8 @@ int shard_enqueue_sweep(desc_pgd* h, hipStream_t st) {
     a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
     a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_Trecv; a.xt = h->d_xt; a.nv_tab = h->d_nv;
     a.s_slice = my_slice(h); a.partials = my_slice(h) + h->slice_S;       // S and the workgroup partials go straight into the slice
-    if (shard_direct(h)) { a.Tfull = h->d_T; a.xt = nullptr; a.s_slice = nullptr; }
+    a.csr_bytes = (uint32_t)(16 * h->m); a.t_bytes = (uint32_t)(8 * h->t_part); a.slice_bytes = (uint32_t)(8 * h->slice_S); a.seg_count = (uint32_t)h->m_pos;
+    if (shard_direct(h)) { a.Tfull = h->d_T; a.xt = nullptr; a.s_slice = nullptr; a.t_bytes = a.csr_bytes; }
     a.state = h->d_state; a.st = sa; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks;
     a.max_cnt = h->max_cnt; a.ablate = 0;
     const hipStream_t keep = h->stream; h->stream = st;
@@ -3568,6 +3595,44 @@ int desc_debug_wg_plan(desc_pgd* h, int64_t* out, int32_t cap) {
     });
 }
 
+// What the layout of this handle moves per iteration (bench.py: the floor of its own traffic, next to the 72-byte algorithmic count):
+// out[0] = (cycle, endpoint) pairs read by the column sums, out[1] = pieces of the band sweep, out[2] = bands, out[3] = CSR entries of band
+// rows loaded into the LDS per sweep, out[4] = local cycles, out[5] = local segments.  Returns the number of values written.
+int desc_pgd_layout_stats(const desc_pgd* h, int64_t* out, int32_t cap) {
+    if (!h || !out) return fail(DESC_ERR_INVALID, "NULL argument");
+    const int64_t v[6] = {h->colsum_entries, h->n_pieces, h->n_bands, h->piece_row_entries, local_cycles(h), h->variant == VARIANT_NODE ? h->seg_hi - h->seg_lo : h->m_pos};
+    int k = 0;
+    for (; k < 6 && k < cap; ++k) out[k] = v[k];
+    return k;
+}
+
+// Diagnostics (tests): name and template arguments of the sweep kernel this handle launched last ("" before the first sweep).
+const char* desc_debug_last_sweep(const desc_pgd* h) { return h ? h->last_sweep.c_str() : ""; }
+
+// Diagnostics (tests/test_gpu_sharded.py): the exchange layout of a sharded handle.  xpos, spos: 2m entries each (CSR slot -> place of its
+// column sum in the reduce-scatter send buffer / place of its edge's S in the gathered slices); xt: 2 * (seg_hi - seg_lo) entries, {ta, tb}
+// of the owned segments in device order; slot_ab: the same count, {slot_a, slot_b} = the CSR slots of those segments' edges.
+int desc_debug_shard_layout(desc_pgd* h, int32_t* xpos, int32_t* spos, int32_t* xt, int32_t* slot_ab) {
+    return no_throw("desc_debug_shard_layout", [&]() -> int {
+    if (!h || !xpos || !spos || !xt || !slot_ab) return fail(DESC_ERR_INVALID, "NULL argument");
+    if (h->variant != VARIANT_NODE) return fail(DESC_ERR_STATE, "sharding needs the node layout");
+    int rc = set_device(h); if (rc) return rc;
+    DESC_HIP(hipStreamSynchronize(h->stream));
+    if (h->m > 0) {
+        DESC_HIP(hipMemcpy(xpos, h->d_xpos, sizeof(int32_t) * 2 * (size_t)h->m, hipMemcpyDeviceToHost));
+        DESC_HIP(hipMemcpy(spos, h->d_spos, sizeof(int32_t) * 2 * (size_t)h->m, hipMemcpyDeviceToHost));
+    }
+    const int64_t nsl = h->seg_hi - h->seg_lo;
+    if (nsl > 0) {
+        DESC_HIP(hipMemcpy(xt, h->d_xt + h->seg_lo, sizeof(int2) * (size_t)nsl, hipMemcpyDeviceToHost));
+        hvec<EdgeInfo> ei((size_t)nsl);
+        DESC_HIP(hipMemcpy(ei.data(), h->d_einfo + h->seg_lo, sizeof(EdgeInfo) * (size_t)nsl, hipMemcpyDeviceToHost));
+        for (int64_t q = 0; q < nsl; ++q) { slot_ab[2 * q] = ei[q].slot_a; slot_ab[2 * q + 1] = ei[q].slot_b; }
+    }
+    return DESC_OK;
+    });
+}
+
 int desc_pgd_stopped(desc_pgd* h, int32_t* stopped) {
     if (!h || !stopped) return fail(DESC_ERR_INVALID, "NULL argument");
     int rc = set_device(h); if (rc) return rc;
@@ -3609,7 +3674,7 @@ int desc_debug_band_plan(const desc_problem* prob, const desc_structure* s, int3
     }
     if (max_deg > BAND_ROW_CAP) return fail(DESC_ERR_TOO_LARGE, "a row exceeds the LDS budget");
     NodePlan P;
-    int rc = make_node_plan(prob, s, max_deg, world, s->max_cnt <= 32 ? 32 : s->max_cnt <= 128 ? 16 : 8, BAND_ROW_CAP, P);
+    int rc = make_node_plan(prob, s, max_deg, world, s->max_cnt <= 32 ? 32 : s->max_cnt <= 128 ? 16 : 8, band_row_cap(max_deg), P);
     if (rc) return rc;
     const int64_t seg_lo = P.chunk_seg[P.rank_chunk[rank]], seg_hi = P.chunk_seg[P.rank_chunk[rank + 1]];
     const int64_t cyc_lo = P.cum2[seg_lo], mcl = P.cum2[seg_hi] - cyc_lo;

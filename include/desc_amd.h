@@ -201,6 +201,10 @@ int desc_pgd_sync(desc_pgd* h);
 int desc_pgd_download(desc_pgd* h, desc_result* r);              /* finishes objective trace */
 int desc_pgd_get_s0(desc_pgd* h, double* s0 /* m_cycle */);       /* S0_long                  */
 int desc_pgd_sizes(const desc_pgd* h, int64_t* m, int64_t* m_pos, int64_t* m_cycle, int32_t* max_cnt);
+/* what this handle's layout streams per iteration (bench.py's `floor_bytes`): out[0] = (cycle, endpoint) pairs the mirror-sum pass reads
+ * (DESC_PGD.m:185-191: cycles whose mirror was sampled), out[1] = pieces of the band sweep, out[2] = bands, out[3] = CSR entries of band rows
+ * staged in the LDS per sweep, out[4] / out[5] = cycles / segments this rank owns.  Returns how many values were written (<= cap). */
+int desc_pgd_layout_stats(const desc_pgd* h, int64_t* out, int32_t cap);
 /* name of the main-sweep kernel variant chosen for this handle (rocprof cross-reference) */
 const char* desc_pgd_kernel_name(const desc_pgd* h);
 
@@ -352,6 +356,14 @@ int desc_debug_band_plan(const desc_problem* prob, const desc_structure* s, int3
 int desc_debug_wg_clock(desc_pgd* h, uint64_t* out, int32_t cap);
 /* ... and what the piece scheduler gave each of them: out[4 * w + {0,1,2,3}] = cycles, segments, pieces, CSR entries of the band rows loaded. */
 int desc_debug_wg_plan(desc_pgd* h, int64_t* out, int32_t cap);
+
+/* Test hooks (tests/test_gpu_sharded.py).  desc_debug_last_sweep: name and template arguments of the sweep kernel the handle launched last
+ * ("k_sweep_band<16,4,0,512,XT>": the sharded instance), "" before the first sweep.  desc_debug_shard_layout: the exchange layout of a
+ * (possibly sharded) handle -- xpos / spos: 2m entries each (CSR slot -> place of its mirror sum, DESC_PGD.m:189-190, in the reduce-scatter
+ * send buffer / place of its edge's S in the gathered slices); xt: {ta, tb} per owned segment (device order), slot_ab: the CSR slots of
+ * the same segments' edges; both 2 * (seg_hi - seg_lo) entries. */
+const char* desc_debug_last_sweep(const desc_pgd* h);
+int desc_debug_shard_layout(desc_pgd* h, int32_t* xpos, int32_t* spos, int32_t* xt, int32_t* slot_ab);
 
 /* Measurement hook (tools/next_rows_bench.py; SURVEY.md 8d "document the MFMA measurement rather than assume"): the 3x3-block SpMM of the
  * connection matrix (Spectral.m:27-37) with unit weights, `reps` products in its vector-FMA form and in a v_mfma_f64_4x4x4 form on the

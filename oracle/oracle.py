@@ -48,15 +48,38 @@ def lib():
         # 256 spinning threads is pathologically slow there
         os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         _LIB = C.CDLL(so)
-        try:
-            avail = len(os.sched_getaffinity(0))
-        except AttributeError:
-            avail = os.cpu_count() or 1
-        _LIB.oracle_set_threads(int(os.environ.get("ORACLE_THREADS", min(16, avail))))
+        _LIB.oracle_set_threads(int(os.environ.get("ORACLE_THREADS", granted_cpus()["granted"])))
         _LIB.oracle_sample_key.restype = C.c_uint64
         _LIB.oracle_sample_key.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         _LIB.oracle_num_threads.restype = C.c_int
     return _LIB
+
+
+def granted_cpus():
+    """CPUs this process may actually use: the affinity mask, cut down by the cgroup's CPU quota where one is set (a GPU box shows all
+    256 host threads in the mask and grants a share of them through the quota).  The OpenMP team of the oracle is sized to `granted`."""
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count() or 1
+    quota = None
+    try:                                            # cgroup v2: "max 100000" or "<quota> <period>"
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:                                        # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    granted = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
+    return dict(granted=granted, affinity=affinity, cgroup_quota=quota, host_cpus=os.cpu_count())
 
 
 def _p(a, t):

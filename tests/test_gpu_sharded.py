@@ -64,6 +64,8 @@ def _emulate(lib, nn, ii, jj, rij, p, world, check_every=5, where=None, nmin=30)
     outs = [s.download() for s in shards]
     ctx.__exit__(None, None, None)
     segs = [(s.info.seg_lo, s.info.seg_hi, s.info.cyc_lo, s.info.cyc_hi) for s in shards]
+    for o, s in zip(outs, shards):
+        o["last_sweep"], o["kernel"] = s.solver.last_sweep(), s.solver.kernel_name()
     for s in shards: s.destroy()
     return outs, segs
 
@@ -214,3 +216,170 @@ def test_fused_protocol_two_processes_one_gpu(oracle):
         assert np.abs(S - ref["S_vec"]).max() <= TOL
         assert np.allclose(obj, ref["obj"], rtol=1e-12, atol=1e-9)
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+# ---------------------------------------------------------------- the kernels a multi-GPU run executes
+# A C4 shard runs k_sweep_band<...,XT=true> (exchange positions per segment, S into the all-gather slice), k_xpos / k_xt (the exchange
+# layout) and k_unpack_S.  Small graphs take k_sweep_node by default and have ONE band (every rank but the first would be empty): the
+# tests below force the band sweep (DESC_DEBUG_VARIANT=3) and shrink the LDS budget of a band (DESC_DEBUG_ROW_CAP) so that the graph is cut
+# into dozens of bands and world = 8 gives every rank work.  Coupling under test: DESC_PGD.m:185-193.
+BAND_CASES = dict(
+    const=dict(n=150, p=0.6, iters=30, kw=dict(lr=0.01), env={}),                                      # sampling regime, <16,4> / <16,2> shapes
+    jmajor_tail=dict(n=200, p=0.5, iters=25, kw=dict(lr=0.01), env=dict(DESC_DEBUG_JMAJOR="1", DESC_DEBUG_JBLOCK="24", DESC_DEBUG_TAIL="200")),
+    piecewise=dict(n=150, p=0.6, iters=25, kw=dict(lr=0.05, step_kind=1, decay_interval=4, t0=1), env={}),
+    adam=dict(n=120, p=0.6, iters=20, kw=dict(lr=0.01, step_kind=2), env={}),
+    early_stop=dict(n=60, p=0.5, iters=300, kw=dict(lr=1.0, patience=5, stop_tol=1e-3), env={}),
+    short_segments=dict(n=40, p=0.5, iters=30, kw=dict(lr=0.01), env={}),                              # <= 16 cycles: the 1024-thread instance
+)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("case", sorted(BAND_CASES))
+def test_sharded_band_sweep_emulated(lib, oracle, world, case, monkeypatch):
+    cfg = BAND_CASES[case]
+    monkeypatch.setenv("DESC_DEBUG_VARIANT", "3")
+    monkeypatch.setenv("DESC_DEBUG_ROW_CAP", str(max(64, int(cfg["n"] * cfg["n"] * cfg["p"] / 24))))     # ~24 bands
+    for k, v in cfg["env"].items():
+        monkeypatch.setenv(k, v)
+    mo, nn, ii, jj, rij = make_problem("uniform", n=cfg["n"], p=cfg["p"], q=0.2, sigma=0.1, seed=8)
+    st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=3, iters=cfg["iters"], **cfg["kw"])
+    outs, segs = _emulate(lib, nn, ii, jj, rij, c_params(cfg["iters"], seed=3, **cfg["kw"]), world, where=lib.BUILD_DEVICE)
+    assert segs[0][0] == 0 and segs[-1][1] == st["m_pos"] and segs[-1][3] == st["m_cycle"]
+    busy = sum(1 for a in segs if a[1] > a[0])
+    assert busy >= min(world, 3), segs                         # the small row cap gives (nearly) every rank a range of bands
+    tol = 1e-9 if case == "adam" else TOL
+    for out, sg in zip(outs, segs):
+        assert "band" in out["kernel"]
+        if sg[1] > sg[0]:
+            assert "k_sweep_band" in out["last_sweep"] and ",XT>" in out["last_sweep"], out["last_sweep"]
+        assert out["iters_run"] == ref["iters_run"]
+        assert np.abs(out["S_vec"] - ref["S_vec"]).max() <= tol
+        assert np.allclose(out["obj"], ref["obj"], rtol=1e-12, atol=1e-9)
+        assert np.allclose(out["avg"], ref["avg"], rtol=1e-9, atol=1e-14)
+    for out in outs[1:]:
+        assert np.array_equal(out["S_vec"], outs[0]["S_vec"]) and np.array_equal(out["obj"], outs[0]["obj"])
+
+
+def _csr(nn, ii, jj):
+    """CSR adjacency (neighbours ascending) with the edge id of every slot, as the library builds it."""
+    m = ii.shape[0]
+    src = np.concatenate([ii, jj]); dst = np.concatenate([jj, ii]); eid = np.concatenate([np.arange(m), np.arange(m)])
+    order = np.lexsort((dst, src))
+    rowptr = np.zeros(nn + 1, dtype=np.int64)
+    np.add.at(rowptr, src + 1, 1)
+    return np.cumsum(rowptr), dst[order], eid[order], src[order]
+
+
+@pytest.mark.parametrize("world,row_cap", [(2, 700), (3, 700), (8, 700), (8, 0)])
+def test_exchange_layout_invariants(lib, world, row_cap, monkeypatch):
+    """k_xpos / k_xt: xpos is a bijection of the 2m CSR slots into the owners' parts of the reduce-scatter buffer, {ta, tb} of a segment are
+    the xpos of its two slots, spos = (owner of the smaller endpoint, edge number inside the owner's range); the same on every rank.
+    row_cap = 0: the default LDS budget, one band -> every rank but the first owns an empty node range."""
+    monkeypatch.setenv("DESC_DEBUG_VARIANT", "3")
+    if row_cap:
+        monkeypatch.setenv("DESC_DEBUG_ROW_CAP", str(row_cap))
+    mo, nn, ii, jj, rij = make_problem("uniform", n=130, p=0.55, q=0.2, sigma=0.1, seed=12)
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    st = lib.Structure.build(prob, 30, 1, lib.BUILD_DEVICE, 0)
+    m = ii.shape[0]
+    rowptr, adj, adj_eid, row_of = _csr(nn, ii, jj)
+    layouts, infos = [], []
+    for r in range(world):
+        sv = lib.Solver(prob, st, 0, r, world)
+        layouts.append(sv.shard_layout()); infos.append(sv.shard_info())
+        sv.destroy()
+    st.free()
+    t_part, slice_len = infos[0].t_part, infos[0].slice_len
+    assert all(i.t_part == t_part and i.slice_len == slice_len for i in infos)
+    xpos, spos = layouts[0]["xpos"], layouts[0]["spos"]
+    for lay in layouts[1:]:                                   # the layout is global: identical on every rank
+        assert np.array_equal(lay["xpos"], xpos) and np.array_equal(lay["spos"], spos)
+    assert np.unique(xpos).size == 2 * m and xpos.min() >= 0 and xpos.max() < world * t_part          # injective
+    # the owner of a slot's column sum = the owner of the SMALLER endpoint of its edge; owners own contiguous edge ranges
+    owner = xpos // t_part
+    small = np.minimum(row_of, adj)
+    for r in range(world):
+        mine = small[owner == r]
+        others = small[owner != r]
+        if mine.size:
+            assert not np.any((others >= mine.min()) & (others <= mine.max())), r               # node ranges do not interleave
+    e_owner = np.zeros(m, dtype=np.int64); e_owner[adj_eid] = owner
+    assert np.all(np.diff(e_owner) >= 0)                      # edge list sorted by (i, j): ranks own consecutive ranges
+    e_lo = np.searchsorted(e_owner, np.arange(world))
+    assert np.array_equal(spos, e_owner[adj_eid] * slice_len + (adj_eid - e_lo[e_owner[adj_eid]]))
+    # T1 half: edge order; T2 half behind it
+    upper = adj > row_of
+    assert np.array_equal(xpos[upper], owner[upper] * t_part + (adj_eid[upper] - e_lo[owner[upper]]))
+    assert np.all(xpos[~upper] - owner[~upper] * t_part >= t_part // 2)
+    covered = 0
+    for r, (lay, info) in enumerate(zip(layouts, infos)):
+        nsl = int(info.seg_hi - info.seg_lo)
+        assert lay["xt"].shape == (nsl, 2)
+        if nsl == 0:
+            continue
+        sa, sb = lay["slot_ab"][:, 0], lay["slot_ab"][:, 1]
+        assert np.array_equal(lay["xt"][:, 0], xpos[sa] - r * t_part) and np.array_equal(lay["xt"][:, 1], xpos[sb] - r * t_part)
+        assert np.all(owner[sa] == r) and np.all(owner[sb] == r)
+        assert np.array_equal(spos[sa], r * slice_len + lay["xt"][:, 0]) and np.array_equal(spos[sa], spos[sb])
+        covered += nsl
+    assert covered == infos[0].m_pos
+    if not row_cap:
+        assert sum(1 for i in infos if i.seg_hi > i.seg_lo) == 1
+
+
+def _unsharded(lib, prob, st, p):
+    solver = lib.Solver(prob, st, 0)
+    out = solver.run(p)
+    out["kernel"], out["last_sweep"] = solver.kernel_name(), solver.last_sweep()
+    solver.destroy()
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_c2_full_size_equals_unsharded(lib, world):
+    """BASELINE configs[1] (n = 1000, 15.7 M cycles), device-built structure, default kernel choice: every emulated rank runs the XT instance
+    of the band sweep on its range of bands; S_vec / objective of every rank within 1e-12 of the one-GPU run and bitwise equal across ranks."""
+    import bench
+    mo, nn, ii, jj, rij = bench.generate("C2")
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    p = c_params(30, lr=0.01, seed=0)
+    st = lib.Structure.build(prob, 30, 0, lib.BUILD_DEVICE, 0)
+    one = _unsharded(lib, prob, st, p)
+    st.free()
+    assert "band" in one["kernel"] and "one-rank" in one["last_sweep"]
+    outs, segs = _emulate(lib, nn, ii, jj, rij, p, world, where=lib.BUILD_DEVICE)
+    assert all(b > a for a, b, _, _ in segs)                   # every rank owns bands
+    cyc = [d - c for _, _, c, d in segs]
+    assert max(cyc) <= 1.5 * (sum(cyc) / world), cyc           # whole-band cuts: 28 bands of unequal weight at C2 (C4 has 263: tools/shard_compute.py)
+    for out in outs:
+        assert "k_sweep_band" in out["last_sweep"] and ",XT>" in out["last_sweep"], out["last_sweep"]
+        assert out["iters_run"] == one["iters_run"] == 30
+        assert np.abs(out["S_vec"] - one["S_vec"]).max() <= 1e-12
+        assert np.allclose(out["obj"], one["obj"], rtol=1e-12, atol=0)
+        assert np.allclose(out["avg"], one["avg"], rtol=1e-9, atol=1e-15)
+    for out in outs[1:]:
+        assert np.array_equal(out["S_vec"], outs[0]["S_vec"]) and np.array_equal(out["obj"], outs[0]["obj"])
+
+
+def test_fused_protocol_forced_collectives_c2(lib, monkeypatch):
+    """The fused two-stream C protocol on the multi-rank code path (exchange layout, XT sweep, real RCCL calls on a one-rank communicator,
+    unpack) at C2 against the one-GPU run."""
+    import bench
+    from desc_amd.sharded import NativeShard, RcclComm
+    mo, nn, ii, jj, rij = bench.generate("C2")
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    p = c_params(30, lr=0.01, seed=0, check_every=8)
+    st = lib.Structure.build(prob, 30, 0, lib.BUILD_DEVICE, 0)
+    one = _unsharded(lib, prob, st, p)
+    monkeypatch.setenv("DESC_DEBUG_FORCE_COLLECTIVES", "1")
+    comm = RcclComm(0, 1, 0)
+    assert comm.ok and comm.count == 1
+    shard = NativeShard(prob, st, 0, 0, 1, comm)
+    st.free()
+    out = shard.run(p)
+    name = shard.solver.last_sweep()
+    shard.destroy(); comm.destroy()
+    assert "k_sweep_band" in name and ",XT>" in name, name
+    assert out["iters_run"] == 30
+    assert np.abs(out["S_vec"] - one["S_vec"]).max() <= 1e-12
+    assert np.allclose(out["obj"], one["obj"], rtol=1e-12, atol=0)
