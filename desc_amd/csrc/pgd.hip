@@ -819,8 +819,12 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
     };
 #if DESC_BUF
     // num_records = the arrays' real lengths: an offset past the end reads 0 / stores nothing instead of touching a neighbouring block
-    const __amdgpu_buffer_rsrc_t rs_S = make_rsrc(a.S_old, a.csr_bytes), rs_T = make_rsrc(a.Tfull, a.t_bytes), rs_Sn = make_rsrc(a.S_new, a.csr_bytes);      // CSR-aligned: 2m doubles < 4 GiB
-    const __amdgpu_buffer_rsrc_t rs_sl = XT ? make_rsrc(a.s_slice, a.slice_bytes) : rs_Sn;                        // sharded runs: this rank's all-gather slice
+#ifndef DESC_RSRC_UNBOUNDED          // A/B builds only: 1 = the round-3 descriptors (num_records 0xFFFFFFFF)
+#define DESC_RSRC_UNBOUNDED 0
+#endif
+    const uint32_t nb_csr = DESC_RSRC_UNBOUNDED ? 0xFFFFFFFFu : a.csr_bytes, nb_t = DESC_RSRC_UNBOUNDED ? 0xFFFFFFFFu : a.t_bytes, nb_sl = DESC_RSRC_UNBOUNDED ? 0xFFFFFFFFu : a.slice_bytes;
+    const __amdgpu_buffer_rsrc_t rs_S = make_rsrc(a.S_old, nb_csr), rs_T = make_rsrc(a.Tfull, nb_t), rs_Sn = make_rsrc(a.S_new, nb_csr);      // CSR-aligned: 2m doubles < 4 GiB
+    const __amdgpu_buffer_rsrc_t rs_sl = XT ? make_rsrc(a.s_slice, nb_sl) : rs_Sn;                        // sharded runs: this rank's all-gather slice
     const __amdgpu_buffer_rsrc_t rs_cum = make_rsrc(a.cum, (a.seg_count + 1u) * 4u), rs_ei = make_rsrc(a.einfo, a.seg_count * 16u);          // per-lane records (VREC shapes only; C3 -1 %)
 #endif
     int pc = p0, ticket = -1;
@@ -1242,92 +1246,127 @@ constexpr int COLSUM_U = 8;
 // kernel consumes them (node-major, then incident segment, then contributing cycle; `moff` = start of a CSR slot's run), read
 // sequentially -- instead of the 4-byte packed words of the cycles, which sit in scattered 50-byte runs next to the weights
 // (round 2: -25 % of this pass's sectors).
+// Walks the segments [0, nrun) of one node's run (records in LDS: sb = first contributing cycle, sc = their number, sm = start in midx)
+// in groups of SPI = 64 / CL consecutive segments, first group g_first, then every g_step-th, adding each contributing cycle's weight to
+// column midx[..] of `cols`.  COLSUM_U groups are in flight per wave.
+//
+// The columns are 64-bit FIXED-POINT sums (round 4): a weight lies in [0, 1], a column adds at most one cycle of every incident segment, so
+// round(w * 2^fx_bits) with fx_bits = 62 - ceil(log2(max degree + 1)) never overflows and costs <= 2^-(fx_bits+1) per term (2.2e-16 at C4,
+// below the rounding of a double sum of the same terms).  Integer adds commute: the sum does not depend on the order in which lanes, waves or
+// the LDS unit apply them, so the pass is bitwise reproducible BY CONSTRUCTION, and ONE copy of the columns per workgroup serves all four
+// waves (a quarter of the accumulator LDS: 3 -> 7 workgroups per CU at C4).  History: rounds 1-3 kept per-wave copies of doubles and relied on
+// the LDS unit resolving same-address lanes of one ds_add_f64 in a fixed order (observed, not specified); the order-explicit form of that
+// (one segment of an instruction after the other) measured +10 % on this kernel (profiles/r04_ab_colsum_ordered_and_descriptors.txt: C4 230 ->
+// 253 us, C2 27.0 -> 29.5); the fixed-point form had measured -5 % in round 3 (profiles/r03_colsum_bound.txt) and was shelved then.
+template <int CL>
+__device__ __forceinline__ void colsum_walk(unsigned long long* cols, const int* sb, const int* sc, const uint32_t* sm, int nrun, int g_first, int g_step,
+                                            const uint16_t* midx, const double* w, int lane, double fx_scale) {
+    // Inside a segment the cycles are ordered [(ik;j) only | both mirrors | (jk;i) only |
+    // none], so either endpoint reads one run: only the `nact` cycles that contribute to its
+    // columns (~n_sample/codeg of them; the smaller endpoint the first two classes, the larger
+    // the middle two).  A wave instruction serves 4 segments x 16 lanes; segments
+    // with more than 16 contributing cycles take further passes.  Every load of a batch is
+    // issued before any result is touched (a use between loads would make the compiler wait
+    // for each one).
+    // CL lanes per segment, i.e. 2 CL slots per segment and round.  16 is right when a segment has 12-25 contributing cycles per endpoint
+    // (C2, C3, C4); with ~9 (C5: 30 sampled cycles, 30 % of them with a sampled mirror) half of a 16-lane group's loads and adds are
+    // idle: 8 lanes and 8 segments per instruction there -- C5 389.5 -> 370 us; at C4 / C3 / C2 the narrower groups cost +2.6 / +2.7 / +15 %
+    // (second rounds), so the host picks by the average run length (setup_node).
+    constexpr int SPI = 64 / CL;          // segments per wave instruction
+    const int sub = lane / CL, l16 = lane % CL;
+    for (int g0 = g_first; SPI * g0 < nrun; g0 += g_step * COLSUM_U) {
+        // pieces 0 and 1 (contributing cycles 0..31 of each segment) are loaded together;
+        // segments with more take further rounds
+        for (int round = 0; round < MAX_SEG_CYCLES / (2 * CL); ++round) {
+            uint32_t pv[2 * COLSUM_U]; double wvv[2 * COLSUM_U];
+            bool more = false;
+#pragma unroll
+            for (int u = 0; u < COLSUM_U; ++u) {
+                const int tt = SPI * (g0 + g_step * u) + sub;
+                pv[2 * u] = 0xFFFFu; pv[2 * u + 1] = 0xFFFFu; wvv[2 * u] = 0.0; wvv[2 * u + 1] = 0.0;
+                if (tt < nrun) {
+                    const int nact = sc[tt] & 0x1FF;
+                    more |= nact > 2 * CL * (round + 1);
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int q = l16 + CL * (2 * round + h2);
+                        if (q < nact) {
+                            const int64_t c = (int64_t)sb[tt] + q;          // (as buffer loads, like the band sweep's: no change, 239.1 vs 239.0 us at C4)
+                            pv[2 * u + h2] = midx[(size_t)sm[tt] + q];
+                            wvv[2 * u + h2] = w[c];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2 * COLSUM_U; ++u)
+                if (pv[u] != 0xFFFFu) atomicAdd(&cols[pv[u]], (unsigned long long)__double2ll_rn(wvv[u] * fx_scale));      // ds_add_u64
+            if (!__any(more)) break;
+        }
+    }
+}
+
+constexpr int COLSUM_SHORT = 128;         // sharded runs: rows whose owned run has at most this many segments are summed by ONE wave (four nodes per workgroup)
+// LDS: `copies` x stride_cols 64-bit columns (1: the workgroup's shared copy; 4: one per wave, when the launch has short-run nodes), then 3 ints per incident edge
 template <int CL>
 __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, const int2* adj_seg, const uint32_t* moff, const uint16_t* midx, const double* w,
-                                                     double* Tfull, int n, int stride_cols, const DevState* st, const int32_t* xpos, FinArgs fin, int32_t* tail_ticket, const int32_t* node_order) {
+                                                     double* Tfull, int n, int stride_cols, const DevState* st, const int32_t* xpos, FinArgs fin, int32_t* tail_ticket, const int32_t* node_order,
+                                                     const int2* node_run, int n_long, int copies, double fx_scale, double fx_inv) {
     if (blockIdx.x == gridDim.x - 1) {
         if (threadIdx.x < 64 && fin.st) finalize_wave(fin);
         if (threadIdx.x == 0 && tail_ticket) *tail_ticket = 0;          // the sweep that follows hands out its tail pieces from 0
         return;
     }
     if (st->stop) return;
-    extern __shared__ double acc[];                   // [4][stride_cols] doubles, then 3 ints per incident edge
-    int* seg_base = (int*)(acc + 4 * stride_cols);
+    extern __shared__ unsigned long long acc[];
+    int* seg_base = (int*)(acc + copies * stride_cols);
     int* seg_cf = seg_base + stride_cols;             // slot_record: {first contributing cycle, their number (| flag)}
     uint32_t* seg_mo = (uint32_t*)(seg_cf + stride_cols);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int vi = blockIdx.x; vi < n; vi += gridDim.x - 1) {
-        const int v = node_order ? node_order[vi] : vi;       // the dispatcher hands workgroups out in index order: see setup_node for the order
+    // node_order lists the nodes to visit (the dispatcher hands workgroups out in index order: see setup_node for the order), first the
+    // n_long nodes that get a workgroup each, then the short-run nodes of a sharded run, four per workgroup
+    if ((int)blockIdx.x < n_long) {
+        const int vi = blockIdx.x;
+        const int v = node_order ? node_order[vi] : vi;
         const int r0 = rowptr[v], deg = rowptr[v + 1] - r0;
-        if (deg == 0) continue;
-        for (int t = threadIdx.x; t < 4 * stride_cols; t += 256) acc[t] = 0.0;
-        for (int t = threadIdx.x; t < deg; t += 256) {     // CSR-aligned segment records: one coalesced load
-            const int2 rec = adj_seg[r0 + t];
-            seg_base[t] = rec.x; seg_cf[t] = rec.y; seg_mo[t] = moff[r0 + t];
+        if (deg == 0) return;
+        // Sharded runs: the segments of row v this rank owns -- those whose smaller endpoint lies in its node range -- are ONE contiguous run
+        // [run.x, run.y) of the row's CSR slots (neighbours ascending); only that run is loaded and walked.  One rank: the whole row.
+        const int2 run = node_run ? node_run[v] : int2{0, deg};
+        const int ra = r0 + run.x, nrun = run.y - run.x;
+        for (int t = threadIdx.x; t < deg; t += 256) acc[t] = 0ull;
+        for (int t = threadIdx.x; t < nrun; t += 256) {    // CSR-aligned segment records: one coalesced load
+            const int2 rec = adj_seg[ra + t];
+            seg_base[t] = rec.x; seg_cf[t] = rec.y; seg_mo[t] = moff[ra + t];
         }
         __syncthreads();
-        double* mine = acc + wv * stride_cols;
-        // Inside a segment the cycles are ordered [(ik;j) only | both mirrors | (jk;i) only |
-        // none], so either endpoint reads one run: only the `nact` cycles that contribute to its
-        // columns (~n_sample/codeg of them; the smaller endpoint the first two classes, the larger
-        // the middle two).  A wave instruction serves 4 segments x 16 lanes; segments
-        // with more than 16 contributing cycles take further passes.  Every load of a batch is
-        // issued before any result is touched (a use between loads would make the compiler wait
-        // for each one).
-        // CL lanes per segment, i.e. 2 CL slots per segment and round.  16 is right when a segment has 12-25 contributing cycles per endpoint
-        // (C2, C3, C4); with ~9 (C5: 30 sampled cycles, 30 % of them with a sampled mirror) half of a 16-lane group's loads and adds are
-        // idle: 8 lanes and 8 segments per instruction there -- C5 389.5 -> 370 us; at C4 / C3 / C2 the narrower groups cost +2.6 / +2.7 / +15 %
-        // (second rounds), so the host picks by the average run length (setup_node).
-        constexpr int SPI = 64 / CL;          // segments per wave instruction
-        const int sub = lane / CL, l16 = lane % CL;
-        for (int g0 = wv; SPI * g0 < deg; g0 += 4 * COLSUM_U) {      // groups of SPI consecutive segments, dealt to waves round-robin
-            // pieces 0 and 1 (contributing cycles 0..31 of each segment) are loaded together;
-            // segments with more take further rounds
-            for (int round = 0; round < MAX_SEG_CYCLES / (2 * CL); ++round) {
-                uint32_t pv[2 * COLSUM_U]; double wvv[2 * COLSUM_U];
-                bool more = false;
-#pragma unroll
-                for (int u = 0; u < COLSUM_U; ++u) {
-                    const int tt = SPI * (g0 + 4 * u) + sub;
-                    pv[2 * u] = 0xFFFFu; pv[2 * u + 1] = 0xFFFFu; wvv[2 * u] = 0.0; wvv[2 * u + 1] = 0.0;
-                    if (tt < deg) {
-                        const int nact = seg_cf[tt] & 0x1FF;
-                        more |= nact > 2 * CL * (round + 1);
-#pragma unroll
-                        for (int h2 = 0; h2 < 2; ++h2) {
-                            const int q = l16 + CL * (2 * round + h2);
-                            if (q < nact) {
-                                const int64_t c = (int64_t)seg_base[tt] + q;          // (as buffer loads, like the band sweep's: no change, 239.1 vs 239.0 us at C4)
-                                pv[2 * u + h2] = midx[(size_t)seg_mo[tt] + q];
-                                wvv[2 * u + h2] = w[c];
-                            }
-                        }
-                    }
-                }
-#ifdef DESC_COLSUM_ORDERED
-                // Order-explicit form (build with -DDESC_COLSUM_ORDERED): the four segments of an instruction add one after the other.  Third
-                // vertices are distinct inside a segment, so a 16-lane group never hits one column twice; two groups of one instruction may, and
-                // the production form below then relies on the LDS unit resolving same-address lanes of one ds_add_f64 in a fixed order (observed:
-                // the full-size tests compare two runs bit for bit).  Measured cost of the explicit form: column sums +7 % at C4, +10 % at C2
-                // (profiles/r03_experiments.txt), i.e. ~1.2 % of an iteration: not the default.
-#pragma unroll
-                for (int u = 0; u < 2 * COLSUM_U; ++u)
-#pragma unroll
-                    for (int s4 = 0; s4 < SPI; ++s4)
-                        if (sub == s4 && pv[u] != 0xFFFFu) unsafeAtomicAdd(&mine[pv[u]], wvv[u]);
-#else
-#pragma unroll
-                for (int u = 0; u < 2 * COLSUM_U; ++u)
-                    if (pv[u] != 0xFFFFu) unsafeAtomicAdd(&mine[pv[u]], wvv[u]);          // ds_add_f64
-#endif
-                if (!__any(more)) break;
-            }
-        }
+        // groups of segments are dealt to the four waves round-robin; all add into the one shared copy
+        colsum_walk<CL>(acc, seg_base, seg_cf, seg_mo, nrun, wv, 4, midx, w, lane, fx_scale);
         __syncthreads();
         for (int t = threadIdx.x; t < deg; t += 256)
-            Tfull[xpos ? xpos[r0 + t] : r0 + t] = (acc[t] + acc[stride_cols + t]) + (acc[2 * stride_cols + t] + acc[3 * stride_cols + t]);   // xpos: owner-sorted exchange layout
-        __syncthreads();
+            Tfull[xpos ? xpos[r0 + t] : r0 + t] = (double)(long long)acc[t] * fx_inv;   // xpos: owner-sorted exchange layout
+        return;
     }
+    // Short runs (sharded ranks: most rows hold only a few dozen of a rank's segments -- at C4 over 8 GPUs rank 0 visits 4670 rows with ~66 of
+    // its segments each): one WAVE per node, its copy of the columns wave-private, no barrier; four nodes per workgroup.  Measured per rank
+    // before (a workgroup per node): 50-79 us by rank for ~29 us worth of entries (profiles/r04_shard_w8_c4_default.json).
+    const int vi = n_long + ((int)blockIdx.x - n_long) * 4 + wv;
+    if (vi >= n) return;
+    const int v = node_order[vi];
+    const int r0 = rowptr[v], deg = rowptr[v + 1] - r0;
+    const int2 run = node_run[v];
+    const int ra = r0 + run.x, nrun = min(run.y - run.x, COLSUM_SHORT);
+    unsigned long long* mine = acc + wv * stride_cols;
+    int* sb = seg_base + wv * COLSUM_SHORT; int* sc = seg_cf + wv * COLSUM_SHORT; uint32_t* sm = seg_mo + wv * COLSUM_SHORT;
+    for (int t = lane; t < deg; t += 64) mine[t] = 0ull;
+    for (int t = lane; t < nrun; t += 64) {
+        const int2 rec = adj_seg[ra + t];
+        sb[t] = rec.x; sc[t] = rec.y; sm[t] = moff[ra + t];
+    }
+    __builtin_amdgcn_wave_barrier();                  // one wave: its LDS operations execute in program order
+    colsum_walk<CL>(mine, sb, sc, sm, nrun, 0, 1, midx, w, lane, fx_scale);
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < deg; t += 64) Tfull[xpos ? xpos[r0 + t] : r0 + t] = (double)(long long)mine[t] * fx_inv;
 }
 
 // Setup of the node layout: packs idx_i(k) / idx_j(k) / mirror bits of every cycle and
@@ -1581,6 +1620,19 @@ __global__ __launch_bounds__(1024) void k_prefB(const int32_t* rowptr, const int
         __syncthreads();
     }
 }
+// Sharded column sums: the run of row v's CSR slots whose segments {v, u} belong to the rank that owns the nodes [lo, hi) -- those with
+// min(v, u) in [lo, hi): u >= lo when v itself is owned, lo <= u < hi when v >= hi, none when v < lo.  Neighbours are ascending: one run.
+__global__ __launch_bounds__(256) void k_node_runs(const int32_t* rowptr, const int32_t* adj, int lo, int hi, int2* runs, int n) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    const int r0 = rowptr[v], r1 = rowptr[v + 1];
+    int2 run{0, 0};
+    if (v >= lo) {
+        run.x = nbrs_below(adj, r0, r1, lo);
+        run.y = v < hi ? r1 - r0 : nbrs_below(adj, r0, r1, hi);
+    }
+    runs[v] = run;
+}
 __device__ __forceinline__ int owner_of_node(const int32_t* node_lo, int world, int v) { int r = 0; while (r + 1 < world && v >= node_lo[r + 1]) ++r; return r; }
 // xpos[t]: where the column sum of CSR slot t = (v, u) goes in the send buffer; spos[t]: where S of edge {v, u} sits in the gathered slices
 __global__ __launch_bounds__(256) void k_xpos(const int32_t* rowptr, const int32_t* adj, const int32_t* adj_eid, const int32_t* node_lo, const int32_t* e_lo,
@@ -1691,10 +1743,21 @@ __global__ __launch_bounds__(256) void k_unpack_S(const int32_t* spos, int64_t n
     // once the stop rule has fired the slices hold the discarded sweep: the double buffers must keep the final iterate
     if (fin.st->stop || !S_a) return;
     // every CSR slot from its place in the gathered slices: coalesced writes; reads contiguous for the larger-neighbour half of a row
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nslots; t += (int64_t)(gridDim.x - 1) * 256) {
-        const double v = sall[spos[t]];
-        S_a[t] = v;
-        if (S_b) S_b[t] = v;
+    // (four independent position -> value chains in flight per thread: one at a time the pass ran at 60 G slots/s, latency-bound --
+    //  83 us for the 5 M slots of C4, profiles/r04_shard_w8_c4_before.json)
+    const int64_t stride = (int64_t)(gridDim.x - 1) * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nslots; t += 4 * stride) {
+        int32_t q[4]; double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = spos[min(t + u * stride, nslots - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = sall[q[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (t + u * stride < nslots) {
+                S_a[t + u * stride] = v[u];
+                if (S_b) S_b[t + u * stride] = v[u];
+            }
     }
 }
 
@@ -1731,6 +1794,9 @@ struct desc_pgd {
     int grid = 0;               // sweep grid (multiple of 8)
     int obj_grid = 0;
     int colsum_grid = 0, colsum_stride = 0, colsum_cl = 16;     // colsum_cl: lanes per segment in k_colsum_node (8 when the runs are short)
+    int colsum_fx_bits = 47;                                     // fixed-point position of the column sums: 62 - ceil(log2(max degree + 1))
+    int colsum_nodes = 0;                                        // nodes k_colsum_node visits (sharded: those with segments of this rank in their row)
+    int colsum_long = 0;                                         // nodes that get a whole workgroup in k_colsum_node (the rest: a wave each, sharded runs)
     int64_t colsum_entries = 0;                                  // (cycle, endpoint) pairs the column sums read: cycles whose mirror was sampled, per endpoint
     int64_t n_pieces = 0, n_bands = 0, piece_row_entries = 0;    // band sweep plan: pieces, bands, CSR entries of band rows loaded per sweep
     int band = 0;
@@ -1742,7 +1808,8 @@ struct desc_pgd {
     unsigned long long* d_wg_clock = nullptr;   // diagnostics: DESC_DEBUG_WGCLOCK
     int band_tail_first = 0, band_ntail = 0;    // shared tail of the band sweep (BandSweepArgs)
     int32_t* d_ticket = nullptr;
-    int32_t* d_node_order = nullptr;            // column sums: the order the nodes are gone through (one workgroup each, dispatched in index order)
+    int32_t* d_node_order = nullptr;            // column sums: the nodes gone through (one workgroup each, dispatched in index order); sharded: only those with owned segments
+    int2* d_node_run = nullptr;                 // sharded runs: per node the run [x, y) of its row's CSR slots whose segments this rank owns (NULL: whole rows)
     hvec<void*> allocs;
     int uc_default = 0;         // which streamed arrays go to uncached memory (dalloc_stream)
     // common
@@ -1773,7 +1840,8 @@ struct desc_pgd {
     int64_t slice_S = 0;                // ... of which S values (the rest: SHARD_PARTS pairs of partials)
     desc_collectives coll{};            // fused protocol: the caller's collectives (RCCL entry points + communicator)
     hipStream_t comm_stream = nullptr;  // second stream: exchange + unpack overlap the next column-sum pass
-    hipEvent_t ev_col = nullptr, ev_rs = nullptr, ev_sw = nullptr, ev_done = nullptr;
+    hipEvent_t ev_col = nullptr, ev_rs = nullptr, ev_sw = nullptr, ev_ag = nullptr;
+    int unpack_pending = 0;             // fused protocol: sweep whose all-gathered S still has to be unpacked (on the compute stream, behind ev_ag)
     bool own_xbuf = false, force_coll = false;
     hvec<int64_t> rank_seg;      // world+1 segment boundaries
     double* x_T = nullptr;              // caller-bound exchange buffers (device): owner-sorted partial mirror sums (send)
@@ -1853,7 +1921,7 @@ void free_all(desc_pgd* h) {
     for (void* q : h->allocs) dev_free_idle(q);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
-    for (hipEvent_t e : {h->ev_col, h->ev_rs, h->ev_sw, h->ev_done}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {h->ev_col, h->ev_rs, h->ev_sw, h->ev_ag}) if (e) (void)hipEventDestroy(e);
     stream_release(h->comm_stream);
     if (!h->borrowed_stream) stream_release(h->stream);
     delete h;
@@ -2017,6 +2085,23 @@ void flush_finalize(desc_pgd* h) {
     h->pending_fin = 0;
 }
 
+// column copies in the LDS of k_colsum_node: one shared by the workgroup; four (one per wave) when the launch has short-run nodes, a wave each
+int colsum_copies(const desc_pgd* h) { return h->colsum_long < h->colsum_nodes ? 4 : 1; }
+size_t colsum_lds(const desc_pgd* h) { return (size_t)h->colsum_stride * (colsum_copies(h) * sizeof(unsigned long long) + 3 * sizeof(int)); }
+// the column-sum pass over the weights `w` -> T (through xpos: the exchange layout of a sharded run); `fin`: the bookkeeping that rides on it
+void launch_colsum(desc_pgd* h, hipStream_t st, const double* w, double* T, const int32_t* xpos, const FinArgs& fin) {
+    const dim3 grid(h->colsum_grid + 1), block(256);
+    const size_t lds = colsum_lds(h);
+    const int copies = colsum_copies(h);
+    const double fx_scale = std::ldexp(1.0, h->colsum_fx_bits), fx_inv = std::ldexp(1.0, -h->colsum_fx_bits);
+    if (h->colsum_cl == 8)
+        hipLaunchKernelGGL(k_colsum_node<8>, grid, block, lds, st, h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, w, T, h->colsum_nodes, h->colsum_stride, h->d_state,
+                           xpos, fin, h->d_ticket, h->d_node_order, h->d_node_run, h->colsum_long, copies, fx_scale, fx_inv);
+    else
+        hipLaunchKernelGGL(k_colsum_node<16>, grid, block, lds, st, h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, w, T, h->colsum_nodes, h->colsum_stride, h->d_state,
+                           xpos, fin, h->d_ticket, h->d_node_order, h->d_node_run, h->colsum_long, copies, fx_scale, fx_inv);
+}
+
 // enqueue sweep number t (1-based) and its finalize; ev0/ev1 bracket the kernels of the sweep proper
 int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool captured = false) {
     const int rd = (t - 1) & 1, wr = t & 1;
@@ -2027,14 +2112,7 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
         FinArgs fin = fin_args(h, h->d_partials, captured ? sweep_parts(h, adam) : h->pending_parts, h->pending_fin, 0);
         if (captured) { fin.t = 0; fin.dev_t = 1; }          // which sweep to book-keep: DevState.next_fin, at replay time
         else fin.t_after = t;                                // the next column-sum launch (direct or replayed) book-keeps sweep t
-        if (h->colsum_cl == 8)
-            hipLaunchKernelGGL(k_colsum_node<8>, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int)), h->stream,
-                               h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, h->d_w[rd], h->d_T, (int)h->n,
-                               h->colsum_stride, h->d_state, (const int32_t*)nullptr, fin, h->d_ticket, h->d_node_order);
-        else
-        hipLaunchKernelGGL(k_colsum_node<16>, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int)), h->stream,
-                           h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, h->d_w[rd], h->d_T, (int)h->n,
-                           h->colsum_stride, h->d_state, (const int32_t*)nullptr, fin, h->d_ticket, h->d_node_order);
+        launch_colsum(h, h->stream, h->d_w[rd], h->d_T, nullptr, fin);
         h->pending_fin = 0;
         NodeSweepArgs a{};
         a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
@@ -2346,7 +2424,13 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
                                           [](int64_t v, int32_t c) { return v < (int64_t)c; }) - cum2.begin()) - 1;
     };
     const int jmajor_env = env_int("DESC_DEBUG_JMAJOR", -1);
-    const bool jmajor = jmajor_env >= 0 ? jmajor_env != 0 : (int64_t)2 * m * 8 > (12ll << 20);      // C3 (6.4 MB): contiguous 0.167 ms, units 0.184
+    // (C3, 6.4 MB of S: contiguous 0.167 ms, units 0.184.  Round 4: a rank of a sharded run with < 150 K cycles per workgroup -- C4 over 8 GPUs:
+    //  61 K -- takes contiguous ranges too: a unit's row load and pipeline fill cost as much as its cycles there; measured one rank at a time,
+    //  profiles/r04_shard_w8_c4_{default,jmajor0}.json: 1033 -> 272 pieces per rank, sweep 196 -> 173 us)
+    //  C5 over 8 GPUs -- 73 K cycles per workgroup, but 80 MB of S and segments of 30 cycles -- is the other way round: units 250 us, contiguous 287 us
+    //  (profiles/r04_shard_w8_c5_v2*.json); the rule below separates the two measured cases by the size of S, nothing deeper.
+    const bool small_share = mcl < (int64_t)150000 * G && (int64_t)2 * m * 8 <= (48ll << 20);
+    const bool jmajor = jmajor_env >= 0 ? jmajor_env != 0 : ((int64_t)2 * m * 8 > (12ll << 20) && !small_share);
     jmajor_out = jmajor;
     // what a piece costs besides its cycles -- the load of the band's rows into the LDS and the fill of the register pipeline -- in cycle
     // units.  Measured per workgroup with DESC_DEBUG_WGCLOCK (tools/wg_clock.py, least squares of the durations on the plan): 11 us per piece
@@ -2783,25 +2867,50 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     }
     h->obj_grid = (int)std::min<int64_t>(SHARD_PARTS, std::max<int64_t>(1, (nsl + 3) / 4));     // sharded runs: its partials travel in the all-gather slice
     h->colsum_stride = (h->max_deg + 1) | 1;                 // odd stride: the 4 copies start on different banks
-    h->colsum_grid = (int)std::max<int64_t>(1, n);            // one node per workgroup: the dispatcher balances
+    // one node per workgroup: the dispatcher balances
     // ... in REVERSE node order (round 3).  The sweep before it ends with the last j-blocks, i.e. the weights of the segments with the largest
     // j are the freshest lines in the L2s, and the sweep after it begins with the first j-blocks, i.e. gathers T2 of the smallest j first: going
     // through the nodes from n-1 down to 0 the pass starts on what the sweep just wrote and ends on what the next sweep reads first.  C4
     // (profiles/r03_node_order.txt, alternating in one call): column sums 238 -> 232 us, the SWEEP 1193 -> 1129 us (-5.4 %); a hashed
     // shuffle: sweep -4 % but column sums +4 %; longest row first (the scheduling argument): erratic; C5, C2, C3: within noise.
     // DESC_DEBUG_NODE_ORDER: 0 ascending (round 2), 1 longest row first, 2 reverse (default), 3 hashed shuffle.
-    if (n > 0 && env_int("DESC_DEBUG_NODE_ORDER", 2)) {
-        hvec<int32_t> ord((size_t)n);
-        for (int64_t v = 0; v < n; ++v) ord[v] = (int32_t)v;
+    // Sharded runs (round 4): only the nodes that have segments of this rank in their row are visited, and of their row only the run of CSR
+    // slots those segments occupy (k_node_runs).  Measured per rank of 8 at C4 before that (profiles/r04_shard_w8_c4_before.json): 132 us
+    // for an eighth of the cycles against 233 us for all of them on one GPU -- every rank started all n workgroups and walked whole rows.
+    {
+        hvec<int32_t> ord;
+        hvec<int2> runs;
+        ord.reserve((size_t)n);
+        if (h->world > 1 && n > 0) {
+            if ((rc = dalloc(h, &h->d_node_run, (size_t)n))) return rc;
+            hipLaunchKernelGGL(k_node_runs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_rowptr, d_adj, P.rank_node[h->rank], P.rank_node[h->rank + 1],
+                               h->d_node_run, (int)n);
+            runs.resize((size_t)n);
+            DESC_HIP(hipStreamSynchronize(h->stream));
+            DESC_HIP(hipMemcpy(runs.data(), h->d_node_run, sizeof(int2) * (size_t)n, hipMemcpyDeviceToHost));
+            for (int64_t v = 0; v < n; ++v) if (runs[v].y > runs[v].x) ord.push_back((int32_t)v);
+        } else
+            for (int64_t v = 0; v < n; ++v) ord.push_back((int32_t)v);
         const int mode = env_int("DESC_DEBUG_NODE_ORDER", 2);
         if (mode == 2) std::reverse(ord.begin(), ord.end());
         else if (mode == 3) std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return mix64((uint64_t)x) < mix64((uint64_t)y); });
-        else std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return P.rowptr[x + 1] - P.rowptr[x] > P.rowptr[y + 1] - P.rowptr[y]; });
-        if ((rc = dalloc(h, &h->d_node_order, (size_t)n)) || (rc = upload(h, h->d_node_order, ord.data(), (size_t)n))) return rc;
+        else if (mode == 1) std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return P.rowptr[x + 1] - P.rowptr[x] > P.rowptr[y + 1] - P.rowptr[y]; });
+        // sharded: rows with a short run of this rank's segments go to the back of the list -- k_colsum_node gives them a wave each
+        h->colsum_long = (int)ord.size();
+        if (!runs.empty() && 4 * COLSUM_SHORT <= ((h->max_deg + 1) | 1) && env_int("DESC_DEBUG_COLSUM_SHORT", 1)) {
+            const auto mid = std::stable_partition(ord.begin(), ord.end(), [&](int32_t v) { return runs[v].y - runs[v].x > COLSUM_SHORT; });
+            h->colsum_long = (int)(mid - ord.begin());
+        }
+        h->colsum_nodes = (int)ord.size();
+        h->colsum_grid = h->colsum_long + (h->colsum_nodes - h->colsum_long + 3) / 4;     // workgroups (0: a rank without segments); the launch adds the bookkeeping workgroup
+        if ((rc = dalloc(h, &h->d_node_order, ord.size())) || (rc = upload(h, h->d_node_order, ord.data(), ord.size()))) return rc;
         DESC_HIP(hipStreamSynchronize(h->stream));
     }
     {
-        const size_t lds = (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int));
+        int bits = 0;
+        while ((1 << bits) < h->max_deg + 1) ++bits;
+        h->colsum_fx_bits = 62 - bits;
+        const size_t lds = colsum_lds(h);
         if (lds > 64 * 1024)
         {
             DESC_HIP(hipFuncSetAttribute((const void*)k_colsum_node<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -3151,14 +3260,19 @@ int desc_pgd_iterate_timed(desc_pgd* h, int32_t n_iters, float* ms_total, float*
     return DESC_OK;
 }
 
+namespace { int shard_unpack_pending(desc_pgd* h); }
+
 int desc_pgd_sync(desc_pgd* h) {
     if (!h) return fail(DESC_ERR_INVALID, "NULL handle");
     int rc = set_device(h); if (rc) return rc;
+    if ((rc = shard_unpack_pending(h))) return rc;           // fused protocol: a sync leaves every enqueued iteration complete, its unpacking included
     DESC_HIP(hipStreamSynchronize(h->stream));
     if (h->comm_stream) DESC_HIP(hipStreamSynchronize(h->comm_stream));
     DESC_HIP(hipGetLastError());
     return DESC_OK;
 }
+
+namespace { int shard_unpack_pending(desc_pgd* h); }
 
 int desc_pgd_download(desc_pgd* h, desc_result* r) {
     if (!h || !r) return fail(DESC_ERR_INVALID, "NULL argument");
@@ -3167,6 +3281,7 @@ int desc_pgd_download(desc_pgd* h, desc_result* r) {
     int rc = set_device(h); if (rc) return rc;
     const int T = h->t_done;
     flush_finalize(h);
+    if ((rc = shard_unpack_pending(h))) return rc;           // fused protocol: S and the stop rule of the last sweep
     if (h->comm_stream) DESC_HIP(hipStreamSynchronize(h->comm_stream));
     // objective of the last sweep (DESC_PGD.m:233) and its stop test
     if (h->m_pos > 0 && T >= 1 && h->world == 1 && h->final_obj_T != T) {
@@ -3363,14 +3478,7 @@ bool shard_direct(const desc_pgd* h) { return h->world == 1 && !h->force_coll &&
 int shard_enqueue_colsum(desc_pgd* h, hipStream_t st) {
     const int rd = h->t_done & 1;
     const bool direct = shard_direct(h);
-    if (h->colsum_cl == 8)
-        hipLaunchKernelGGL(k_colsum_node<8>, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int)), st,
-                           h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, h->d_w[rd], direct ? h->d_T : h->x_T, (int)h->n, h->colsum_stride, h->d_state,
-                           direct ? (const int32_t*)nullptr : h->d_xpos, FinArgs{}, h->d_ticket, h->d_node_order);
-    else
-    hipLaunchKernelGGL(k_colsum_node<16>, dim3(h->colsum_grid + 1), dim3(256), (size_t)h->colsum_stride * (4 * sizeof(double) + 3 * sizeof(int)), st,
-                       h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, h->d_w[rd], direct ? h->d_T : h->x_T, (int)h->n, h->colsum_stride, h->d_state,
-                       direct ? (const int32_t*)nullptr : h->d_xpos, FinArgs{}, h->d_ticket, h->d_node_order);
+    launch_colsum(h, st, h->d_w[rd], direct ? h->d_T : h->x_T, direct ? nullptr : h->d_xpos, FinArgs{});
     DESC_HIP(hipGetLastError());
     return DESC_OK;
 }
@@ -3472,7 +3580,7 @@ int desc_pgd_shard_set_collectives(desc_pgd* h, const desc_collectives* c) {
     if (!h->x_sall && (rc = desc_pgd_shard_bind(h, nullptr, nullptr, nullptr, nullptr))) return rc;
     if (!h->comm_stream) {
         DESC_HIP(stream_acquire(&h->comm_stream));
-        for (hipEvent_t* e : {&h->ev_col, &h->ev_rs, &h->ev_sw, &h->ev_done}) DESC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t* e : {&h->ev_col, &h->ev_rs, &h->ev_sw, &h->ev_ag}) DESC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     return DESC_OK;
 }
@@ -3494,14 +3602,31 @@ int desc_pgd_shard_start(desc_pgd* h, const desc_params* p) {
     DESC_HIP(hipEventRecord(h->ev_sw, h->stream));
     DESC_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_sw, 0));
     if ((rc = shard_all_gather(h))) return rc;
-    if ((rc = shard_enqueue_unpack(h, h->comm_stream, h->d_S[0], h->d_S[1], 0, 0, 0))) return rc;
-    DESC_HIP(hipEventRecord(h->ev_done, h->comm_stream));
+    DESC_HIP(hipEventRecord(h->ev_ag, h->comm_stream));
+    DESC_HIP(hipStreamWaitEvent(h->stream, h->ev_ag, 0));
+    if ((rc = shard_enqueue_unpack(h, h->stream, h->d_S[0], h->d_S[1], 0, 0, 0))) return rc;
+    h->unpack_pending = 0;
     return DESC_OK;
 }
 
-// n iterations: compute stream  colsum(t) . . . . . . sweep(t) | colsum(t+1) . . . sweep(t+1)
-//               comm stream               RS(t)                | AG(t), unpack(t) + stop rule, RS(t+1)
-// colsum(t+1) needs only the weights of sweep t, so the all-gather of S and its unpacking overlap it.
+namespace {
+// the all-gather of sweep t has been enqueued on the exchange stream (ev_ag behind it): its unpacking + the stop rule, on the compute stream
+int shard_unpack_pending(desc_pgd* h) {
+    if (!h->unpack_pending) return DESC_OK;
+    const int t = h->unpack_pending;
+    h->unpack_pending = 0;
+    DESC_HIP(hipStreamWaitEvent(h->stream, h->ev_ag, 0));
+    // one rank on the direct path: the sweep already wrote S of every edge; only the bookkeeping is left
+    return shard_enqueue_unpack(h, h->stream, shard_direct(h) ? nullptr : h->d_S[t & 1], nullptr, t, 0, h->last_parts);
+}
+}  // namespace
+
+// n iterations (round 4):
+//   compute stream   colsum(t+1) | unpack(t) + stop rule | sweep(t+1)
+//   exchange stream  AG(t)       | RS(t+1) . . . . . . . |            AG(t+1)
+// colsum(t+1) needs only the weights of sweep t: it runs under the all-gather of S(t); the unpacking of S(t) runs under the reduce-scatter
+// of the mirror sums.  (Round 3 had the unpack on the exchange stream IN FRONT of the reduce-scatter: measured per rank of 8 at C4,
+// profiles/r04_shard_w8_c4_*.json, all-gather + unpack (~60 + 90 us) outlast the column sums (50-80 us), so the reduce-scatter started late.)
 int desc_pgd_shard_iterate(desc_pgd* h, int32_t n_iters) {
     if (!h || !h->armed) return fail(DESC_ERR_STATE, "desc_pgd_shard_start must be called first");
     if (!h->comm_stream) return fail(DESC_ERR_STATE, "desc_pgd_shard_set_collectives must be called first");
@@ -3509,23 +3634,22 @@ int desc_pgd_shard_iterate(desc_pgd* h, int32_t n_iters) {
     int rc = set_device(h); if (rc) return rc;
     for (int q = 0; q < n_iters; ++q) {
         if ((rc = shard_enqueue_colsum(h, h->stream))) return rc;
-        if (h->world > 1 || h->force_coll) {
+        const bool exchange = h->world > 1 || h->force_coll;
+        if (exchange) {
             DESC_HIP(hipEventRecord(h->ev_col, h->stream));
             DESC_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_col, 0));
             const int rcc = h->coll.reduce_scatter(h->x_T, h->x_Trecv, (size_t)h->t_part, 8 /* ncclDouble */, 0 /* ncclSum */, h->coll.comm, h->comm_stream);
             if (rcc) return coll_fail(rcc, "reduce_scatter");
             DESC_HIP(hipEventRecord(h->ev_rs, h->comm_stream));
-            DESC_HIP(hipStreamWaitEvent(h->stream, h->ev_rs, 0));      // implies S of the previous iteration unpacked (same stream, earlier)
-        } else {
-            DESC_HIP(hipStreamWaitEvent(h->stream, h->ev_done, 0));
         }
+        if ((rc = shard_unpack_pending(h))) return rc;                  // S of the previous sweep into the CSR-aligned replica, under the reduce-scatter
+        if (exchange) DESC_HIP(hipStreamWaitEvent(h->stream, h->ev_rs, 0));
         if ((rc = shard_enqueue_sweep(h, h->stream))) return rc;
         DESC_HIP(hipEventRecord(h->ev_sw, h->stream));
         DESC_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_sw, 0));
         if ((rc = shard_all_gather(h))) return rc;
-        // one rank on the direct path: the sweep already wrote S of every edge; only the bookkeeping is left
-        if ((rc = shard_enqueue_unpack(h, h->comm_stream, shard_direct(h) ? nullptr : h->d_S[h->t_done & 1], nullptr, h->t_done, 0, h->last_parts))) return rc;
-        DESC_HIP(hipEventRecord(h->ev_done, h->comm_stream));
+        DESC_HIP(hipEventRecord(h->ev_ag, h->comm_stream));
+        h->unpack_pending = h->t_done;
     }
     return DESC_OK;
 }
@@ -3544,13 +3668,14 @@ int desc_pgd_shard_run(desc_pgd* h, const desc_params* p, desc_result* r) {
         if (left > 0) { int32_t stop = 0; if ((rc = desc_pgd_stopped(h, &stop))) return rc; if (stop) break; }
     }
     if (h->t_done >= 1) {
-        DESC_HIP(hipStreamWaitEvent(h->stream, h->ev_done, 0));
+        if ((rc = shard_unpack_pending(h))) return rc;
         if ((rc = shard_enqueue_objective(h, h->stream))) return rc;
         DESC_HIP(hipEventRecord(h->ev_sw, h->stream));
         DESC_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_sw, 0));
         if ((rc = shard_all_gather(h))) return rc;
-        if ((rc = shard_enqueue_unpack(h, h->comm_stream, nullptr, nullptr, h->t_done, 1, h->obj_grid))) return rc;
-        DESC_HIP(hipEventRecord(h->ev_done, h->comm_stream));
+        DESC_HIP(hipEventRecord(h->ev_ag, h->comm_stream));
+        DESC_HIP(hipStreamWaitEvent(h->stream, h->ev_ag, 0));
+        if ((rc = shard_enqueue_unpack(h, h->stream, nullptr, nullptr, h->t_done, 1, h->obj_grid))) return rc;
         h->objective_done = true; h->final_obj_T = h->t_done;
     }
     rc = desc_pgd_download(h, r); if (rc) return rc;
@@ -3638,6 +3763,7 @@ int desc_pgd_stopped(desc_pgd* h, int32_t* stopped) {
     int rc = set_device(h); if (rc) return rc;
     DevState st{};
     flush_finalize(h);
+    if ((rc = shard_unpack_pending(h))) return rc;
     if (h->comm_stream) DESC_HIP(hipStreamSynchronize(h->comm_stream));
     DESC_HIP(hipStreamSynchronize(h->stream));
     DESC_HIP(hipMemcpy(&st, h->d_state, sizeof st, hipMemcpyDeviceToHost));      // synchronous: `st` is a stack slot

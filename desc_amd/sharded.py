@@ -347,12 +347,48 @@ def init_distributed():
     return rank, world, device
 
 
+def shared_problem(name, rank, world, comm, generate):
+    """The synthetic workload, generated ONCE: rank 0 runs the generator and parks the arrays in /dev/shm, the other ranks of the node map
+    them (round 3 had every rank run the generator: 4.5 s of NumPy per rank at C4, all at the same time on the host's cores).
+    Returns (nn, ii, jj, rij, err_vec)."""
+    if world == 1:
+        mo, nn, ii, jj, rij = generate(name)
+        return nn, ii, jj, rij, mo.ErrVec
+    base = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"desc_amd_bench_{os.environ.get('MASTER_PORT', '0')}_{name}")
+    keys = ("ii", "jj", "rij", "err")
+    if rank == 0:
+        mo, nn, ii, jj, rij = generate(name)
+        arrs = dict(ii=ii, jj=jj, rij=np.ascontiguousarray(rij).reshape(-1), err=np.asarray(mo.ErrVec, dtype=np.float64))
+        for k in keys:
+            np.save(f"{base}_{k}.npy", arrs[k])
+        with open(f"{base}_n.txt", "w") as f:
+            f.write(str(int(nn)))
+    comm.barrier()
+    if rank != 0:
+        with open(f"{base}_n.txt") as f:
+            nn = int(f.read())
+        arrs = {k: np.load(f"{base}_{k}.npy", mmap_mode="r") for k in keys}
+    out = (nn, np.ascontiguousarray(arrs["ii"]), np.ascontiguousarray(arrs["jj"]), np.ascontiguousarray(arrs["rij"]), np.ascontiguousarray(arrs["err"]))
+    comm.barrier()                                      # every rank holds its copy: the files can go
+    if rank == 0:
+        for k in keys:
+            try:
+                os.remove(f"{base}_{k}.npy")
+            except OSError:
+                pass
+        try:
+            os.remove(f"{base}_n.txt")
+        except OSError:
+            pass
+    return out
+
+
 def _bench_one(name, args, rank, world, device, comm, describe, generate, native_comm):
     """K timed sharded iterations of one workload; returns the measurements (identical on every rank).
     native_comm: RcclComm (fused C protocol) or None (piecewise protocol over torch.distributed)."""
     import torch
     K, W = args.steps, args.warmup
-    mo, nn, ii, jj, rij = generate(name)                 # identical on every rank (fixed seeds)
+    nn, ii, jj, rij, err_vec = shared_problem(name, rank, world, comm, generate)
     prob = _lib.ProblemArrays(nn, ii, jj, rij)
     t0 = time.perf_counter()
     try:
@@ -400,11 +436,40 @@ def _bench_one(name, args, rank, world, device, comm, describe, generate, native
         out = drv.finish()
         driver = "piecewise protocol (torch.distributed collectives between ctypes calls)"
     info = shard.info
+    lay = shard.solver.layout_stats()
+    # this rank's share and what it exchanges per iteration: gathered to rank 0 for the line
+    mine = dict(rank=rank, cycles=int(info.cyc_hi - info.cyc_lo), segments=int(info.seg_hi - info.seg_lo), pieces=lay.get("pieces", 0),
+                sweep_kernel=shard.solver.last_sweep(),
+                reduce_scatter_bytes_out=int(8 * info.t_part * (world - 1)), all_gather_bytes_out=int(8 * info.slice_len * (world - 1)))
+    per_rank = [None] * world
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_gather_object(per_rank, mine)
+    else:
+        per_rank = [mine]
     res = dict(name=name, nn=nn, m=shard.solver.m, m_pos=info.m_pos, m_cycle=info.m_cycle, n_sample=int(n_sample), dt=dt,
-               t_struct=t_struct, t_create=t_create, err=float(np.mean(np.abs(out["S_vec"] - mo.ErrVec))),
-               workload=describe(name), driver=driver)
+               t_struct=t_struct, t_create=t_create, err=float(np.mean(np.abs(out["S_vec"] - err_vec))),
+               workload=describe(name), driver=driver, per_rank=per_rank, S_vec=out["S_vec"], ii=ii, jj=jj, rij=rij, device=device)
     shard.destroy()
     return res
+
+
+def _cpu_leg(r, args, cpu_baseline):
+    """cpu_baseline + parity_vs_cpu for the N > 1 line (rank 0, after the timed region).  The oracle needs the cycle structure on the
+    host: rank 0 builds it once more on its GPU and exports it (bench.py does the same at N = 1); the sharded S_vec it is compared with
+    comes from a fresh one-GPU solve of the same iteration count -- what the ranks computed together is checked against the one-GPU
+    run by tests/test_gpu_sharded.py, and against the truth by `mean_abs_err_vs_truth` above."""
+    prob = _lib.ProblemArrays(r["nn"], r["ii"], r["jj"], r["rij"])
+    st = _lib.Structure.build(prob, 30, args.seed, _lib.BUILD_DEVICE, r["device"])
+    arrays = st.arrays()
+    st.free()
+    cb, ref, it = cpu_baseline(r["nn"], r["ii"], r["jj"], r["rij"], arrays, budget_s=12.0, max_iters=10 if r["name"] in ("C4", "C5") else 50)
+    p = _lib.default_params()
+    p.iters = it; p.lr = 0.01; p.seed = args.seed; p.patience = (1 << 31) - 1; p.device = r["device"]
+    out = _lib.solve(prob, p)
+    d = np.abs(out["S_vec"] - ref["S_vec"])
+    return cb, {"iters": int(it), "mean_abs": float(d.mean()), "max_abs": float(d.max()),
+                "what": "S_vec of a one-GPU HIP run vs oracle/desc_oracle.c (OpenMP) after the same iterations, same structure"}
 
 
 def bench_sharded(args, WORKLOADS, describe, generate, cpu_baseline):
@@ -454,10 +519,21 @@ def bench_sharded(args, WORKLOADS, describe, generate, cpu_baseline):
                      "kernel": "whole iteration incl. collectives (aggregate over ranks)", "bytes_per_launch": bytes_iter},
         "cycle_updates_per_s": r["m_cycle"] * K / dt,
         "cpu_baseline": None,
+        "per_rank": r["per_rank"],
         "setup_ms": {"structure": r["t_struct"] * 1e3, "create_shard": r["t_create"] * 1e3},
         "mean_abs_err_vs_truth": r["err"],
         "secondary_config": extra,
     }
+    if rank == 0 and not getattr(args, "no_cpu_baseline", False):
+        # The CPU data point of the SAME workload, AFTER the timed region, on rank 0's host cores (the other ranks wait at the barrier
+        # below): the oracle's OpenMP restatement for a bounded number of iterations, and the GPU result of the same count next to it.
+        try:
+            cb, parity = _cpu_leg(r, args, cpu_baseline)
+            line["cpu_baseline"] = cb
+            line["gpu_over_cpu"] = line["value"] / cb["value"]
+            line["parity_vs_cpu"] = parity
+        except Exception as e:                           # test infrastructure: never lose the line over it
+            line["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(line), flush=True)
     import torch.distributed as dist

@@ -508,7 +508,10 @@ def test_make_plots_traces(lib):
     st.free()
     tr = sol.run_traced(pr, dp, mo2.ErrVec)
     assert plain["iters_run"] < 400 and tr["iters_run"] == plain["iters_run"]
-    assert np.array_equal(tr["S_vec"], plain["S_vec"]) and np.array_equal(tr["obj"], plain["obj"])
+    assert np.array_equal(tr["S_vec"], plain["S_vec"])
+    # the objective of the iteration at which the run stops comes from k_objective_node in the traced run (evaluated by the download of
+    # that iteration) and from the following sweep's workgroup partials in the plain one: the same terms in another order
+    assert np.allclose(tr["obj"], plain["obj"], rtol=1e-12, atol=0)
     assert len(tr["svec_errors"]) == tr["iters_run"] and tr["R_est_all"].shape == (tr["iters_run"], 3, 3, n2)
     Rg, _ = lib.gcw_run(dp, tr["S_vec"])
     assert np.abs(tr["R_est_all"][-1] - Rg).max() < 1e-9           # same S_vec, same solver: the last estimate is GCW of the result
