@@ -83,6 +83,10 @@ __device__ __forceinline__ double abs_acos_ext(double x) {
     return acos(x);
 }
 
+// The mirror-weight sums travel as 64-bit fixed-point integers (k_colsum_node: order-independent adds; sharded runs reduce-scatter them as
+// ncclInt64, so the totals -- and with them S_vec and the weights -- are bitwise the same for every number of ranks).  `t` holds the bits.
+__device__ __forceinline__ double fx_to_double(double t, double fx_inv) { return (double)__double_as_longlong(t) * fx_inv; }
+
 template <int STEP>
 __device__ __forceinline__ double apply_step(const StepArgs& a, double w, double g, int64_t c) {
     if (STEP == DESC_STEP_HYBRID) {               // HybridGradient.m:28-35 (strategy 0)
@@ -408,6 +412,7 @@ struct NodeSweepArgs {
     uint32_t t_bytes;          // bytes of Tfull (sharded runs: this rank's part of the reduce-scattered sums)
     uint32_t slice_bytes;      // bytes of s_slice (sharded runs)
     uint32_t seg_count;        // segments in cum / einfo / xt (device order, all ranks): cum has seg_count + 1 entries
+    double fx_inv;             // 2^-fx_bits: Tfull holds fixed-point integers (fx_to_double)
 };
 
 struct StreamRegs { uint4 pk; double2 w, d; };   // one 16-byte vector of each streamed array
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
         // ---- arithmetic of chunk k
         const int a0 = d0.c0 & ~3;
         const int cnt = r0.cnt;
-        const double T1 = c.g.T1, T2 = c.g.T2, nv = cnt > 0 ? s_nv[cnt] : 0.0;
+        const double T1 = fx_to_double(c.g.T1, a.fx_inv), T2 = fx_to_double(c.g.T2, a.fx_inv), nv = cnt > 0 ? s_nv[cnt] : 0.0;
         double ws[E];
         uint32_t okm = 0;
         double part = 0.0;
@@ -963,8 +968,8 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
             g.T1 = (DESC_BAND_ABLATE & 32) ? 0.25 : buf_load_f64(rs_T, (uint32_t)((lane & 1) ? tb : ta) * 8u);
             g.T2 = 0.0;
 #else
-            g.T1 = (DESC_BAND_ABLATE & 32) ? 0.25 : a.Tfull[ta];                      // column j of node i = sum(wijk(IKJ(mask)))  (:189)
-            g.T2 = (DESC_BAND_ABLATE & 32) ? 0.25 : a.Tfull[tb];                      // column i of node j = sum(wijk(JKI(mask)))  (:190)
+            g.T1 = (DESC_BAND_ABLATE & 32) ? 0.25 : fx_to_double(a.Tfull[ta], a.fx_inv);                      // column j of node i = sum(wijk(IKJ(mask)))  (:189)
+            g.T2 = (DESC_BAND_ABLATE & 32) ? 0.25 : fx_to_double(a.Tfull[tb], a.fx_inv);                      // column i of node j = sum(wijk(JKI(mask)))  (:190)
 #endif
             g.So = (DESC_BAND_ABLATE & 16) ? 0.5 : s_rows[r.sa - pd.row_lo];
             return g;
@@ -974,8 +979,9 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
             const int cnt = r.cnt;
 #if DESC_BUF
             Gat g = g0;
-            g.T1 = dpp_mov_f64<0xA0>(g0.T1);        // quad_perm:[0,0,2,2]: the even lane's value = T1
-            g.T2 = dpp_mov_f64<0xF5>(g0.T1);        // quad_perm:[1,1,3,3]: the odd lane's value = T2
+            const double tconv = (DESC_BAND_ABLATE & 32) ? g0.T1 : fx_to_double(g0.T1, a.fx_inv);       // this lane's load: T1 (even lanes) or T2 (odd lanes)
+            g.T1 = dpp_mov_f64<0xA0>(tconv);        // quad_perm:[0,0,2,2]: the even lane's value = T1
+            g.T2 = dpp_mov_f64<0xF5>(tconv);        // quad_perm:[1,1,3,3]: the odd lane's value = T2
 #else
             const Gat& g = g0;
 #endif
@@ -1311,7 +1317,7 @@ constexpr int COLSUM_SHORT = 128;         // sharded runs: rows whose owned run 
 template <int CL>
 __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, const int2* adj_seg, const uint32_t* moff, const uint16_t* midx, const double* w,
                                                      double* Tfull, int n, int stride_cols, const DevState* st, const int32_t* xpos, FinArgs fin, int32_t* tail_ticket, const int32_t* node_order,
-                                                     const int2* node_run, int n_long, int copies, double fx_scale, double fx_inv) {
+                                                     const int2* node_run, int n_long, int copies, double fx_scale) {
     if (blockIdx.x == gridDim.x - 1) {
         if (threadIdx.x < 64 && fin.st) finalize_wave(fin);
         if (threadIdx.x == 0 && tail_ticket) *tail_ticket = 0;          // the sweep that follows hands out its tail pieces from 0
@@ -1344,7 +1350,7 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
         colsum_walk<CL>(acc, seg_base, seg_cf, seg_mo, nrun, wv, 4, midx, w, lane, fx_scale);
         __syncthreads();
         for (int t = threadIdx.x; t < deg; t += 256)
-            Tfull[xpos ? xpos[r0 + t] : r0 + t] = (double)(long long)acc[t] * fx_inv;   // xpos: owner-sorted exchange layout
+            Tfull[xpos ? xpos[r0 + t] : r0 + t] = __longlong_as_double((long long)acc[t]);   // the fixed-point bits (fx_to_double); xpos: owner-sorted exchange layout
         return;
     }
     // Short runs (sharded ranks: most rows hold only a few dozen of a rank's segments -- at C4 over 8 GPUs rank 0 visits 4670 rows with ~66 of
@@ -1366,7 +1372,7 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
     __builtin_amdgcn_wave_barrier();                  // one wave: its LDS operations execute in program order
     colsum_walk<CL>(mine, sb, sc, sm, nrun, 0, 1, midx, w, lane, fx_scale);
     __builtin_amdgcn_wave_barrier();
-    for (int t = lane; t < deg; t += 64) Tfull[xpos ? xpos[r0 + t] : r0 + t] = (double)(long long)mine[t] * fx_inv;
+    for (int t = lane; t < deg; t += 64) Tfull[xpos ? xpos[r0 + t] : r0 + t] = __longlong_as_double((long long)mine[t]);
 }
 
 // Setup of the node layout: packs idx_i(k) / idx_j(k) / mirror bits of every cycle and
@@ -2093,13 +2099,13 @@ void launch_colsum(desc_pgd* h, hipStream_t st, const double* w, double* T, cons
     const dim3 grid(h->colsum_grid + 1), block(256);
     const size_t lds = colsum_lds(h);
     const int copies = colsum_copies(h);
-    const double fx_scale = std::ldexp(1.0, h->colsum_fx_bits), fx_inv = std::ldexp(1.0, -h->colsum_fx_bits);
+    const double fx_scale = std::ldexp(1.0, h->colsum_fx_bits);
     if (h->colsum_cl == 8)
         hipLaunchKernelGGL(k_colsum_node<8>, grid, block, lds, st, h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, w, T, h->colsum_nodes, h->colsum_stride, h->d_state,
-                           xpos, fin, h->d_ticket, h->d_node_order, h->d_node_run, h->colsum_long, copies, fx_scale, fx_inv);
+                           xpos, fin, h->d_ticket, h->d_node_order, h->d_node_run, h->colsum_long, copies, fx_scale);
     else
         hipLaunchKernelGGL(k_colsum_node<16>, grid, block, lds, st, h->d_rowptr, h->d_adj_seg, h->d_moff, h->d_midx, w, T, h->colsum_nodes, h->colsum_stride, h->d_state,
-                           xpos, fin, h->d_ticket, h->d_node_order, h->d_node_run, h->colsum_long, copies, fx_scale, fx_inv);
+                           xpos, fin, h->d_ticket, h->d_node_order, h->d_node_run, h->colsum_long, copies, fx_scale);
 }
 
 // enqueue sweep number t (1-based) and its finalize; ev0/ev1 bracket the kernels of the sweep proper
@@ -2118,7 +2124,7 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
         a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
         a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->d_T; a.xt = nullptr; a.nv_tab = h->d_nv; a.partials = h->d_partials;
         a.state = h->d_state; a.st = st; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks; a.max_cnt = h->max_cnt; a.ablate = h->ablate;
-        a.csr_bytes = (uint32_t)(16 * h->m); a.t_bytes = a.csr_bytes; a.slice_bytes = 0; a.seg_count = (uint32_t)h->m_pos;
+        a.csr_bytes = (uint32_t)(16 * h->m); a.t_bytes = a.csr_bytes; a.slice_bytes = 0; a.seg_count = (uint32_t)h->m_pos; a.fx_inv = std::ldexp(1.0, -h->colsum_fx_bits);
         launch_sweep_node_layout(h, a, adam);
     } else {
         SweepArgs a{};
@@ -3492,7 +3498,7 @@ int shard_enqueue_sweep(desc_pgd* h, hipStream_t st) {
     a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
     a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_Trecv; a.xt = h->d_xt; a.nv_tab = h->d_nv;
     a.s_slice = my_slice(h); a.partials = my_slice(h) + h->slice_S;       // S and the workgroup partials go straight into the slice
-    a.csr_bytes = (uint32_t)(16 * h->m); a.t_bytes = (uint32_t)(8 * h->t_part); a.slice_bytes = (uint32_t)(8 * h->slice_S); a.seg_count = (uint32_t)h->m_pos;
+    a.csr_bytes = (uint32_t)(16 * h->m); a.t_bytes = (uint32_t)(8 * h->t_part); a.slice_bytes = (uint32_t)(8 * h->slice_S); a.seg_count = (uint32_t)h->m_pos; a.fx_inv = std::ldexp(1.0, -h->colsum_fx_bits);
     if (shard_direct(h)) { a.Tfull = h->d_T; a.xt = nullptr; a.s_slice = nullptr; a.t_bytes = a.csr_bytes; }
     a.state = h->d_state; a.st = sa; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks;
     a.max_cnt = h->max_cnt; a.ablate = 0;
@@ -3638,7 +3644,7 @@ int desc_pgd_shard_iterate(desc_pgd* h, int32_t n_iters) {
         if (exchange) {
             DESC_HIP(hipEventRecord(h->ev_col, h->stream));
             DESC_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_col, 0));
-            const int rcc = h->coll.reduce_scatter(h->x_T, h->x_Trecv, (size_t)h->t_part, 8 /* ncclDouble */, 0 /* ncclSum */, h->coll.comm, h->comm_stream);
+            const int rcc = h->coll.reduce_scatter(h->x_T, h->x_Trecv, (size_t)h->t_part, 4 /* ncclInt64: fixed-point mirror sums, order-independent */, 0 /* ncclSum */, h->coll.comm, h->comm_stream);
             if (rcc) return coll_fail(rcc, "reduce_scatter");
             DESC_HIP(hipEventRecord(h->ev_rs, h->comm_stream));
         }

@@ -119,8 +119,10 @@ class HipShard:
         # stream_ctx) the collectives, so they are ordered without host synchronisation.
         self.stream = stream if stream is not None else torch.cuda.Stream(dev)
         with torch.cuda.stream(self.stream):
-            self.T = torch.zeros(self.info.t_len, dtype=torch.float64, device=dev)        # send: zero padding stays zero
-            self.T_recv = torch.zeros(self.info.t_part, dtype=torch.float64, device=dev)
+            # the mirror sums are exchanged as 64-bit fixed-point integers (k_colsum_node): integer sums do not depend on the order the
+            # collective adds the ranks' parts in, so S_vec comes out bitwise the same for every number of ranks
+            self.T = torch.zeros(self.info.t_len, dtype=torch.int64, device=dev)        # send: zero padding stays zero
+            self.T_recv = torch.zeros(self.info.t_part, dtype=torch.int64, device=dev)
             self.sall = torch.zeros(self.info.world * self.info.slice_len, dtype=torch.float64, device=dev)
         self.stream.synchronize()
         self.solver.shard_bind(self.T.data_ptr(), self.T_recv.data_ptr(), self.sall.data_ptr(), self.stream.cuda_stream)
@@ -276,7 +278,7 @@ class TrampolineComm:
         def rs(send, recv, recvcount, dtype, op, comm, stream):
             try:
                 L.desc_device_synchronize(self.device)
-                h = torch.empty(self.world * recvcount, dtype=torch.float64)
+                h = torch.empty(self.world * recvcount, dtype=torch.int64 if dtype == 4 else torch.float64)   # 4 = ncclInt64 (fixed-point mirror sums), 8 = ncclDouble
                 L.desc_memcpy_d2h(h.data_ptr(), send, 8 * h.numel())
                 dist.all_reduce(h, group=self.group)
                 mine = h.view(self.world, recvcount)[self.rank].contiguous()

@@ -230,8 +230,9 @@ typedef struct desc_shard_info {
 int desc_pgd_create_shard(const desc_problem* prob, const desc_structure* s, int32_t device,
                           int32_t rank, int32_t world, desc_pgd** out);
 int desc_pgd_shard_info(const desc_pgd* h, desc_shard_info* info);
-/* T_send: t_len doubles, zero-initialised by the caller (this rank's partial mirror sums, grouped by
- * owning rank: part r = [r*t_part, (r+1)*t_part)); T_recv: t_part doubles (the caller's
+/* T_send: t_len 8-byte words, zero-initialised by the caller (this rank's partial mirror sums, grouped by
+ * owning rank: part r = [r*t_part, (r+1)*t_part)); the words are 64-bit fixed-point INTEGERS: the caller's
+ * reduce-scatter must add them as int64 (ncclInt64 / torch.int64), not as doubles.  T_recv: t_part words (the caller's
  * reduce-scatter(sum) of every rank's T_send); sall: world*slice_len doubles, zero-initialised; all on `device`.
  * All three NULL: the library allocates them itself (the fused protocol below needs no caller buffers).
  * hip_stream: the stream the caller's collectives are ordered on (NULL keeps the handle's own). */
@@ -250,8 +251,10 @@ int desc_pgd_shard_objective(desc_pgd* h, int32_t phase);
 /* Fused protocol: the library enqueues whole iterations itself -- column sums, reduce-scatter, sweep, all-gather,
  * unpack + stop rule -- on two streams, so that the all-gather of S_vec and its unpacking overlap the next
  * iteration's column-sum pass (which needs only the weights).  The collectives are the caller's: two function
- * pointers with the signatures of RCCL's ncclReduceScatter / ncclAllGather (datatype 8 = ncclDouble, op 0 =
- * ncclSum, hipStream_t stream) and the communicator they take; a binding passes the addresses of the RCCL
+ * pointers with the signatures of RCCL's ncclReduceScatter / ncclAllGather (hipStream_t stream; the reduce-scatter is
+ * called with datatype 4 = ncclInt64 and op 0 = ncclSum -- the mirror sums of DESC_PGD.m:189-190 travel as 64-bit fixed-point
+ * integers, whose sum does not depend on the order the ranks' parts are added in --, the all-gather with datatype 8 =
+ * ncclDouble) and the communicator they take; a binding passes the addresses of the RCCL
  * symbols of the process (desc_amd/sharded.py: the librccl.so PyTorch ships, communicator created with
  * ncclCommInitRank from an id broadcast over torch.distributed) or its own trampolines.  world == 1: both may
  * be NULL.  Nothing in the reference corresponds to this (it is single-process MATLAB). */

@@ -62,7 +62,7 @@ def all_gather():
 
 
 def reduce_scatter():
-    tot = torch.zeros(world * Lp, dtype=torch.float64, device=dev)
+    tot = torch.zeros(world * Lp, dtype=shards[0].T.dtype, device=dev)
     for s in shards:
         tot += s.T[:world * Lp]
     for r, s in enumerate(shards):
