@@ -1,5 +1,7 @@
 // Host side of the C ABI that needs no device code: error text, parameter
 // defaults, structure objects, and the one-shot desc_pgd_solve.
+#include <thread>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -162,9 +164,17 @@ int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* 
     double* d_rij = nullptr;
     const char* ov = std::getenv("DESC_DEBUG_OVERLAP_UPLOAD");
     const bool overlap_upload = ov ? std::atoi(ov) == 2 || (std::atoi(ov) != 0 && prob->m >= (1 << 16)) : prob->m >= (1 << 16);     // 0 off, 2 whatever the size (tests)
+    const uint64_t ind0 = g_ind_upload_count.load();
+    std::atomic<bool> builder_done{false};
     try {
     run_threads(overlap_upload ? 2 : 1, [&](int share) {
-        if (share == 1) { (void)upload_rij(prob, p->device, &d_rij); return; }      // failed: d_rij stays NULL, the handle uploads for itself
+        if (share == 1) {
+            // after the builder's own (small) uploads: see g_ind_upload_count
+            while (g_ind_upload_count.load() == ind0 && !builder_done.load()) std::this_thread::sleep_for(std::chrono::microseconds(20));
+            (void)upload_rij(prob, p->device, &d_rij);       // failed: d_rij stays NULL, the handle uploads for itself
+            return;
+        }
+        struct Done { std::atomic<bool>& f; ~Done() { f.store(true); } } done{builder_done};
         rc = structure_build_checked(prob, p->n_sample_min > 0 ? p->n_sample_min : 30, p->seed, p->build_where, p->device, &s, true);
         if (rc == DESC_ERR_TOO_LARGE && p->build_where == DESC_BUILD_DEVICE)      // device budget exceeded: host builder
             rc = structure_build_checked(prob, p->n_sample_min > 0 ? p->n_sample_min : 30, p->seed, DESC_BUILD_HOST, p->device, &s, true);

@@ -1,5 +1,6 @@
 // Internal declarations shared by the host-side translation units of libdesc_amd.so.
 #pragma once
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -53,6 +54,8 @@ struct desc_structure {
     int dev = -1;
     void* ev_fill = nullptr;                  // hipEvent_t recorded behind the kernel that fills d_k / d_tau / d_ktau: the device builder returns while it
                                               // runs (the host plans the solver's layout meanwhile); consumers on other streams wait for it
+    void* fill_stream = nullptr;              // hipStream_t (pooled, non-blocking) the compaction and cycle-sampling kernels of the device builder run on
+    hvec<void*> d_build_blocks;               // scratch of those kernels: lives until structure_free_device (freeing a block waits for the device, i.e. for the fill)
     int32_t *d_k = nullptr;
     unsigned long long* d_tau = nullptr;      // m, indexed by edge id (defined for edges with cycles)
     int32_t* d_ktau = nullptr;                // m
@@ -96,6 +99,9 @@ void structure_free_device(desc_structure* s);
 // built from the edge list; the solver handle is then created on that device copy.  upload_rij: *d_rij = a device block holding prob->rij
 // (NULL and an error code if there is no device, no memory or the copy failed: the caller carries on without it); release_rij frees it.
 int upload_rij(const desc_problem* prob, int32_t device, double** d_rij);
+// incremented by the device structure builder once the edge list is on the device: desc_pgd_solve's helper thread starts pinning and copying
+// the rotations only then (hipHostRegister of 180 MB holds the runtime for ~10 ms: the builder's two small copies waited behind it)
+extern std::atomic<uint64_t> g_ind_upload_count;
 void release_rij(double* d_rij, int32_t device);
 int pgd_create_with_rij(const desc_problem* prob, const double* d_rij, const desc_structure* s, int32_t device, desc_pgd** out);
 // CEMP.m:44-65 on the device: nsample cycles per edge-with-cycles, with replacement.  The four arrays are

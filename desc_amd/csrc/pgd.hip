@@ -53,6 +53,7 @@
 #include <vector>
 
 #include "device_utils.h"
+#include "node_plan.h"
 
 namespace desc {
 
@@ -63,8 +64,6 @@ struct DevState {
     int32_t final_parity;  // which double buffer holds the final iterate
     int32_t last_tested;   // last iteration whose stop test (:243-256) has been applied: a download between
                            // iterations evaluates the objective early, the next sweep must not count it again
-    int32_t next_fin;      // sweep whose bookkeeping the next column-sum launch has to do (0: none).  Kept by the device so that a
-                           // captured hipGraph of several iterations can be replayed: its launches carry no iteration number
 };
 
 struct StepArgs {
@@ -104,7 +103,7 @@ __device__ __forceinline__ double apply_step(const StepArgs& a, double w, double
 // reaches the same active set as the reference's sort-and-scan (the first sorted i with
 // sum(w(i:end)-w(i)) < 1).
 template <int G>
-__device__ __forceinline__ double simplex_threshold(double ws, bool act0, int lane, bool single_pass) {
+__device__ __forceinline__ double simplex_threshold(double ws, bool act0, int lane) {
     bool act = act0;
     double T = 0.0;
     for (;;) {
@@ -114,7 +113,7 @@ __device__ __forceinline__ double simplex_threshold(double ws, bool act0, int la
         const bool keep = act && (ws > T);
         const bool changed = keep != act;
         act = keep;
-        if (!__any(changed) || single_pass) break;
+        if (!__any(changed)) break;
     }
     return T;
 }
@@ -179,7 +178,6 @@ struct SweepArgs {
     const DevState* state;
     StepArgs st;
     int32_t m_pos;
-    int32_t ablate;           // diagnostics only (env DESC_DEBUG_ABLATE); 0 in production
 };
 
 template <int G, int STEP>
@@ -208,24 +206,22 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a) {
         int ia = -1, ib = -1;
         if (act0) {
             const int ejk = a.e_jk[c], eki = a.e_ki[c];
-            if (!(a.ablate & 16)) { ia = a.ikj[c]; ib = a.jki[c]; }
+            ia = a.ikj[c]; ib = a.jki[c];
             w = a.w_old[c]; d = a.S0[c];
-            ssum = (a.ablate & 1) ? 1.0 + 1e-9 * (double)(ejk + eki) : a.S_old[ejk] + a.S_old[eki];
-            if (!(a.ablate & 2)) {
-                if (ia >= 0) wa = a.w_old[ia];
-                if (ib >= 0) wb = a.w_old[ib];
-            }
+            ssum = a.S_old[ejk] + a.S_old[eki];
+            if (ia >= 0) wa = a.w_old[ia];
+            if (ib >= 0) wb = a.w_old[ib];
         }
         obj_acc += w * ssum;                       // objective of the iterate being read (:233, one sweep late)
         // mirror-weight sums: one scalar per edge, applied to masked positions only (:189-190)
-        const double T1 = (a.ablate & 8) ? wa : group_sum<G>(wa), T2 = (a.ablate & 8) ? wb : group_sum<G>(wb);
+        const double T1 = group_sum<G>(wa), T2 = group_sum<G>(wb);
         double g = ssum + ((ia >= 0 ? T1 : 0.0) + (ib >= 0 ? T2 : 0.0)) * d;          // :193
         // tangent projection grad - (grad*nv')*nv, nv = ones/sqrt(cnt)  (:199-201)
         const double nv = act0 ? a.nv_tab[cnt] : 0.0;
-        const double dot = (a.ablate & 8) ? 0.0 : group_sum<G>(act0 ? g * nv : 0.0);
+        const double dot = group_sum<G>(act0 ? g * nv : 0.0);
         g = g - dot * nv;
         const double ws = act0 ? apply_step<STEP>(a.st, w, g, c) : 0.0;               // :207
-        const double T = simplex_threshold<G>(ws, act0, lane, a.ablate & 4);          // :215-223
+        const double T = simplex_threshold<G>(ws, act0, lane);          // :215-223
         const double wn = act0 ? fmax(ws - T, 0.0) : 0.0;                             // :224
         const double snew = group_sum<G>(wn * d);                                     // :229
         if (act0) a.w_new[c] = wn;
@@ -373,10 +369,6 @@ struct EdgeInfo {
 
 
 constexpr int SWEEP_THREADS = 512;
-constexpr int CHUNK_LDS = 960;             // entries of the LDS image of a chunk: one 16-byte vector of w per thread
-constexpr int CHUNK_CAP = CHUNK_LDS - 4;   // cycles per chunk: the image starts up to 3 entries before the chunk (16-byte alignment)
-constexpr int MAX_SEG_CYCLES = 256;         // longest segment the node layout takes (64 lanes x 4 cycles)
-constexpr int64_t GRAPH_MAX_CYCLES = 40000000;   // graph replays (enqueue_iterations) for graphs up to this many cycles: beyond it two launch gaps per iteration are noise
 
 // first / end cycle and first / end segment of a chunk, one 16-byte scalar load
 struct alignas(16) ChunkDesc { int32_t c0, c1, l0, l1; };
@@ -407,7 +399,6 @@ struct NodeSweepArgs {
     StepArgs st;
     int32_t nchunks;
     int32_t max_cnt;
-    int32_t ablate;
     uint32_t csr_bytes;        // bytes of the CSR-aligned arrays (S_old, S_new, Tfull of a one-rank run: 2m doubles) -- num_records of their buffer descriptors
     uint32_t t_bytes;          // bytes of Tfull (sharded runs: this rank's part of the reduce-scattered sums)
     uint32_t slice_bytes;      // bytes of s_slice (sharded runs)
@@ -513,11 +504,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
         for (int e = 0; e < E; ++e) {                // unconditional: idle lanes repeat the segment's first cycle
             const int idx = r16 + LPS * e;
             const uint32_t p = xb.pk[r.qb + (idx < r.cnt ? idx : 0)];
-            int si = r.rbi + (int)(p & 0x7FFFu), sj = r.rbj + (int)((p >> 16) & 0x7FFFu);
-            if (a.ablate & 1) { si = lane; sj = lane; }     // diagnostics: gathers that always hit L1
-            if (a.ablate & 2) { si = (int)(p & 511u); sj = (int)((p >> 16) & 511u); }   // divergent, but inside one 4 KiB window
-            if (a.ablate & 32) si = (int)(p & 511u);                                    // only the i-row gathers redirected
-            if (a.ablate & 16) sj = (int)((p >> 16) & 511u);                            // only the j-row gathers redirected
+            const int si = r.rbi + (int)(p & 0x7FFFu), sj = r.rbj + (int)((p >> 16) & 0x7FFFu);
             g.sjk[e] = a.S_old[sj]; g.ski[e] = a.S_old[si];
         }
         const int ta = a.xt ? r.seg : r.sa, tb = r.sb;
@@ -548,7 +535,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
         uint32_t okm = 0;
         double part = 0.0;
         // waves whose four lane groups own no segment of this chunk skip the arithmetic (wave-uniform)
-        if (__ballot(cnt > 0) != 0ull && !(a.ablate & 64)) {
+        if (__ballot(cnt > 0) != 0ull) {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int idx = r16 + LPS * e;
@@ -591,7 +578,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
                 for (int e = 0; e < E; ++e) keep |= (((act >> e) & 1u) && ws[e] * nad > s1v) ? 1u << e : 0u;
                 const bool changed = keep != act;
                 act = keep;
-                if (!__any(changed) || (a.ablate & 4)) break;
+                if (!__any(changed)) break;
             }
             const double T = s1v / (double)na;
             double sn = 0.0;
@@ -615,16 +602,14 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
         asm volatile("" : "+v"(o.g.T1), "+v"(o.g.T2), "+v"(o.g.So));
         asm volatile("" : "+v"(o.r.qb), "+v"(o.r.cnt), "+v"(o.r.rbi), "+v"(o.r.rbj), "+v"(o.r.sa), "+v"(o.r.sb), "+v"(o.r.seg));
         __builtin_amdgcn_sched_barrier(0);
-        if (!(a.ablate & 128)) {
 #pragma unroll
-            for (int e = 0; e < E; ++e)
-                if ((okm >> e) & 1u) a.w_new[(int64_t)a0 + r0.qb + r16 + LPS * e] = ws[e];
-            if (cnt > 0 && r16 == 0) {
-                chg_acc += fabs(part - c.g.So);                                                      // :232
-                // sharded runs: only the all-gather slice is written; k_unpack_S scatters S of every edge, this rank's included
-                if (a.s_slice) a.s_slice[r0.seg] = part;
-                else { a.S_new[r0.sa] = part; a.S_new[r0.sb] = part; }
-            }
+        for (int e = 0; e < E; ++e)
+            if ((okm >> e) & 1u) a.w_new[(int64_t)a0 + r0.qb + r16 + LPS * e] = ws[e];
+        if (cnt > 0 && r16 == 0) {
+            chg_acc += fabs(part - c.g.So);                                                      // :232
+            // sharded runs: only the all-gather slice is written; k_unpack_S scatters S of every edge, this rank's included
+            if (a.s_slice) a.s_slice[r0.seg] = part;
+            else { a.S_new[r0.sa] = part; a.S_new[r0.sb] = part; }
         }
         return o;
     };
@@ -686,9 +671,6 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
 //   the gathers of S({j,k}), T1, T2 (+ LDS reads)     1 iteration ahead (2 sets),
 // issued in the order gathers -> stream -> arithmetic -> stores: loads and stores retire through one in-order
 // counter on gfx950, so everything an iteration waits for was issued before the previous iteration's stores.
-#ifndef DESC_EXP                    // experiment switches of the current round (tools/build_exp.sh builds A/B libraries); 0 = production
-#define DESC_EXP 0
-#endif
 // BUFFER instructions (round 3).  The band sweep and the column sums address global memory as `descriptor in SGPRs + 32-bit byte offset per
 // lane` (buffer_load / buffer_store ... offen) instead of a 64-bit address per lane (global_load / global_store): half the address data per
 // instruction on the way to the address unit -- the busiest unit of the CU in this kernel (TA_BUSY 76 % at C4, section 5 of DESIGN.md) -- and no
@@ -698,9 +680,6 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
 // gathers (same file): nt 1873 us, sc1 / sc0 sc1 1253 us -- no.  Offsets are 32 bits: the descriptors of the per-cycle arrays are rebuilt per
 // piece with the piece's first cycle as base (any m_cycle), the CSR-aligned arrays (2m doubles) must stay below 4 GiB (setup_node: else no band sweep).
 // Out-of-range offsets read 0 and store nothing (num_records) instead of faulting.  DESC_BUF=0 builds the round-2 forms (A/B).
-#ifndef DESC_BUF
-#define DESC_BUF 1
-#endif
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 template <class T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const T* p, uint32_t bytes = 0xFFFFFFFFu) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);          // raw buffer (stride 0), 32-bit data format
@@ -729,13 +708,6 @@ __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t rs, uint32_
     u32x2_t v; __builtin_memcpy(&v, &d, 8);
     __builtin_amdgcn_raw_buffer_store_b64(v, rs, (int)off, 0, 0);
 }
-#ifndef DESC_BAND_ABLATE            // diagnostic builds only (tools/build_ablate.sh): 1 S({j,k}) from the LDS too, 2 no arithmetic,
-#define DESC_BAND_ABLATE 0          // 4 one threshold pass, 8 no stores, 16 no LDS gathers, 32 no T1/T2 loads, 64 S({j,k}) rows confined to 1 MiB,
-                                    // 128 / 256 non-temporal stream loads / stores, 2048 gathers issued where they are used (no prefetch)
-#endif
-constexpr int BAND_ROW_CAP = 19200;          // doubles of LDS for the band rows (150 KiB of the CU's 160 KiB)
-constexpr int MAX_TAIL_PIECES = 768;         // shared tail of the band sweep: at most this many queued pieces (their partials: SHARD_PARTS - grid)
-struct alignas(16) PieceDesc { int32_t row_lo, row_len, seg_lo, seg_hi; };   // CSR slots of the band, device-order segments
 
 struct BandSweepArgs {
     NodeSweepArgs n;
@@ -795,10 +767,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
     // Only the constant / piecewise-step shapes for segments of up to 64 cycles (LPS <= 16: what the BASELINE workloads run).  Measured on the others:
     // unsampled C5 (<64,4>) 8.05 -> 7.89 ms; the Adam instances (<32,2> at C2 / C4) no gain (2.19 -> 2.27 ms at C4, 0.251 -> 0.267 at C2) -- both
     // keep the round-2 map, and with it results bitwise equal to k_sweep_node's (which two tests assert).
-#ifndef DESC_PAIR
-#define DESC_PAIR 1
-#endif
-    constexpr bool PAIR = DESC_PAIR && DESC_BUF && (E % 2 == 0) && LPS <= 16 && !ADAM && !(DESC_BAND_ABLATE & (128 | 256));
+    constexpr bool PAIR = (E % 2 == 0) && LPS <= 16 && !ADAM;
     // (four adjacent cycles per lane -- the packed words as ONE 16-byte load -- measured on top: C4 1025-1054 vs 989-1034 us, C2 +3 %: not adopted)
     auto cidx = [&](int e) { return PAIR ? 2 * rr + (e & 1) + 2 * LPS * (e >> 1) : rr + LPS * e; };
     struct Str { uint32_t pk[E]; double w[E], d[E], am[EA], av[EA]; };     // am / av: HybridGradient.m_t / v_t (Adam only)
@@ -822,7 +791,6 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
         }
         obj_acc = 0.0; chg_acc = 0.0;
     };
-#if DESC_BUF
     // num_records = the arrays' real lengths: an offset past the end reads 0 / stores nothing instead of touching a neighbouring block
 #ifndef DESC_RSRC_UNBOUNDED          // A/B builds only: 1 = the round-3 descriptors (num_records 0xFFFFFFFF)
 #define DESC_RSRC_UNBOUNDED 0
@@ -831,7 +799,6 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
     const __amdgpu_buffer_rsrc_t rs_S = make_rsrc(a.S_old, nb_csr), rs_T = make_rsrc(a.Tfull, nb_t), rs_Sn = make_rsrc(a.S_new, nb_csr);      // CSR-aligned: 2m doubles < 4 GiB
     const __amdgpu_buffer_rsrc_t rs_sl = XT ? make_rsrc(a.s_slice, nb_sl) : rs_Sn;                        // sharded runs: this rank's all-gather slice
     const __amdgpu_buffer_rsrc_t rs_cum = make_rsrc(a.cum, (a.seg_count + 1u) * 4u), rs_ei = make_rsrc(a.einfo, a.seg_count * 16u);          // per-lane records (VREC shapes only; C3 -1 %)
-#endif
     int pc = p0, ticket = -1;
     for (;;) {
         if (ticket < 0 && pc >= p1) {                      // own list done: its partials, then the shared tail
@@ -852,7 +819,6 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
         const int nit = (pd.seg_hi - pd.seg_lo + NW * SPW - 1) / (NW * SPW);
         // the piece's cycles are one contiguous range of the per-cycle arrays: Rec::c0 counts from its start
         const int c_lo = uniform_load(a.cum, pd.seg_lo);
-#if DESC_BUF
         const uint32_t c_len = (uint32_t)(uniform_load(a.cum, pd.seg_hi) - c_lo) + 8u;           // + the 16-byte tail the arrays are padded by
         const __amdgpu_buffer_rsrc_t rs_pk = make_rsrc(a.pk + c_lo, c_len * 4u), rs_w = make_rsrc(a.w_old + c_lo, c_len * 8u),
                                      rs_d = make_rsrc(a.S0 + c_lo, c_len * 8u), rs_wn = make_rsrc(a.w_new + c_lo, c_len * 8u);
@@ -861,23 +827,18 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
             rs_am = make_rsrc(a.st.adam_m + c_lo, c_len * 8u); rs_av = make_rsrc(a.st.adam_v + c_lo, c_len * 8u);
             rs_amo = make_rsrc(a.st.adam_m_out + c_lo, c_len * 8u); rs_avo = make_rsrc(a.st.adam_v_out + c_lo, c_len * 8u);
         }
-#endif
 
         auto load_raw = [&](int it) -> RecRaw {            // past the end: the piece's last segment, cnt = 0
             RecRaw q;
             q.t0 = pd.seg_lo + (it * NW + wv) * SPW;
             if constexpr (VREC) {
                 const int t = min(q.t0 + grp, pd.seg_hi - 1);
-#if DESC_BUF
                 {
                     const u32x2_t cc = __builtin_amdgcn_raw_buffer_load_b64(rs_cum, t * 4, 0, 0);
                     const u32x4_t ee = __builtin_amdgcn_raw_buffer_load_b128(rs_ei, t * 16, 0, 0);
                     q.c0[0] = (int)cc.x; q.c1[0] = (int)cc.y;
                     q.ei[0].rb_i = (int)ee.x; q.ei[0].rb_j = (int)ee.y; q.ei[0].slot_a = (int)ee.z; q.ei[0].slot_b = (int)ee.w;
                 }
-#else
-                q.c0[0] = a.cum[t]; q.c1[0] = a.cum[t + 1]; q.ei[0] = a.einfo[t];
-#endif
                 if constexpr (XT) { const int2 x = a.xt[t]; q.xa[0] = x.x; q.xb[0] = x.y; }
                 return q;
             }
@@ -909,7 +870,6 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
         };
         auto load_stream = [&](const Rec& r) -> Str {      // unconditional: idle lanes repeat a valid cycle of the segment
             Str x;
-#if DESC_BUF
             if constexpr (PAIR) {
 #pragma unroll
                 for (int h = 0; h < E / 2; ++h) {
@@ -926,25 +886,11 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
                 }
                 return x;
             }
-#endif
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int cr = r.c0 + min(rr + LPS * e, max(r.cnt, 1) - 1);
-                const int64_t c = (int64_t)c_lo + cr;
-                if (DESC_BAND_ABLATE & 128) {       // streamed once: non-temporal, so that the j-rows of S keep their place in the L2
-                    x.pk[e] = __builtin_nontemporal_load(&a.pk[c]); x.w[e] = __builtin_nontemporal_load(&a.w_old[c]); x.d[e] = __builtin_nontemporal_load(&a.S0[c]);
-                } else {
-#if DESC_BUF
-                    x.pk[e] = buf_load_u32(rs_pk, (uint32_t)cr * 4u); x.w[e] = buf_load_f64(rs_w, (uint32_t)cr * 8u); x.d[e] = buf_load_f64(rs_d, (uint32_t)cr * 8u);
-#else
-                    x.pk[e] = a.pk[c]; x.w[e] = a.w_old[c]; x.d[e] = a.S0[c];
-#endif
-                }
-#if DESC_BUF
+                x.pk[e] = buf_load_u32(rs_pk, (uint32_t)cr * 4u); x.w[e] = buf_load_f64(rs_w, (uint32_t)cr * 8u); x.d[e] = buf_load_f64(rs_d, (uint32_t)cr * 8u);
                 if (ADAM) { x.am[e % EA] = buf_load_f64(rs_am, (uint32_t)cr * 8u); x.av[e % EA] = buf_load_f64(rs_av, (uint32_t)cr * 8u); }
-#else
-                if (ADAM) { x.am[e % EA] = a.st.adam_m[c]; x.av[e % EA] = a.st.adam_v[c]; }
-#endif
             }
             return x;
         };
@@ -953,46 +899,26 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const uint32_t p = x.pk[e];
-#if DESC_BUF
-                g.sj[e] = (DESC_BAND_ABLATE & 1) ? s_rows[((p >> 16) & 0x7FFFu) + (lane & 7)]
-                        : buf_load_f64(rs_S, (uint32_t)(((DESC_BAND_ABLATE & 64) ? (r.rbj & 0x1FFFF) : r.rbj) + (int)((p >> 16) & 0x7FFFu)) * 8u);   // 64: rows confined to 1 MiB (L2 hits)
-#else
-                g.sj[e] = (DESC_BAND_ABLATE & 1) ? s_rows[((p >> 16) & 0x7FFFu) + (lane & 7)]
-                        : a.S_old[((DESC_BAND_ABLATE & 64) ? (r.rbj & 0x1FFFF) : r.rbj) + (int)((p >> 16) & 0x7FFFu)];   // 64: rows confined to 1 MiB (L2 hits)
-#endif
-                g.si[e] = (DESC_BAND_ABLATE & 16) ? 0.5 : s_rows[r.rbi + (int)(p & 0x7FFFu)];
+                g.sj[e] = buf_load_f64(rs_S, (uint32_t)(r.rbj + (int)((p >> 16) & 0x7FFFu)) * 8u);      // S({j,k}): a gather inside row j (L1 / L2)
+                g.si[e] = s_rows[r.rbi + (int)(p & 0x7FFFu)];                                              // S({k,i}): the band's rows in the LDS
             }
             const int ta = XT ? r.seg : r.sa, tb = r.sb;
-#if DESC_BUF             // T1 and T2 in ONE load instruction (even lanes T1, odd lanes T2), exchanged inside the quads where they are used (compute);
                         // this and the single S store: C4 1059.5 -> 1045.8 / 1083 -> 1059 us, C2 within noise (profiles/r03_buffer_instructions.txt)
-            g.T1 = (DESC_BAND_ABLATE & 32) ? 0.25 : buf_load_f64(rs_T, (uint32_t)((lane & 1) ? tb : ta) * 8u);
+            g.T1 = buf_load_f64(rs_T, (uint32_t)((lane & 1) ? tb : ta) * 8u);
             g.T2 = 0.0;
-#else
-            g.T1 = (DESC_BAND_ABLATE & 32) ? 0.25 : fx_to_double(a.Tfull[ta], a.fx_inv);                      // column j of node i = sum(wijk(IKJ(mask)))  (:189)
-            g.T2 = (DESC_BAND_ABLATE & 32) ? 0.25 : fx_to_double(a.Tfull[tb], a.fx_inv);                      // column i of node j = sum(wijk(JKI(mask)))  (:190)
-#endif
-            g.So = (DESC_BAND_ABLATE & 16) ? 0.5 : s_rows[r.sa - pd.row_lo];
+            g.So = s_rows[r.sa - pd.row_lo];
             return g;
         };
         // arithmetic + stores of one segment group (DESC_PGD.m:193-233), everything in registers
         auto compute = [&](const Rec& r, const Str& x, const Gat& g0) {
             const int cnt = r.cnt;
-#if DESC_BUF
             Gat g = g0;
-            const double tconv = (DESC_BAND_ABLATE & 32) ? g0.T1 : fx_to_double(g0.T1, a.fx_inv);       // this lane's load: T1 (even lanes) or T2 (odd lanes)
+            const double tconv = fx_to_double(g0.T1, a.fx_inv);       // this lane's load: T1 (even lanes) or T2 (odd lanes)
             g.T1 = dpp_mov_f64<0xA0>(tconv);        // quad_perm:[0,0,2,2]: the even lane's value = T1
             g.T2 = dpp_mov_f64<0xF5>(tconv);        // quad_perm:[1,1,3,3]: the odd lane's value = T2
-#else
-            const Gat& g = g0;
-#endif
             double ws[E], mo[EA], vo[EA];
             uint32_t okm = 0;
             double part = 0.0;
-            if (DESC_BAND_ABLATE & 2) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) { const bool ok = cidx(e) < cnt; if (ok) okm |= 1u << e; ws[e] = x.w[e] + g.sj[e] + g.si[e] + x.d[e] + (double)(x.pk[e] & 1u) + g.T1 + g.T2; }
-                part = ws[0];
-            } else
             if (__ballot(cnt > 0) != 0ull) {               // wave-uniform; no memory operation inside
                 const double nv = cnt > 0 ? s_nv[cnt] : 0.0;
 #pragma unroll
@@ -1043,7 +969,7 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
                     for (int e = 0; e < E; ++e) keep |= (((act >> e) & 1u) && ws[e] * nad > s1v) ? 1u << e : 0u;
                     const bool changed = keep != act;
                     act = keep;
-                    if (!__any(changed) || (DESC_BAND_ABLATE & 4)) break;
+                    if (!__any(changed)) break;
                 }
                 const double T = s1v / (double)na;
                 double sn = 0.0;
@@ -1055,8 +981,6 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
                 }
                 part = group_sum<LPS>(sn);                                                               // :229
             }
-            if (DESC_BAND_ABLATE & 8) { obj_acc += ws[0] + ws[E - 1] + part; return; }
-#if DESC_BUF
             if constexpr (PAIR) {                      // 16-byte stores of the pairs; the last pair of an odd segment: its first cycle alone
 #pragma unroll
                 for (int h = 0; h < E / 2; ++h) {
@@ -1071,41 +995,16 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
                     }
                 }
             } else
-#endif
 #pragma unroll
             for (int e = 0; e < E; ++e)
                 if ((okm >> e) & 1u) {
-                    const int64_t c = (int64_t)c_lo + r.c0 + rr + LPS * e;
-                    if (DESC_BAND_ABLATE & 256) __builtin_nontemporal_store(ws[e], &a.w_new[c]);
-                    else {
-#if DESC_BUF
-                        buf_store_f64(rs_wn, (uint32_t)(r.c0 + rr + LPS * e) * 8u, ws[e]);
-#else
-                        a.w_new[c] = ws[e];
-#endif
-                    }
-#if DESC_BUF
+                    buf_store_f64(rs_wn, (uint32_t)(r.c0 + rr + LPS * e) * 8u, ws[e]);
                     if (ADAM) { buf_store_f64(rs_amo, (uint32_t)(r.c0 + rr + LPS * e) * 8u, mo[e % EA]); buf_store_f64(rs_avo, (uint32_t)(r.c0 + rr + LPS * e) * 8u, vo[e % EA]); }
-#else
-                    if (ADAM) { a.st.adam_m_out[c] = mo[e % EA]; a.st.adam_v_out[c] = vo[e % EA]; }
-#endif
                 }
-#if DESC_BUF             // both slots of S in ONE store instruction (lane 0 of the group: slot (i,j), lane 1: slot (j,i)); `part` is the same in every lane
             if (!XT && cnt > 0 && rr < 2) buf_store_f64(rs_Sn, (uint32_t)(rr == 0 ? r.sa : r.sb) * 8u, part);
-#endif
             if (cnt > 0 && rr == 0) {
                 chg_acc += fabs(part - g.So);                                                            // :232
-                if constexpr (XT) {                                           // sharded: k_unpack_S copies it into the CSR-aligned replica
-#if DESC_BUF
-                    buf_store_f64(rs_sl, (uint32_t)r.seg * 8u, part);
-#else
-                    a.s_slice[r.seg] = part;
-#endif
-                } else {
-#if !DESC_BUF
-                    a.S_new[r.sa] = part; a.S_new[r.sb] = part;
-#endif
-                }
+                if constexpr (XT) buf_store_f64(rs_sl, (uint32_t)r.seg * 8u, part);       // sharded: k_unpack_S copies it into the CSR-aligned replica
             }
         };
 
@@ -1120,7 +1019,6 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
         {
             // up to 19 loads in flight per thread: one batch for 1024 threads, two for 512 (38 at once cost the 64 x 4 instance 3.5 %)
             constexpr int RL = (BAND_ROW_CAP + 1023) / 1024;
-#if DESC_BUF && DESC_PAIR
             // 16 bytes per lane (half the address-unit cycles per byte, see PAIR): thread t takes the doubles 2 t, 2 t + 1 of every batch of 2 NT
             constexpr int RL2 = (RL + 1) / 2;
             for (int base = 0; base < pd.row_len; base += 2 * RL2 * NT) {
@@ -1135,32 +1033,16 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
                     else if (t0 < pd.row_len) s_rows[t0] = pd.row_len >= 2 ? v1[u] : v0[u];      // the row's last double: the clamped load ended on it
                 }
             }
-#else
-            for (int base = 0; base < pd.row_len; base += RL * NT) {
-                double v[RL];
-#pragma unroll
-                for (int u = 0; u < RL; ++u) {
-#if DESC_BUF
-                    v[u] = buf_load_f64(rs_S, (uint32_t)(pd.row_lo + min(base + u * NT + tid, pd.row_len - 1)) * 8u);
-#else
-                    v[u] = a.S_old[pd.row_lo + min(base + u * NT + tid, pd.row_len - 1)];
-#endif
-                }
-#pragma unroll
-                for (int u = 0; u < RL; ++u) if (base + u * NT + tid < pd.row_len) s_rows[base + u * NT + tid] = v[u];
-            }
-#endif
         }
         __syncthreads();
         G0 = issue_gathers(R0, S0);
         // one iteration: Ra/Sa/Ga = group g (computed), Rb/Sb = g+1 (gathers issued into Gb), Rd/Sd <- g+3
         auto step = [&](int g, const Rec& Ra, const Str& Sa, const Gat& Ga, const Rec& Rb, const Str& Sb, Gat& Gb, Rec& Rd, Str& Sd) {
             const RecRaw qn = load_raw(g + 4);
-            if (!(DESC_BAND_ABLATE & 2048)) Gb = issue_gathers(Rb, Sb);
+            Gb = issue_gathers(Rb, Sb);
             Rd = land(Q);
             Sd = load_stream(Rd);
-            if (DESC_BAND_ABLATE & 2048) { const Gat gn = issue_gathers(Ra, Sa); compute(Ra, Sa, gn); }    // 2048: gathers not prefetched at all (latency probe)
-            else compute(Ra, Sa, Ga);
+            compute(Ra, Sa, Ga);
             Q = qn;
         };
         for (int g = 0; g < nit; g += 4) {                 // the tail iterations past nit compute nothing (cnt = 0)
@@ -1185,22 +1067,10 @@ struct FinArgs {
     const double* partials; DevState* st; double* obj_trace; double* avg_trace;
     int64_t m; double stop_tol; int32_t nparts, t, patience, last_only;      // t == 0: nothing to do
     int64_t rank_stride; int32_t nranks;     // sharded runs: the partials of rank r start at partials + r * rank_stride (0 / 0: one rank)
-    int32_t t_after;                         // > 0: DevState.next_fin after this call (the sweep that follows this column-sum launch); < 0: 0 (done, nothing pending)
-    int32_t dev_t;                           // 1: t comes from DevState.next_fin, which then advances by one (hipGraph replays)
 };
-__device__ __forceinline__ void finalize_core(const FinArgs f);
-__device__ __forceinline__ void finalize_wave(FinArgs f) {
+__device__ __forceinline__ void finalize_wave(const FinArgs f) {
     DevState* st = f.st;
-    if (f.dev_t) f.t = st->next_fin;                       // every lane reads the same value; written below by lane 0 only
-    if (f.t > 0) finalize_core(f);
-    if ((threadIdx.x & 63) == 0) {
-        if (f.dev_t) st->next_fin = f.t + 1;
-        else if (f.t_after != 0) st->next_fin = max(f.t_after, 0);
-    }
-}
-__device__ __forceinline__ void finalize_core(const FinArgs f) {
-    DevState* st = f.st;
-    if (st->stop) return;
+    if (f.t <= 0 || st->stop) return;          // t == 0: no sweep to book-keep
     const int lane = threadIdx.x & 63;
     // every lane adds its strided share in index order, then the fixed DPP butterfly
     double o = 0.0, ch = 0.0;
@@ -1493,6 +1363,22 @@ __global__ __launch_bounds__(256) void k_seg_tables(const int32_t* order, const 
         const int32_t l = order[q], e = nat_pos_edge[l];
         src_start[q] = nat_cum[l];
         pos_edge2[q] = e; devpos[e] = (int32_t)q;
+    }
+}
+// Round 4: a one-rank handle computes the packed words, S0_long and the in-segment class order in the structure's NATURAL order as soon as the
+// sampled cycles exist -- while the host is still planning the band-major order (8-9 ms at C4) -- and moves whole segments to their device
+// positions afterwards: segment q of the device order is natural segment order[q].  One wave per segment; ~26 bytes per cycle, bandwidth-bound.
+__global__ __launch_bounds__(256) void k_permute_segments(const int32_t* order, const int32_t* nat_cum, const int32_t* cum, const uint32_t* pk_nat, const double* S0_nat,
+                                                          const uint8_t* perm_nat, const uint32_t* counts_nat, uint32_t* pk, double* S0, uint8_t* seg_perm, uint32_t* counts,
+                                                          int64_t m_pos) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t q = wid; q < m_pos; q += nw) {
+        const int32_t l = order[q];
+        const int64_t src = nat_cum[l], dst = cum[q];
+        const int cnt = cum[q + 1] - cum[q];
+        for (int t = lane; t < cnt; t += 64) { pk[dst + t] = pk_nat[src + t]; S0[dst + t] = S0_nat[src + t]; seg_perm[dst + t] = perm_nat[src + t]; }
+        if (lane == 0) counts[q] = counts_nat[l];
     }
 }
 // per-edge slots of the CSR-aligned arrays, on the device (device-built structures): eslot[e] = this
@@ -1870,16 +1756,8 @@ struct desc_pgd {
     int t_done = 0;             // sweeps enqueued since reset
     int t_plugin = 0;           // plugin counter (PiecewiseStepSize.t / HybridGradient.t)
     double ms_upload = 0, ms_cycle_d = 0, ms_pgd = 0;
-    int ablate = 0;             // diagnostics (DESC_DEBUG_ABLATE)
     std::string kname;
     std::string last_sweep;     // the sweep instance launched last, with its template arguments (desc_debug_last_sweep: tests assert which kernel ran)
-    // GRAPH_ITERS iterations (column sums + sweep each) captured once per reset as a hipGraph and replayed: the launches of a
-    // replay carry no iteration number (DevState.next_fin), so one executable graph serves the whole run.  Constant step only.
-    hipGraphExec_t graph_exec = nullptr;
-    hipGraph_t graph = nullptr;
-    bool graph_failed = false;
-    int graph_launches = 0;
-    struct GraphSig { double lr, stop_tol; int patience, grid; const void *partials, *obj, *avg; } graph_sig{};     // what the captured launches bake
 };
 
 namespace {
@@ -1925,8 +1803,6 @@ void free_all(desc_pgd* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();                              // once for all blocks and both streams (dev_free would wait per block)
     for (void* q : h->allocs) dev_free_idle(q);
-    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-    if (h->graph) (void)hipGraphDestroy(h->graph);
     for (hipEvent_t e : {h->ev_col, h->ev_rs, h->ev_sw, h->ev_ag}) if (e) (void)hipEventDestroy(e);
     stream_release(h->comm_stream);
     if (!h->borrowed_stream) stream_release(h->stream);
@@ -1937,19 +1813,6 @@ template <class T>
 int upload(desc_pgd* h, T* dst, const T* src, size_t count) {
     if (count) DESC_HIP(hipMemcpyAsync(dst, src, sizeof(T) * count, hipMemcpyHostToDevice, h->stream));
     return DESC_OK;
-}
-
-int env_int(const char* name, int dflt) {
-    const char* v = std::getenv(name);
-    return v ? std::atoi(v) : dflt;
-}
-
-template <class F>
-void host_parallel(int64_t count, F&& body, int64_t grain = 65536) {
-    unsigned hw = std::thread::hardware_concurrency();
-    int nt = (int)std::min<int64_t>(std::max(1u, std::min(hw, 16u)), std::max<int64_t>(1, count / grain));
-    if (nt <= 1) { body(0, count); return; }
-    run_threads(nt, [&](int t) { body(count * t / nt, count * (t + 1) / nt); });
 }
 
 StepArgs make_step(desc_pgd* h, bool* adam, int rd, int wr) {
@@ -2081,12 +1944,11 @@ int sweep_parts(const desc_pgd* h, bool adam) { return h->variant == VARIANT_NOD
 size_t parts_cap(const desc_pgd* h) { return (size_t)std::max(std::max(h->grid, h->obj_grid), h->band_grid + h->band_ntail); }
 double* obj_partials(const desc_pgd* h) { return h->d_partials + 2 * parts_cap(h); }
 FinArgs fin_args(const desc_pgd* h, const double* partials, int nparts, int t, int last_only) {
-    return FinArgs{partials, h->d_state, h->d_obj, h->d_avg, h->m, h->p.stop_tol, nparts, t, h->p.patience, last_only, 0, 1, 0, 0};
+    return FinArgs{partials, h->d_state, h->d_obj, h->d_avg, h->m, h->p.stop_tol, nparts, t, h->p.patience, last_only, 0, 1};
 }
 // the bookkeeping of the last enqueued sweep, if it is still waiting for a column-sum launch to ride on
 void flush_finalize(desc_pgd* h) {
     if (!h->pending_fin) return;
-    // (DevState.next_fin stays: a replayed column-sum launch books the same sweep again from the same partials -- idempotent)
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, h->stream, fin_args(h, h->d_partials, h->pending_parts, h->pending_fin, 0));
     h->pending_fin = 0;
 }
@@ -2109,21 +1971,19 @@ void launch_colsum(desc_pgd* h, hipStream_t st, const double* w, double* T, cons
 }
 
 // enqueue sweep number t (1-based) and its finalize; ev0/ev1 bracket the kernels of the sweep proper
-int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, bool captured = false) {
+int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     const int rd = (t - 1) & 1, wr = t & 1;
     bool adam = false;
     const StepArgs st = make_step(h, &adam, rd, wr);
     if (ev0) (void)hipEventRecord(ev0, h->stream);
     if (h->variant == VARIANT_NODE) {
-        FinArgs fin = fin_args(h, h->d_partials, captured ? sweep_parts(h, adam) : h->pending_parts, h->pending_fin, 0);
-        if (captured) { fin.t = 0; fin.dev_t = 1; }          // which sweep to book-keep: DevState.next_fin, at replay time
-        else fin.t_after = t;                                // the next column-sum launch (direct or replayed) book-keeps sweep t
+        const FinArgs fin = fin_args(h, h->d_partials, h->pending_parts, h->pending_fin, 0);      // the previous sweep's bookkeeping rides on this launch
         launch_colsum(h, h->stream, h->d_w[rd], h->d_T, nullptr, fin);
         h->pending_fin = 0;
         NodeSweepArgs a{};
         a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
         a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->d_T; a.xt = nullptr; a.nv_tab = h->d_nv; a.partials = h->d_partials;
-        a.state = h->d_state; a.st = st; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks; a.max_cnt = h->max_cnt; a.ablate = h->ablate;
+        a.state = h->d_state; a.st = st; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks; a.max_cnt = h->max_cnt;
         a.csr_bytes = (uint32_t)(16 * h->m); a.t_bytes = a.csr_bytes; a.slice_bytes = 0; a.seg_count = (uint32_t)h->m_pos; a.fx_inv = std::ldexp(1.0, -h->colsum_fx_bits);
         launch_sweep_node_layout(h, a, adam);
     } else {
@@ -2131,7 +1991,7 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
         a.cum = h->d_cum; a.pos_edge = h->d_pos_edge; a.e_jk = h->d_ejk; a.e_ki = h->d_eki; a.ikj = h->d_ikj; a.jki = h->d_jki;
         a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr]; a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr];
         a.nv_tab = h->d_nv; a.partials = h->d_partials; a.state = h->d_state; a.st = st;
-        a.m_pos = (int32_t)h->m_pos; a.ablate = h->ablate;
+        a.m_pos = (int32_t)h->m_pos;
         if (adam) launch_gather<DESC_STEP_HYBRID>(h, a); else launch_gather<DESC_STEP_CONSTANT>(h, a);
     }
     if (ev1) (void)hipEventRecord(ev1, h->stream);
@@ -2141,62 +2001,11 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
     return DESC_OK;
 }
 
-// GRAPH_ITERS iterations as one executable hipGraph (captured from the launch stream), or nullptr when the run does not qualify:
-// the launches inside must not depend on the iteration number, i.e. the constant step (ConstantStepSize.m), the node layout, one rank.
-constexpr int GRAPH_ITERS = 10;
-bool graph_eligible(const desc_pgd* h) {
-    // Off by default: measured on MI355X / ROCm 7.2 (profiles/r03_graph_ab.txt) the replays change nothing -- C1 16.5 vs 16.6 us per
-    // iteration, C2 0.150 vs 0.152 ms: the two launches of an iteration were not what a small graph waits for (each kernel is a chain
-    // of 4-6 dependent memory round trips).  DESC_GRAPH=1 enables it up to GRAPH_MAX_CYCLES, 2 for every size (tests).
-    const int mode = env_int("DESC_GRAPH", 0);
-    return mode != 0 && !h->graph_failed && h->variant == VARIANT_NODE && h->world == 1 && h->p.step_kind == DESC_STEP_CONSTANT && h->ablate == 0 &&
-           (mode == 2 || h->m_cycle <= GRAPH_MAX_CYCLES);
-}
-void drop_graph(desc_pgd* h) {
-    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-    if (h->graph) (void)hipGraphDestroy(h->graph);
-    h->graph_exec = nullptr; h->graph = nullptr;
-}
-hipGraphExec_t iteration_graph(desc_pgd* h) {
-    const desc_pgd::GraphSig sig{h->p.lr, h->p.stop_tol, h->p.patience, sweep_parts(h, false), h->d_partials, h->d_obj, h->d_avg};
-    if (h->graph_exec && std::memcmp(&sig, &h->graph_sig, sizeof sig) == 0) return h->graph_exec;
-    drop_graph(h);
-    std::memset(&h->graph_sig, 0, sizeof h->graph_sig);
-    h->graph_sig = sig;
-    const int t_plugin = h->t_plugin, pf = h->pending_fin, pp = h->pending_parts;
-    if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); h->graph_failed = true; return nullptr; }
-    int rc = DESC_OK;
-    for (int k = 1; k <= GRAPH_ITERS && rc == DESC_OK; ++k) rc = enqueue_sweep(h, k, nullptr, nullptr, true);       // k: parity only (first sweep reads buffer 0)
-    hipGraph_t g = nullptr;
-    const hipError_t e = hipStreamEndCapture(h->stream, &g);
-    h->t_plugin = t_plugin; h->pending_fin = pf; h->pending_parts = pp;                                              // nothing was enqueued
-    if (rc != DESC_OK || e != hipSuccess || !g || hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        if (g) (void)hipGraphDestroy(g);
-        h->graph_exec = nullptr; h->graph_failed = true;
-        return nullptr;
-    }
-    h->graph = g;
-    return h->graph_exec;
-}
-// the next n sweeps: replays of the captured graph where a whole block of GRAPH_ITERS fits and the next sweep reads buffer 0,
-// direct launches otherwise
+// the next n sweeps.  (hipGraph replays of 10 captured iterations were built in round 3 and measured no gain -- C1 16.5 vs 16.6 us per
+// iteration, C2 0.150 vs 0.152 ms, profiles/r03_graph_ab.txt: each kernel is a chain of dependent memory round trips, the launches were not
+// what an iteration waits for -- and removed in round 4.)
 int enqueue_iterations(desc_pgd* h, int n) {
-    while (n > 0) {
-        const int t = h->t_done + 1;
-        if (n >= GRAPH_ITERS && ((t - 1) & 1) == 0 && graph_eligible(h)) {
-            hipGraphExec_t ge = iteration_graph(h);
-            if (ge) {
-                DESC_HIP(hipGraphLaunch(ge, h->stream));
-                h->t_done += GRAPH_ITERS; h->t_plugin += GRAPH_ITERS; n -= GRAPH_ITERS;
-                h->pending_fin = h->t_done; h->pending_parts = sweep_parts(h, false);
-                ++h->graph_launches;
-                continue;
-            }
-        }
-        const int rc = enqueue_sweep(h, ++h->t_done); if (rc) return rc;
-        --n;
-    }
+    for (; n > 0; --n) { const int rc = enqueue_sweep(h, ++h->t_done); if (rc) return rc; }
     return DESC_OK;
 }
 
@@ -2269,360 +2078,6 @@ int setup_gather(desc_pgd* h, const desc_problem* prob, const desc_structure* s,
     return DESC_OK;
 }
 
-// ------------------------------------------------------------------ NODE setup
-// Host-side plan of the node layout: band-major order of the edges with cycles, chunking,
-// and the chunk ranges of the `world` ranks (contiguous, equal numbers of chunks).
-struct NodePlan {
-    int band = 0;                     // nodes per band (fixed-size bands), 0: LDS-sized bands
-    hvec<int32_t> band_lo;     // nbands+1: first node of every band
-    hvec<int64_t> bstart;      // nbands+1: first device position (= position in pos_edge) of every band
-    hvec<int32_t> rowptr;      // n+1: CSR row starts (degrees prefix-summed)
-    hvec<int32_t> order;       // device position -> index into s->pos_edge
-    hvec<int32_t> cum2;        // m_pos+1, device order, global cycle numbering
-    hvec<int32_t> chunk_seg;   // nchunks+1
-    hvec<int64_t> rank_chunk;  // world+1
-    hvec<int32_t> rank_node;   // world+1: rank r owns the nodes [rank_node[r], rank_node[r+1]) -- whole bands -- and the segments whose smaller endpoint they are
-};
-
-// row_cap > 0: bands = maximal runs of consecutive nodes whose CSR rows hold <= row_cap entries together (the band
-// sweep keeps them in the LDS); row_cap == 0: bands of a fixed number of nodes sized for the L2 (k_sweep_node).
-int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_deg, int world, int max_seg, int row_cap, NodePlan& P) {
-    const int64_t mp = s->m_pos, n = prob->n, m = prob->m;
-    const bool timing = env_int("DESC_DEBUG_TIMING", 0) > 1;
-    auto t_lap = std::chrono::steady_clock::now();
-    auto lap = [&](const char* what) {
-        if (!timing) return;
-        auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[desc_amd] node plan %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_lap).count());
-        t_lap = now;
-    };
-    const int32_t* ii = prob->ind_i; const int32_t* jj = prob->ind_j; const int32_t* pe = s->pos_edge.data();
-    if ((int64_t)s->rowptr_host.size() == n + 1) P.rowptr = s->rowptr_host;      // the device builder already made them
-    else {
-        P.rowptr.assign((size_t)n + 1, 0);
-        for (int64_t e = 0; e < m; ++e) { P.rowptr[ii[e] + 1]++; P.rowptr[jj[e] + 1]++; }
-        for (int64_t v = 0; v < n; ++v) P.rowptr[v + 1] += P.rowptr[v];
-    }
-    P.band_lo.clear();
-    if (row_cap > 0) {
-        P.band = 0;
-        for (int64_t v = 0; v < n;) {
-            P.band_lo.push_back((int32_t)v);
-            int64_t e = v + 1;                               // a band holds at least one node (max_deg <= row_cap is the caller's check)
-            while (e < n && P.rowptr[e + 1] - P.rowptr[v] <= row_cap) ++e;
-            v = e;
-        }
-    } else {
-        int band = env_int("DESC_DEBUG_BAND", 0);
-        if (band <= 0)   // rows of one band should stay in an XCD's 4 MiB L2 next to the streamed arrays: ~1 MiB
-            band = (int)std::max<int64_t>(8, std::min<int64_t>(512, (1 << 20) / (8 * (int64_t)std::max(1, max_deg))));
-        P.band = band;
-        for (int64_t v = 0; v < n; v += band) P.band_lo.push_back((int32_t)v);
-    }
-    P.band_lo.push_back((int32_t)n);
-    const int64_t nb = (int64_t)P.band_lo.size() - 1;
-    // order by (band(i), j, i): Ind -- and with it pos_edge -- is sorted by (i, j), so a band is a
-    // contiguous range of pos_edge and one stable counting sort by j per band (bands in parallel)
-    // gives the order in O(m_pos + bands * n)
-    P.order.resize((size_t)mp);
-    P.cum2.assign((size_t)mp + 1, 0);
-    P.bstart.assign((size_t)nb + 1, mp);       // first position of every band in pos_edge
-    {
-        int64_t l = 0;                         // pos_edge is sorted by (i, j): the first edge with i >= band_lo[b], by binary search from the previous band's start
-        for (int64_t b = 0; b <= nb; ++b) {
-            const int32_t want = P.band_lo[b];
-            l = std::partition_point(pe + l, pe + mp, [&](int32_t e) { return ii[e] < want; }) - pe;
-            P.bstart[b] = l;
-        }
-    }
-    lap("bands + starts");
-    host_parallel(nb, [&](int64_t b0, int64_t b1) {
-        hvec<int32_t> cnt((size_t)n + 1);
-        for (int64_t b = b0; b < b1; ++b) {
-            const int64_t lo = P.bstart[b], hi = P.bstart[b + 1];
-            if (lo == hi) continue;
-            std::fill(cnt.begin(), cnt.end(), 0);
-            for (int64_t l = lo; l < hi; ++l) cnt[jj[pe[l]] + 1]++;
-            for (int64_t v = 0; v < n; ++v) cnt[v + 1] += cnt[v];
-            for (int64_t l = lo; l < hi; ++l) {
-                const int64_t q = lo + cnt[jj[pe[l]]]++;
-                P.order[q] = (int32_t)l;
-                P.cum2[q + 1] = (int32_t)(s->cum_ind[l + 1] - s->cum_ind[l]);        // cycle count of the segment at device position q: summed below
-            }
-        }
-    }, mp >= (1 << 18) ? 1 : nb + 1);          // small problems: one thread
-    lap("per-band sorts");
-    for (int64_t q = 0; q < mp; ++q) P.cum2[q + 1] += P.cum2[q];
-    lap("prefix sums");
-    // Several ranks: a rank owns whole bands (its exchange layout is indexed by node ranges, k_xpos); the cuts go to the band boundaries
-    // that split the cycles most evenly (a band is ~0.4 % of the work at C4), and chunks do not straddle them.
-    hvec<int64_t> cut_seg;                                   // device position of the first segment of every rank, + mp
-    P.rank_node.assign((size_t)world + 1, (int32_t)n);
-    P.rank_node[0] = 0;
-    cut_seg.assign((size_t)world + 1, mp);
-    cut_seg[0] = 0;
-    if (world > 1) {
-        const int64_t total = P.cum2[mp];
-        int64_t b = 0;
-        for (int r = 1; r < world; ++r) {
-            const int64_t want = total * r / world;
-            while (b < nb && (int64_t)P.cum2[P.bstart[b]] < want) ++b;          // first band that starts at or beyond the target
-            if (b > 0 && b <= nb && want - (int64_t)P.cum2[P.bstart[b - 1]] < (int64_t)P.cum2[P.bstart[std::min(b, nb)]] - want && P.bstart[b - 1] > cut_seg[r - 1]) --b;
-            const int64_t bb = std::min(b, nb);
-            cut_seg[r] = std::max<int64_t>(P.bstart[bb], cut_seg[r - 1]);
-            P.rank_node[r] = bb < nb ? P.band_lo[bb] : (int32_t)n;
-            if (P.rank_node[r] < P.rank_node[r - 1]) P.rank_node[r] = P.rank_node[r - 1];
-        }
-    }
-    P.chunk_seg.clear();
-    P.chunk_seg.push_back(0);
-    P.rank_chunk.assign((size_t)world + 1, 0);
-    {
-        int rnext = 1;
-        for (int64_t q = 0; q < mp;) {     // chunks: <= CHUNK_CAP cycles and <= CHUNK_SEG segments
-            while (rnext < world && cut_seg[rnext] <= q) P.rank_chunk[rnext++] = (int64_t)P.chunk_seg.size() - 1;
-            const int64_t stop = rnext < world ? cut_seg[rnext] : mp;
-            const int64_t lim = std::min<int64_t>(stop, q + max_seg);         // last segment boundary within CHUNK_CAP cycles: binary search (cum2 increases strictly)
-            const int64_t e = (int64_t)(std::upper_bound(P.cum2.begin() + q, P.cum2.begin() + lim + 1, (int64_t)P.cum2[q] + CHUNK_CAP,
-                                                         [](int64_t v, int32_t c) { return v < (int64_t)c; }) - P.cum2.begin()) - 1;
-            q = e;                          // max_cnt <= MAX_SEG_CYCLES <= CHUNK_CAP: always advances
-            P.chunk_seg.push_back((int32_t)q);
-        }
-        const int64_t nch = (int64_t)P.chunk_seg.size() - 1;
-        while (rnext <= world) P.rank_chunk[rnext++] = nch;
-    }
-    lap("chunks");
-    return DESC_OK;
-}
-
-// The work of every workgroup of the band sweep as a list of pieces (band rows + a range of that band's segments).
-//  * Sfull fits the L2s (small graphs): one contiguous range of segments per workgroup (equal cycle counts), split at band
-//    boundaries -- each workgroup loads one or two bands.
-//  * otherwise S({j,k}) rows would be fetched from the Infinity Cache once per (band, j) (measured: 8 % of the iteration at C4,
-//    17 % at C5): the (band, j) plane is cut into units (band b, block of JB consecutive j) whose j-rows (~1.5 MiB) fit an
-//    XCD's L2, and the units are dealt in j-block-major order to the least-loaded workgroup (deterministic list scheduling), so
-//    that at any moment all workgroups gather from the same block of rows.
-// Host only: no device call (also reachable through desc_debug_band_plan, which the CPU tests and sanitizer builds use).
-void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const NodePlan& P, int64_t seg_lo, int64_t seg_hi, int64_t cyc_lo, int64_t mcl,
-                      int G, hvec<PieceDesc>& pieces, hvec<int32_t>& piece_ptr, int& band_rows, bool& jmajor_out, int* tail_first_out = nullptr, int* n_tail_out = nullptr) {
-    const hvec<int32_t>& cum2 = P.cum2;
-    const int64_t n = prob->n, m = prob->m;
-    const bool timing = env_int("DESC_DEBUG_TIMING", 0) > 1;
-    auto t_lap = std::chrono::steady_clock::now();
-    auto lap = [&](const char* what) {
-        if (!timing) return;
-        auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[desc_amd] band plan %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_lap).count());
-        t_lap = now;
-    };
-    band_rows = 0;
-    const int64_t nbands = (int64_t)P.band_lo.size() - 1;
-    hvec<hvec<PieceDesc>> per_wg((size_t)G);
-    hvec<PieceDesc> tail;                                    // shared tail pieces, j-block-major (BandSweepArgs)
-    auto piece_of = [&](int64_t bd, int64_t q0, int64_t q1) {
-        const int32_t row_lo = P.rowptr[P.band_lo[bd]], row_len = P.rowptr[P.band_lo[bd + 1]] - row_lo;
-        band_rows = std::max(band_rows, (int)row_len);
-        return PieceDesc{row_lo, row_len, (int32_t)q0, (int32_t)q1};
-    };
-    // largest x in [lo, e] with cycles(lo..x) <= room (cum2 increases strictly: a binary search instead of a walk over the segments)
-    auto reach = [&](int64_t lo, int64_t e, int64_t room) {
-        return (int64_t)(std::upper_bound(cum2.begin() + lo, cum2.begin() + e + 1, (int64_t)cum2[lo] + room,
-                                          [](int64_t v, int32_t c) { return v < (int64_t)c; }) - cum2.begin()) - 1;
-    };
-    const int jmajor_env = env_int("DESC_DEBUG_JMAJOR", -1);
-    // (C3, 6.4 MB of S: contiguous 0.167 ms, units 0.184.  Round 4: a rank of a sharded run with < 150 K cycles per workgroup -- C4 over 8 GPUs:
-    //  61 K -- takes contiguous ranges too: a unit's row load and pipeline fill cost as much as its cycles there; measured one rank at a time,
-    //  profiles/r04_shard_w8_c4_{default,jmajor0}.json: 1033 -> 272 pieces per rank, sweep 196 -> 173 us)
-    //  C5 over 8 GPUs -- 73 K cycles per workgroup, but 80 MB of S and segments of 30 cycles -- is the other way round: units 250 us, contiguous 287 us
-    //  (profiles/r04_shard_w8_c5_v2*.json); the rule below separates the two measured cases by the size of S, nothing deeper.
-    const bool small_share = mcl < (int64_t)150000 * G && (int64_t)2 * m * 8 <= (48ll << 20);
-    const bool jmajor = jmajor_env >= 0 ? jmajor_env != 0 : ((int64_t)2 * m * 8 > (12ll << 20) && !small_share);
-    jmajor_out = jmajor;
-    // what a piece costs besides its cycles -- the load of the band's rows into the LDS and the fill of the register pipeline -- in cycle
-    // units.  Measured per workgroup with DESC_DEBUG_WGCLOCK (tools/wg_clock.py, least squares of the durations on the plan): 11 us per piece
-    // at C2 (= 7600 cycles at 1.5 ns per cycle), 9 us at C3 (4800), 8-13 us at C4 (4000-6400).
-    // Adopted: 6144 for the contiguous ranges (C2 sweep 130 -> 117 us, C3 121.5 -> 111 us against equal-cycle ranges; 4096 / 8192 within 2 %),
-    // 4096 for the j-block-major units (C4: 1205 vs 1212 us at 6144 / 8192) -- profiles/r03_piece_cost.txt.
-    const int64_t PC = std::max(0, env_int("DESC_DEBUG_PIECE_COST", jmajor ? 4096 : 6144));
-    if (!jmajor) {
-        // Contiguous ranges, one per workgroup, equal in cycles + PC per piece (a range that crosses a band boundary is two pieces and loads
-        // two sets of rows).  Round 2 made the ranges equal in cycles alone: at C2 / C3 the workgroups with 2-3 pieces finished 10-20 % after
-        // the others (durations 97-124 us at C2, correlation 0.86 with the piece count) and the kernel waited for them.
-        int64_t q = seg_lo, bd = 0;
-        while (bd + 1 < nbands && P.bstart[bd + 1] <= q) ++bd;
-        for (int b = 0; b < G && q < seg_hi; ++b) {
-            // bands that still begin inside what is left: each of them costs one more piece somewhere
-            int64_t bands_left = 0;
-            for (int64_t t = bd + 1; t < nbands && P.bstart[t] < seg_hi; ++t) ++bands_left;
-            const int64_t left = (cyc_lo + mcl) - cum2[q];
-            const int64_t target = (left + PC * ((G - b) + bands_left) + (G - b) - 1) / (G - b);
-            int64_t load = 0;
-            while (q < seg_hi) {
-                while (bd + 1 < nbands && P.bstart[bd + 1] <= q) ++bd;
-                const int64_t band_end = std::min<int64_t>(seg_hi, P.bstart[bd + 1]);
-                int64_t e = band_end;
-                if (b + 1 < G) {
-                    const int64_t room = target - load - PC;
-                    if (room <= 0 && load > 0) break;                       // not even the row load fits: the next workgroup starts here
-                    int64_t lo2 = q, hi2 = band_end;                         // largest e with cycles(q..e) <= room
-                    while (lo2 < hi2) { const int64_t mid = (lo2 + hi2 + 1) >> 1; if (cum2[mid] - cum2[q] <= room) lo2 = mid; else hi2 = mid - 1; }
-                    e = std::max<int64_t>(lo2, q + 1);
-                }
-                per_wg[b].push_back(piece_of(bd, q, e));
-                load += PC + (cum2[e] - cum2[q]);
-                q = e;
-                if (b + 1 < G && load >= target) break;
-            }
-        }
-    } else {
-        const int64_t avg_deg = std::max<int64_t>(1, 2 * m / std::max<int64_t>(1, n));
-        int64_t JB = env_int("DESC_DEBUG_JBLOCK", 0);
-        if (JB <= 0) {
-            // rows of a j-block ~1.5 MiB (they share an XCD's 4 MiB L2 with the streams), but wide enough that a unit streams
-            // >= 32 K cycles for the ~150 KB of band rows it loads (sparse graphs with short segments: C5 0.55 -> 0.60), up to 4 MiB
-            const int64_t jb_l2 = std::max<int64_t>(32, (3ll << 19) / (8 * avg_deg));
-            const double cyc_per_pair = (double)mcl / std::max(1.0, 0.5 * (double)nbands * (double)n);     // cycles per (band, j) pair
-            const int64_t jb_amort = (int64_t)(32768.0 / std::max(cyc_per_pair, 1.0));
-            JB = std::min<int64_t>(std::max(jb_l2, jb_amort), std::max<int64_t>(jb_l2, (4ll << 20) / (8 * avg_deg)));
-        }
-        const int64_t cap = std::max<int64_t>(16384, mcl / (4 * (int64_t)G));        // cycles per unit at most
-        const int64_t nJ = (n + JB - 1) / JB;
-        auto j_of = [&](int64_t q) { return (int64_t)prob->ind_j[s->pos_edge[P.order[q]]]; };
-        // position of the first segment of band bd with j >= jlim, inside the rank's range
-        hvec<int64_t> cur((size_t)nbands), bend((size_t)nbands);
-        for (int64_t bd = 0; bd < nbands; ++bd) {
-            cur[bd] = std::min(std::max(P.bstart[bd], seg_lo), seg_hi);
-            bend[bd] = std::min(std::max(P.bstart[bd + 1], seg_lo), seg_hi);
-        }
-        // min-heap over (load, wg): the next unit goes to the workgroup that would be free first
-        hvec<std::pair<int64_t, int>> heap; heap.reserve((size_t)G);
-        for (int b = 0; b < G; ++b) heap.push_back({0, b});
-        auto cmp = [](const std::pair<int64_t, int>& x, const std::pair<int64_t, int>& y) { return x > y; };
-        std::make_heap(heap.begin(), heap.end(), cmp);
-        // Band affinity (round 3): the next unit of a band goes to the workgroup that took the band's previous unit -- whose LDS still holds
-        // the band's rows: its piece is simply extended, no row load -- unless that workgroup is more than `slack` cycles ahead of the least
-        // loaded one (then plain list scheduling, as in round 2).  Measured (profiles/r03_band_affinity.txt, sweep averages in one call):
-        // C4 3636 -> 1738 pieces, 1183 -> 1148 us (-3 %) at a slack of 16 K cycles (~half a unit); 4 K -1 %, 8 K -2 %, 32 K 0, 64 K +2 %,
-        // 256 K +23 % (the workgroups drift apart in j and lose the L2 locality of the j rows); C5 (529 bands on 256 workgroups: every
-        // workgroup alternates between two bands, little to merge) within noise.  DESC_DEBUG_AFFINITY = slack in K cycles, 0 = off.
-        const int64_t aff_slack = (int64_t)env_int("DESC_DEBUG_AFFINITY", 16) * 1024;
-        if (aff_slack > 0) {
-            hvec<int64_t> load((size_t)G, 0);
-            hvec<int> last_wg((size_t)nbands, -1);
-            // How even the lists end up (tools/wg_clock.py, DESC_DEBUG_WGCLOCK): with units of ~34 K cycles and the affinity slack the plan's
-            // cycle counts spread +-5 % at C4 (455 K .. 509 K) and the workgroups' measured times follow them (correlation 0.74; mean 1105,
-            // max 1158 us).  Two remedies, both here:
-            //  * fit to target (DESC_DEBUG_FIT per mille, default 0): in the last part of the cycles a unit is cut where the workgroup that takes
-            //    it reaches the common target load -- the lists end level to a segment.  Measured: no gain at C4, C5 slightly worse; what is left
-            //    of the spread is not in the plan (even XCDs run 1.5 % slower than odd ones: profiles/r03_experiments.txt);
-            //  * shared tail (DESC_DEBUG_TAIL per mille, default 20): the last part is queued as small pieces for whichever workgroup finishes
-            //    first (k_sweep_band).  First measured with 10 % of the cycles in the queue: it levels the end times (max - mean 4.8 % -> 1.4 %) but
-            //    its ~700 small pieces each load their band rows and the mean rises by as much (profiles/r03_experiments.txt).  With the final
-            //    kernel and 1.5-4 % in the queue: C4 996-1014 -> 984-999 us, C5 1585-1596 -> 1569-1580 (about -1 %, profiles/r03_piece_cost.txt):
-            //    2 % is the default.
-            const int64_t tail_target = tail_first_out ? mcl * std::max(0, std::min(500, env_int("DESC_DEBUG_TAIL", 20))) / 1000 : 0;
-            const int64_t tail_cap = std::max<int64_t>(4096, tail_target / (MAX_TAIL_PIECES - 64));
-            const int64_t fit_from = mcl - mcl * std::max(0, std::min(500, env_int("DESC_DEBUG_FIT", 0))) / 1000;
-            int64_t fit_target = -1;                         // common final load, fixed when the fitting phase starts
-            int64_t dealt = 0;
-            for (int64_t J = 0; J < nJ; ++J) {
-                const int64_t jlim = (J + 1) * JB;
-                for (int64_t bd = 0; bd < nbands; ++bd) {
-                    int64_t lo = cur[bd]; const int64_t hi = bend[bd];
-                    if (lo >= hi) continue;
-                    int64_t a0 = lo, a1 = hi;
-                    while (a0 < a1) { const int64_t mid = (a0 + a1) >> 1; if (j_of(mid) < jlim) a0 = mid + 1; else a1 = mid; }
-                    const int64_t e = a0;
-                    cur[bd] = e;
-                    while (lo < e) {
-                        int64_t x = reach(lo, e, cap);
-                        if (x == lo) x = lo + 1;
-                        if (tail_target > 0 && dealt >= mcl - tail_target && (int64_t)tail.size() < MAX_TAIL_PIECES) {      // the rest of the sweep: queue
-                            x = reach(lo, e, tail_cap);
-                            if (x == lo) x = lo + 1;
-                            tail.push_back(piece_of(bd, lo, x));
-                            dealt += cum2[x] - cum2[lo];
-                            lo = x;
-                            continue;
-                        }
-                        int wmin = 0;
-                        for (int w = 1; w < G; ++w) if (load[w] < load[wmin]) wmin = w;
-                        const int wl = last_wg[bd];
-                        const bool merge = wl >= 0 && load[wl] <= load[wmin] + aff_slack && !per_wg[wl].empty() && per_wg[wl].back().seg_hi == (int32_t)lo &&
-                                           per_wg[wl].back().row_lo == P.rowptr[P.band_lo[bd]];
-                        const int wt = merge ? wl : wmin;
-                        if (dealt >= fit_from) {
-                            if (fit_target < 0) {            // what is left + what is dealt + a row load per workgroup, shared equally
-                                int64_t sum = 0;
-                                for (int w = 0; w < G; ++w) sum += load[w];
-                                fit_target = (sum + (mcl - dealt) + PC * (int64_t)G + G - 1) / G;
-                            }
-                            const int64_t room = fit_target - load[wt] - (merge ? 0 : PC);
-                            if (room < 2048 && load[wmin] + PC + 2048 > fit_target) fit_target += 4096;       // everybody is full: raise the bar a little
-                            else if (room >= 2048) {
-                                const int64_t y = reach(lo, x, room);
-                                if (y > lo) x = y;           // cut the unit where this workgroup reaches the target
-                                else x = lo + 1;
-                            } else {                         // the band's resident workgroup is full: the least loaded one takes the unit instead
-                                last_wg[bd] = -1;
-                                continue;
-                            }
-                        }
-                        dealt += cum2[x] - cum2[lo];
-                        if (merge) {
-                            per_wg[wl].back().seg_hi = (int32_t)x;                 // same rows, contiguous segments: one longer piece
-                            load[wl] += cum2[x] - cum2[lo];
-                        } else {
-                            per_wg[wmin].push_back(piece_of(bd, lo, x));
-                            load[wmin] += cum2[x] - cum2[lo] + PC;
-                            last_wg[bd] = wmin;
-                        }
-                        lo = x;
-                    }
-                }
-            }
-        } else
-        for (int64_t J = 0; J < nJ; ++J) {
-            const int64_t jlim = (J + 1) * JB;
-            for (int64_t bd = 0; bd < nbands; ++bd) {
-                int64_t lo = cur[bd]; const int64_t hi = bend[bd];
-                if (lo >= hi) continue;
-                int64_t a0 = lo, a1 = hi;                   // first q in [lo, hi) with j(q) >= jlim
-                while (a0 < a1) { const int64_t mid = (a0 + a1) >> 1; if (j_of(mid) < jlim) a0 = mid + 1; else a1 = mid; }
-                const int64_t e = a0;
-                cur[bd] = e;
-                while (lo < e) {                             // split units above the cap
-                    int64_t x = reach(lo, e, cap);
-                    if (x == lo) x = lo + 1;
-                    std::pop_heap(heap.begin(), heap.end(), cmp);
-                    auto& top = heap.back();
-                    per_wg[top.second].push_back(piece_of(bd, lo, x));
-                    top.first += cum2[x] - cum2[lo] + PC;    // + the row load and pipeline fill of a piece, in cycle units
-                    std::push_heap(heap.begin(), heap.end(), cmp);
-                    lo = x;
-                }
-            }
-        }
-    }
-    pieces.clear();
-    lap("units dealt");
-    piece_ptr.assign((size_t)G + 1, 0);
-    for (int b = 0; b < G; ++b) {
-        pieces.insert(pieces.end(), per_wg[b].begin(), per_wg[b].end());
-        piece_ptr[b + 1] = (int32_t)pieces.size();
-    }
-    if (tail_first_out) { *tail_first_out = (int)pieces.size(); *n_tail_out = (int)tail.size(); }
-    pieces.insert(pieces.end(), tail.begin(), tail.end());
-    if (pieces.empty()) pieces.push_back(PieceDesc{0, 0, 0, 0});
-}
-
-// LDS budget of a band's rows.  DESC_DEBUG_ROW_CAP (tests only) shrinks it -- never below the longest row -- so that a small graph is cut into
-// many bands: piece boundaries, the ranks' whole-band ranges and the exchange layout of world = 8 are then exercised at oracle sizes.
-int band_row_cap(int max_deg) {
-    const int v = env_int("DESC_DEBUG_ROW_CAP", 0);
-    return v > 0 ? std::min(BAND_ROW_CAP, std::max(v, std::max(max_deg, 2))) : BAND_ROW_CAP;
-}
-
 int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, const double* shared_rij) {
     const int64_t n = h->n, m = h->m, mp = h->m_pos;
     auto t0 = std::chrono::steady_clock::now();
@@ -2636,6 +2091,36 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     };
     int rc;
     NodePlan P;
+    // A structure built on this device brings its CSR, edge tables and sampled k along in HBM: the
+    // per-edge tables and the cycle layout are then made by kernels and the host only plans.
+    const bool dev_cycles = s->dev == h->device && s->d_k != nullptr;
+    double* d_rij = nullptr;
+    auto launch_layout_dev = [&](const int32_t* cum, const int32_t* src_start, const int32_t* pos, const int32_t* rowptr_d, uint32_t* pk, double* S0, uint8_t* perm,
+                                 uint32_t* counts, int64_t nseg) {
+        const int g = (int)std::min<int64_t>(4096, (nseg + 3) / 4);
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, h->stream, cum, src_start, pos, s->d_ii, s->d_jj, s->d_k, s->d_tau, s->d_ktau, (uint64_t)s->seed, rowptr_d,
+                               s->d_bits, s->d_rank, (int)s->words, s->d_adj_eid, d_rij, pk, S0, perm, counts, (int)nseg);
+        };
+        if (h->max_cnt <= 64) go(k_layout_node_dev<1>); else if (h->max_cnt <= 128) go(k_layout_node_dev<2>); else go(k_layout_node_dev<4>);
+    };
+    // One rank: packed words, S0_long (DESC_PGD.m:129-147) and the class order of every segment are computed NOW, in the structure's natural
+    // order, under the host-side planning below; k_permute_segments moves them into the band-major order once that exists.  (Round 3 ran this
+    // kernel -- 8.7 ms at C4 -- after the plan: the device idled through the planning, then the host through the kernel.)
+    uint32_t *d_pk_nat = nullptr, *d_counts_nat = nullptr; double* d_S0_nat = nullptr; uint8_t* d_perm_nat = nullptr;
+    const bool early = dev_cycles && h->world == 1 && mp > 0 && env_int("DESC_DEBUG_EARLY_LAYOUT", 1) != 0;
+    if (early) {
+        if (shared_rij) d_rij = const_cast<double*>(shared_rij);
+        else {
+            if ((rc = dalloc(h, &d_rij, 9 * (size_t)m))) return rc;
+            if (m) DESC_HIP(hipMemcpy(d_rij, prob->rij, sizeof(double) * 9 * (size_t)m, hipMemcpyHostToDevice));
+        }
+        if ((rc = dalloc(h, &d_pk_nat, h->m_cycle + 8)) || (rc = dalloc(h, &d_S0_nat, h->m_cycle + 8)) || (rc = dalloc(h, &d_perm_nat, h->m_cycle + 8)) ||
+            (rc = dalloc(h, &d_counts_nat, mp))) return rc;
+        if (s->ev_fill) DESC_HIP(hipStreamWaitEvent(h->stream, (hipEvent_t)s->ev_fill, 0));
+        launch_layout_dev(s->d_cum, s->d_cum, s->d_pos, s->d_rowptr, d_pk_nat, d_S0_nat, d_perm_nat, d_counts_nat, mp);
+        DESC_HIP(hipGetLastError());
+    }
     // band sweep (i-rows of S in the LDS): segments of up to 64 cycles, every CSR row fits the LDS; DESC_DEBUG_VARIANT=2 keeps
     // the L2-sized bands of k_sweep_node for comparison
     int ncu = 256;
@@ -2684,9 +2169,6 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
                             h->band_grid, jmajor ? "j-block-major units" : "contiguous ranges", h->band_rows);
     }
 
-    // A structure built on this device brings its CSR, edge tables and sampled k along in HBM: the
-    // per-edge tables and the cycle layout are then made by kernels and the host only plans.
-    const bool dev_cycles = s->dev == h->device && s->d_k != nullptr;
     // CSR adjacency (neighbours ascending; single pass because Ind is sorted by (i,j))
     hvec<int32_t> rowptr, adj, adj_eid, eslot, eslot_b;
     if (!dev_cycles) {
@@ -2801,7 +2283,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     }
     lap("alloc");
     int32_t *d_ii = nullptr, *d_jj = nullptr, *d_adj = nullptr, *d_adj_eid = nullptr, *d_pos_edge2 = nullptr;
-    uint32_t* d_kf = nullptr; double* d_rij = nullptr;
+    uint32_t* d_kf = nullptr;
     if (dev_cycles) {               // borrowed from the structure for the duration of this call
         d_ii = s->d_ii; d_jj = s->d_jj; d_adj = s->d_adj; d_adj_eid = s->d_adj_eid;
     } else {
@@ -2812,11 +2294,16 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         if ((rc = dalloc(h, &d_kf, mcl))) return rc;
     }
     if ((rc = dalloc(h, &d_pos_edge2, mp))) return rc;
-    if (shared_rij) d_rij = const_cast<double*>(shared_rij);          // the device problem's copy: no 72-B-per-edge upload
+    const bool rij_up = d_rij != nullptr;                             // the early layout already has the rotations on the device
+    if (rij_up) {}
+    else if (shared_rij) d_rij = const_cast<double*>(shared_rij);     // the device problem's copy: no 72-B-per-edge upload
     else if ((rc = dalloc(h, &d_rij, 9 * (size_t)m))) return rc;
     hvec<int32_t> rank_seg32(h->rank_seg.begin(), h->rank_seg.end());
-    int32_t* d_devpos = nullptr;
-    if (dev_cycles && s->ev_fill) DESC_HIP(hipStreamWaitEvent(h->stream, (hipEvent_t)s->ev_fill, 0));       // the structure's sampled cycles may still be on their way
+    int32_t *d_devpos = nullptr, *d_order_keep = nullptr;
+    if (dev_cycles && s->ev_fill) {       // the structure's sampled cycles may still be on their way; a fault of that kernel is reported as its own
+        const hipError_t ef = hipEventSynchronize((hipEvent_t)s->ev_fill);
+        if (ef != hipSuccess) return fail(DESC_ERR_HIP, "cycle sampling kernel failed: %s", hipGetErrorString(ef));
+    }
     if (dev_cycles) {
         int32_t* d_order = nullptr;
         if ((rc = dalloc(h, &d_devpos, m)) || (rc = dalloc(h, &d_order, mp))) return rc;
@@ -2825,7 +2312,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         hipLaunchKernelGGL(k_seg_tables, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (mp + 256) / 256))), dim3(256), 0, h->stream,
                            d_order, s->d_pos, s->d_cum, h->d_cum, (int32_t)h->cyc_lo, h->d_src_start, d_pos_edge2, d_devpos, mp);
         DESC_HIP(hipStreamSynchronize(h->stream));       // d_order, the host sources of the copies
-        dfree(h, d_order);
+        if (early) d_order_keep = d_order; else dfree(h, d_order);
     } else {
     if ((rc = upload(h, h->d_cum, cum_loc.data(), (size_t)mp + 1))) return rc;
     if ((rc = upload(h, h->d_src_start, src_start.data(), (size_t)mp))) return rc;
@@ -2834,7 +2321,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     if ((rc = upload(h, h->d_chunk_desc, chunk_desc.data(), chunk_desc.size()))) return rc;
     if ((rc = upload(h, h->d_rank_seg, rank_seg32.data(), rank_seg32.size()))) return rc;
     // (a synchronous copy from pageable memory runs 2-3x faster than an asynchronous one on this runtime)
-    if (!shared_rij && m) DESC_HIP(hipMemcpy(d_rij, prob->rij, sizeof(double) * 9 * (size_t)m, hipMemcpyHostToDevice));
+    if (!shared_rij && !rij_up && m) DESC_HIP(hipMemcpy(d_rij, prob->rij, sizeof(double) * 9 * (size_t)m, hipMemcpyHostToDevice));
     if (h->band_ok) {
         if ((rc = upload(h, h->d_pieces, pieces.data(), pieces.size()))) return rc;
         if ((rc = upload(h, h->d_piece_ptr, piece_ptr.data(), piece_ptr.size()))) return rc;
@@ -2946,22 +2433,16 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         uint32_t* d_counts = nullptr;
         if ((rc = dalloc(h, &d_counts, mp))) return rc;
         DESC_HIP(hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * std::max<int64_t>(1, mp), h->stream));
-        if (nsl > 0) {
-            int g = (int)std::min<int64_t>(4096, (nsl + 3) / 4);
-            if (h->max_cnt <= 64) hipLaunchKernelGGL(k_layout_node_dev<1>, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo,
-                               d_pos_edge2 + h->seg_lo, d_ii, d_jj, s->d_k, s->d_tau, s->d_ktau, (uint64_t)s->seed, h->d_rowptr, s->d_bits, s->d_rank, (int)s->words, d_adj_eid, d_rij,
-                               h->d_pk, h->d_S0, h->d_seg_perm, d_counts + h->seg_lo, (int)nsl);
-            else if (h->max_cnt <= 128) hipLaunchKernelGGL(k_layout_node_dev<2>, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo,
-                               d_pos_edge2 + h->seg_lo, d_ii, d_jj, s->d_k, s->d_tau, s->d_ktau, (uint64_t)s->seed, h->d_rowptr, s->d_bits, s->d_rank, (int)s->words, d_adj_eid, d_rij,
-                               h->d_pk, h->d_S0, h->d_seg_perm, d_counts + h->seg_lo, (int)nsl);
-            else hipLaunchKernelGGL(k_layout_node_dev<4>, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo,
-                               d_pos_edge2 + h->seg_lo, d_ii, d_jj, s->d_k, s->d_tau, s->d_ktau, (uint64_t)s->seed, h->d_rowptr, s->d_bits, s->d_rank, (int)s->words, d_adj_eid, d_rij,
-                               h->d_pk, h->d_S0, h->d_seg_perm, d_counts + h->seg_lo, (int)nsl);
-        }
+        if (early) {            // computed in natural order under the planning: move the segments to their device positions
+            hipLaunchKernelGGL(k_permute_segments, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, (mp + 3) / 4))), dim3(256), 0, h->stream,
+                               d_order_keep, s->d_cum, h->d_cum, d_pk_nat, d_S0_nat, d_perm_nat, d_counts_nat, h->d_pk, h->d_S0, h->d_seg_perm, d_counts, mp);
+        } else if (nsl > 0)
+            launch_layout_dev(h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo, d_pos_edge2 + h->seg_lo, h->d_rowptr, h->d_pk, h->d_S0, h->d_seg_perm, d_counts + h->seg_lo, nsl);
         hipLaunchKernelGGL(k_adj_seg, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256))), dim3(256), 0, h->stream,
                            h->d_rowptr, d_adj, d_adj_eid, d_devpos, h->d_cum, d_counts, (int)h->seg_lo, (int)h->seg_hi, h->d_adj_seg, (int)n);
         DESC_HIP(hipStreamSynchronize(h->stream));
         dfree(h, d_devpos); dfree(h, d_counts);
+        dfree(h, d_order_keep); dfree(h, d_pk_nat); dfree(h, d_S0_nat); dfree(h, d_perm_nat); dfree(h, d_counts_nat);
     }
     {   // exchange layout of the sharded runs (both paths have the CSR index, the edge list and the segment tables on the device by now)
         int32_t *d_node_lo = nullptr, *d_elo = nullptr, *d_prefB = nullptr;
@@ -3169,7 +2650,6 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
     h->p = *p;
     if (h->p.patience <= 0) h->p.patience = 30;
     {   // diagnostics only: never set in production runs
-        h->ablate = env_int("DESC_DEBUG_ABLATE", 0);
         const int gr = env_int("DESC_DEBUG_GRID", 0);
         if (gr >= 8 && gr / 8 * 8 != h->grid) {
             dfree(h, h->d_partials); h->d_partials = nullptr;
@@ -3501,7 +2981,7 @@ int shard_enqueue_sweep(desc_pgd* h, hipStream_t st) {
     a.csr_bytes = (uint32_t)(16 * h->m); a.t_bytes = (uint32_t)(8 * h->t_part); a.slice_bytes = (uint32_t)(8 * h->slice_S); a.seg_count = (uint32_t)h->m_pos; a.fx_inv = std::ldexp(1.0, -h->colsum_fx_bits);
     if (shard_direct(h)) { a.Tfull = h->d_T; a.xt = nullptr; a.s_slice = nullptr; a.t_bytes = a.csr_bytes; }
     a.state = h->d_state; a.st = sa; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks;
-    a.max_cnt = h->max_cnt; a.ablate = 0;
+    a.max_cnt = h->max_cnt;
     const hipStream_t keep = h->stream; h->stream = st;
     launch_sweep_node_layout(h, a, adam);
     h->stream = keep;

@@ -1,5 +1,6 @@
 // desc_device_problem: the measurement graph resident in HBM, shared by every entry point of the library.
 // (Nothing in the reference corresponds to this: there, RijMat and Ind are MATLAB arrays every function indexes.)
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <new>
@@ -18,7 +19,12 @@ static hipError_t copy_rij(double* d_rij, const double* rij, int64_t m) {
     const bool pin = m >= (1 << 18) && !(pin_env && std::atoi(pin_env) == 0);
     bool pinned = false;
     if (pin) { pinned = hipHostRegister((void*)rij, sizeof(double) * 9 * m, hipHostRegisterDefault) == hipSuccess; if (!pinned) (void)hipGetLastError(); }
-    const hipError_t e = hipMemcpy(d_rij, rij, sizeof(double) * 9 * m, hipMemcpyHostToDevice);
+    // In pieces of 16 MiB: desc_pgd_solve runs this copy on a helper thread while the structure builder uploads the edge list on the caller's;
+    // behind ONE 180 MB transfer (C4) those two 10 MB copies waited up to 23 ms (profiles/r04_e2e_laps.txt), behind a piece at most ~1 ms.
+    hipError_t e = hipSuccess;
+    const size_t total = sizeof(double) * 9 * (size_t)m, piece = (size_t)16 << 20;
+    for (size_t off = 0; off < total && e == hipSuccess; off += piece)
+        e = hipMemcpy((char*)d_rij + off, (const char*)rij + off, std::min(piece, total - off), hipMemcpyHostToDevice);
     if (pinned) (void)hipHostUnregister((void*)rij);
     return e;
 }

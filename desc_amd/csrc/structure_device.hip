@@ -20,6 +20,8 @@
 #include <type_traits>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "device_utils.h"
 
 namespace desc {
@@ -343,6 +345,27 @@ struct DevBuf {
     }
 };
 
+// Compaction of the edges with cycles (DESC_PGD.m:36-37) and their sampled cycle counts min(codeg, n_sample) (:45): flags and counts here,
+// two exclusive scans (hipCUB), then the scatter below.
+__global__ __launch_bounds__(256) void k_flag_count(const int32_t* codeg, int n_sample, int32_t* flag, int32_t* cnt, int64_t m) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < m; e += (int64_t)gridDim.x * 256) {
+        const int32_t cd = codeg[e];
+        flag[e] = cd > 0 ? 1 : 0;
+        cnt[e] = cd > 0 ? min(cd, n_sample) : 0;
+    }
+}
+// pos[l] = e, poe[e] = l (-1: no cycles), cum[l] = cycles before edge-with-cycles l (int32 for the kernels, int64 for the host's cum_ind)
+__global__ __launch_bounds__(256) void k_compact_edges(const int32_t* flag, const int32_t* cnt, const int32_t* posidx, const long long* cum64, int32_t* pos, int32_t* poe,
+                                                       int32_t* cum, long long* cumc, int64_t m, int64_t mp) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < m; e += (int64_t)gridDim.x * 256) {
+        if (!flag[e]) { poe[e] = -1; continue; }
+        const int32_t l = posidx[e];
+        pos[l] = (int32_t)e; poe[e] = l;
+        cum[l] = (int32_t)cum64[e]; cumc[l] = cum64[e];
+        if (l == mp - 1) { cum[mp] = (int32_t)(cum64[e] + cnt[e]); cumc[mp] = cum64[e] + cnt[e]; }
+    }
+}
+
 }  // namespace
 
 int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint64_t seed, int32_t device, desc_structure* s) {
@@ -391,6 +414,7 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
         DESC_HIP(hipMemcpy(s->d_ii, prob->ind_i, sizeof(int32_t) * m, hipMemcpyHostToDevice));
         DESC_HIP(hipMemcpy(s->d_jj, prob->ind_j, sizeof(int32_t) * m, hipMemcpyHostToDevice));
     }
+    g_ind_upload_count.fetch_add(1);
     lap("upload Ind");
     DESC_HIP(hipMemsetAsync(d_bits, 0, sizeof(unsigned long long) * (size_t)n * words, 0));
     DESC_HIP(hipMemsetAsync(d_hist, 0, sizeof(int32_t) * (n + 1), 0));
@@ -414,15 +438,13 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
         hipLaunchKernelGGL(k_codeg, dim3((unsigned)std::min<int64_t>(2048, (m + 3) / 4)), dim3(256), 0, 0, s->d_ii, s->d_jj, d_bits, d_codeg, d_hist, m, (int)words,
                            (int)std::min<int64_t>(n + 1, (int64_t)s->max_deg + 1));
     DESC_HIP(hipGetLastError());
-    s->codeg.assign((size_t)m, 0);
     hvec<int32_t> hist((size_t)n + 1, 0);
-    if (m) DESC_HIP(hipMemcpy(s->codeg.data(), d_codeg, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
-    DESC_HIP(hipMemcpy(hist.data(), d_hist, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost));
-    lap("bitmaps+codeg+d2h");
+    DESC_HIP(hipMemcpy(hist.data(), d_hist, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost));      // synchronous: every kernel above has finished
+    lap("bitmaps+codeg+hist");
 
-    // edges with cycles, median, n_sample, cum_ind  (DESC_PGD.m:36-51).  The median of the positive
-    // codegrees comes from their histogram (codeg <= n-2): O(n) instead of a selection over m values.
-    int64_t mp = 0;
+    // edges with cycles, median, n_sample, m_cycle  (DESC_PGD.m:36-51) -- all from the codegree histogram (codeg <= n-2): O(n) on the host
+    // instead of a selection / a pass over m values.
+    int64_t mp = 0, mc_total = 0;
     int32_t max_codeg = 0;
     for (int64_t c = 1; c <= n; ++c) if (hist[c]) { mp += hist[c]; max_codeg = (int32_t)c; }
     s->m_pos = mp;
@@ -436,52 +458,57 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
         const double med = (mp & 1) ? kth(mp / 2) : 0.5 * (kth(mp / 2 - 1) + kth(mp / 2));     // MATLAB median (:43)
         n_sample = std::max(n_sample_min, (int32_t)std::ceil(med / 4.0));
     }
+    for (int64_t c = 1; c <= n; ++c) mc_total += (int64_t)hist[c] * std::min<int64_t>(c, n_sample);      // sum of min(codeg, n_sample)  (:45-51)
     s->n_sample = n_sample;
-    s->pos_edge.resize((size_t)mp);
-    s->cum_ind.assign((size_t)mp + 1, 0);
     s->max_cnt = std::min(max_codeg, n_sample);
-    hvec<int32_t> cum32((size_t)mp + 1, 0), pos_of_edge((size_t)std::max<int64_t>(m, 1));     // both filled by the second threaded pass below
-    {   // compaction of the edges with cycles + prefix sum of their cycle counts, in chunks (threads for large m)
-        unsigned hw = std::thread::hardware_concurrency();
-        const int T = m >= (1 << 20) ? (int)std::max(1u, std::min(hw, 16u)) : 1;
-        hvec<int64_t> c_pos((size_t)T + 1, 0), c_cyc((size_t)T + 1, 0);
-        auto run = [&](auto&& body) {
-            run_threads(T, [&](int t) { body(t, m * t / T, m * (t + 1) / T); });
-        };
-        run([&](int t, int64_t a, int64_t b) {
-            int64_t np = 0, nc = 0;
-            for (int64_t e = a; e < b; ++e) { const int32_t cd = s->codeg[e]; if (cd > 0) { ++np; nc += std::min(cd, n_sample); } }
-            c_pos[t + 1] = np; c_cyc[t + 1] = nc;
-        });
-        for (int t = 0; t < T; ++t) { c_pos[t + 1] += c_pos[t]; c_cyc[t + 1] += c_cyc[t]; }
-        run([&](int t, int64_t a, int64_t b) {
-            int64_t l = c_pos[t], c = c_cyc[t];
-            for (int64_t e = a; e < b; ++e) {
-                const int32_t cd = s->codeg[e];
-                if (cd <= 0) { pos_of_edge[e] = -1; continue; }
-                s->pos_edge[l] = (int32_t)e; pos_of_edge[e] = (int32_t)l;
-                c += std::min(cd, n_sample);
-                s->cum_ind[++l] = c;
-                cum32[l] = (int32_t)std::min<int64_t>(c, INT32_MAX);          // (m_cycle < 2^31 - 1 is checked right below)
-            }
-        });
-        if (m == 0) pos_of_edge[0] = -1;
-    }
-    s->m_cycle = s->cum_ind[mp];
+    s->m_cycle = mc_total;
     if (s->m_cycle >= (1ll << 31) - 1) return fail(DESC_ERR_TOO_LARGE, "m_cycle = %lld exceeds 2^31-2", (long long)s->m_cycle);
     if (max_codeg > MAX_CODEG_LDS)
         return fail(DESC_ERR_TOO_LARGE, "an edge has %d common neighbours (> %d): use DESC_BUILD_HOST", max_codeg, MAX_CODEG_LDS);
-    lap("host median/cum");
+    lap("host median");
     const int64_t mc = s->m_cycle;
     s->k.clear(); s->e_jk.clear(); s->e_ki.clear(); s->ikj.clear(); s->jki.clear();
     s->host_cycles = (mp == 0);                       // per-cycle arrays stay in HBM until somebody asks for them
+    s->codeg.assign((size_t)m, 0);
+    s->pos_edge.resize((size_t)mp);
+    s->cum_ind.assign((size_t)mp + 1, 0);
     if (mp > 0) {
+        // Round 4: the compaction of the edges with cycles and the prefix sums of their cycle counts (DESC_PGD.m:36-37, 45-54) are two device
+        // scans (hipCUB) + one scatter pass on a stream of their own, the cycle-sampling kernel follows on the same stream at once, and the
+        // host copies pos_edge / cum_ind / codeg down for its planning WHILE that kernel runs.  (Round 3 did the compaction on the host: 4.2 ms
+        // at C4 with the device idle, the three tables went back up, and only then was the sampling kernel launched.)
+        hipStream_t fs = nullptr;
+        DESC_HIP(stream_acquire(&fs));
+        s->fill_stream = (void*)fs;
+        int32_t *d_flag = nullptr, *d_cnt = nullptr, *d_posidx = nullptr; long long *d_cum64 = nullptr, *d_cumc = nullptr;
+        auto tmp = [&](int slot, auto** out, size_t count) -> int {
+            void* q = nullptr;
+            DESC_HIP(dev_alloc(&q, sizeof(**out) * (count ? count : 1)));
+            (void)slot;
+            s->d_build_blocks.push_back(q);
+            *out = (std::remove_reference_t<decltype(*out)>)q;
+            return DESC_OK;
+        };
         if ((rc = keep(&s->d_pos, mp)) || (rc = keep(&s->d_cum, mp + 1)) || (rc = keep(&s->d_poe, m)) || (rc = keep(&s->d_k, mc)) ||
-            (rc = keep(&s->d_tau, m)) || (rc = keep(&s->d_ktau, m))) return rc;
-        DESC_HIP(hipMemcpy(s->d_pos, s->pos_edge.data(), sizeof(int32_t) * mp, hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(s->d_cum, cum32.data(), sizeof(int32_t) * (mp + 1), hipMemcpyHostToDevice));
-        DESC_HIP(hipMemcpy(s->d_poe, pos_of_edge.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
-        lap("alloc cycles+upload");
+            (rc = keep(&s->d_tau, m)) || (rc = keep(&s->d_ktau, m)) || (rc = tmp(0, &d_flag, 2 * (size_t)m)) || (rc = tmp(1, &d_posidx, m)) ||
+            (rc = tmp(2, &d_cum64, m)) || (rc = tmp(3, &d_cumc, mp + 1))) return rc;
+        d_cnt = d_flag + m;
+        size_t tb1 = 0, tb2 = 0;
+        DESC_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, d_flag, d_posidx, (int)m, fs));
+        DESC_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, d_cnt, d_cum64, (int)m, fs));
+        char* d_scan_tmp = nullptr;
+        size_t tb = std::max(tb1, tb2);
+        if ((rc = tmp(4, &d_scan_tmp, tb))) return rc;
+        const unsigned ge = (unsigned)std::min<int64_t>(4096, (m + 255) / 256);
+        hipLaunchKernelGGL(k_flag_count, dim3(ge), dim3(256), 0, fs, d_codeg, (int)n_sample, d_flag, d_cnt, m);
+        DESC_HIP(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, tb, d_flag, d_posidx, (int)m, fs));
+        DESC_HIP(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, tb, d_cnt, d_cum64, (int)m, fs));
+        hipLaunchKernelGGL(k_compact_edges, dim3(ge), dim3(256), 0, fs, d_flag, d_cnt, d_posidx, d_cum64, s->d_pos, s->d_poe, s->d_cum, d_cumc, m, mp);
+        DESC_HIP(hipGetLastError());
+        hipEvent_t ev_c = nullptr;
+        DESC_HIP(hipEventCreateWithFlags(&ev_c, hipEventDisableTiming));
+        DESC_HIP(hipEventRecord(ev_c, fs));
+        lap("compaction (launched)", false);
         // LDS per wave: key (8 B) + k (4 B) per staged common neighbour
         int cap = 64;
         while (cap < max_codeg) cap <<= 1;
@@ -490,21 +517,34 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
             DESC_HIP(hipFuncSetAttribute((const void*)k_fill_cycles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const char* tenv2 = getenv("DESC_DEBUG_EXACT_SELECT");     // tests: force the exact (tie-safe) ranking path
         const unsigned g = (unsigned)std::min<int64_t>(8192, (mp + 3) / 4);
-        D.release();                   // (waits for the device: everything above has been copied back already) -- nothing below may block on the fill
-        hipLaunchKernelGGL(k_fill_cycles, dim3(g), dim3(256), lds, 0, s->d_pos, s->d_cum, s->d_ii, s->d_jj, d_bits, s->d_k, s->d_tau, s->d_ktau,
+        hipLaunchKernelGGL(k_fill_cycles, dim3(g), dim3(256), lds, fs, s->d_pos, s->d_cum, s->d_ii, s->d_jj, d_bits, s->d_k, s->d_tau, s->d_ktau,
                            mp, (int)words, (int)n_sample, seed, cap, (tenv2 && atoi(tenv2) != 0) ? 1 : 0);
         DESC_HIP(hipGetLastError());
-        // The sampled cycles (5.8 ms of kernel at C4) are not waited for: the caller goes on to plan the solver's layout on the host (11 ms at
-        // C4) while they are drawn.  Whoever reads d_k / d_tau / d_ktau on another stream waits for ev_fill (setup_node); the exports to the
-        // host use the NULL stream like the kernel and are ordered behind it.  DESC_DEBUG_SYNC_FILL=1: wait here (A/B, timing laps).
+        // The sampled cycles (5.8 ms of kernel at C4) are not waited for: the caller goes on to plan the solver's layout on the host (9 ms at
+        // C4) while they are drawn.  Whoever reads d_k / d_tau / d_ktau waits for ev_fill (setup_node, structure_ensure_host).
+        // DESC_DEBUG_SYNC_FILL=1: wait here (A/B, timing laps).
         hipEvent_t ev = nullptr;
         DESC_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         s->ev_fill = (void*)ev;
-        DESC_HIP(hipEventRecord(ev, 0));
+        DESC_HIP(hipEventRecord(ev, fs));
+        // the host's copies of the per-edge tables, under the sampling kernel (the copies wait for the compaction only)
+        {
+            const hipError_t ew = hipEventSynchronize(ev_c);
+            (void)hipEventDestroy(ev_c);
+            if (ew != hipSuccess) return fail(DESC_ERR_HIP, "edge compaction kernels failed: %s", hipGetErrorString(ew));
+        }
+        DESC_HIP(hipMemcpy(s->pos_edge.data(), s->d_pos, sizeof(int32_t) * mp, hipMemcpyDeviceToHost));
+        DESC_HIP(hipMemcpy(s->cum_ind.data(), d_cumc, sizeof(int64_t) * (mp + 1), hipMemcpyDeviceToHost));
+        DESC_HIP(hipMemcpy(s->codeg.data(), d_codeg, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+        if (s->cum_ind[mp] != mc) return fail(DESC_ERR_STATE, "cycle prefix sums (%lld) disagree with the codegree histogram (%lld)", (long long)s->cum_ind[mp], (long long)mc);
+        lap("tables to host", false);
+        // the builder's own scratch (codegrees, histogram, degree tables) is still being read by the kernels in flight: the structure keeps it
+        for (void* q : D.p) s->d_build_blocks.push_back(q);
+        D.p.clear();
         const char* sf = getenv("DESC_DEBUG_SYNC_FILL");
         if (sf && atoi(sf) != 0) DESC_HIP(hipDeviceSynchronize());
         lap("fill (launched)", false);
-    }
+    } else if (m) DESC_HIP(hipMemcpy(s->codeg.data(), d_codeg, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
     s->ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return DESC_OK;
 }
@@ -575,12 +615,17 @@ int build_cemp_samples_device(const desc_device_problem* dp, int32_t nsample, ui
 // Full index structure of a device-built structure on the host: derive e_jk / e_ki and the mirror
 // maps on the device, copy everything down once.
 static std::atomic<int64_t> g_host_exports{0};
+std::atomic<uint64_t> g_ind_upload_count{0};
 
 int structure_ensure_host(desc_structure* s) {
     if (!s || s->host_cycles) return DESC_OK;
     g_host_exports.fetch_add(1);
     const int64_t mc = s->m_cycle, mp = s->m_pos;
     DESC_HIP(hipSetDevice(s->dev));
+    if (s->ev_fill) {       // the sampled cycles come from a kernel on the builder's own stream: wait for it, and report ITS failure as such
+        const hipError_t ef = hipEventSynchronize((hipEvent_t)s->ev_fill);
+        if (ef != hipSuccess) return fail(DESC_ERR_HIP, "cycle sampling kernel failed: %s", hipGetErrorString(ef));
+    }
     DevBuf D;
     int rc;
     int32_t *d_ejk, *d_eki, *d_ikj, *d_jki;
@@ -603,7 +648,14 @@ int structure_ensure_host(desc_structure* s) {
 void structure_free_device(desc_structure* s) {
     if (!s || s->dev < 0) return;
     (void)hipSetDevice(s->dev);
-    if (s->ev_fill) { (void)hipEventSynchronize((hipEvent_t)s->ev_fill); (void)hipEventDestroy((hipEvent_t)s->ev_fill); s->ev_fill = nullptr; }
+    if (s->ev_fill) {
+        if (hipEventSynchronize((hipEvent_t)s->ev_fill) != hipSuccess)      // nobody consumed the cycles: say so at least
+            fprintf(stderr, "[desc_amd] the cycle-sampling kernel of a device-built structure failed: %s\n", hipGetErrorString(hipGetLastError()));
+        (void)hipEventDestroy((hipEvent_t)s->ev_fill); s->ev_fill = nullptr;
+    }
+    if (s->fill_stream) { stream_release((hipStream_t)s->fill_stream); s->fill_stream = nullptr; }
+    for (void* q : s->d_build_blocks) dev_free(q);
+    s->d_build_blocks.clear();
     for (void* q : {(void*)s->d_k, (void*)s->d_tau, (void*)s->d_ktau, (void*)s->d_rowptr, (void*)s->d_adj, (void*)s->d_adj_eid, (void*)s->d_ii,
                     (void*)s->d_jj, (void*)s->d_pos, (void*)s->d_cum, (void*)s->d_poe, (void*)s->d_bits, (void*)s->d_rank})
         dev_free(q);

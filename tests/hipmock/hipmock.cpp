@@ -73,6 +73,8 @@ hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if (n) std::m
 
 hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t)std::malloc(8); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+int hipGetStreamDeviceId(hipStream_t) { return 0; }      // hipCUB's host side asks (device scans of the structure builder)
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 64; return hipSuccess; }
 hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { return hipStreamCreate(s); }
 hipError_t hipStreamDestroy(hipStream_t s) { std::free((void*)s); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
