@@ -107,7 +107,7 @@ int pgd_create_with_rij(const desc_problem* prob, const double* d_rij, const des
 // CEMP.m:44-65 on the device: nsample cycles per edge-with-cycles, with replacement.  The four arrays are
 // hipMalloc'ed on `device` (caller frees); DESC_ERR_TOO_LARGE when a codegree exceeds the LDS staging budget.
 int build_cemp_samples_device(const desc_device_problem* dp, int32_t nsample, uint64_t seed, int64_t* m_pos,
-                              int32_t** d_pos, int32_t** d_k, int32_t** d_ejk, int32_t** d_eki);
+                              int32_t** o_pos, int32_t** o_k, int32_t** o_ejk, int32_t** o_eki, uint32_t** o_pk = nullptr, int32_t* o_max_deg = nullptr);
 // the desc_problem view of a device problem's host index copies (rij = NULL)
 inline desc_problem host_view(const desc_device_problem* dp) { return desc_problem{dp->n, dp->m, dp->ii.data(), dp->jj.data(), nullptr}; }
 int build_cemp_samples_host(const desc_problem* prob, int32_t nsample, uint64_t seed, hvec<int32_t>& pos_edge,

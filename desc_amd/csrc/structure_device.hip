@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_fill_cycles(const int32_t* pos_edge, co
 // draw t = CoInd[key(seed, e, t) mod codeg]; one wave per edge.
 __global__ __launch_bounds__(256) void k_cemp_samples(const int32_t* pos_edge, const int32_t* ind_i, const int32_t* ind_j,
                                                       const unsigned long long* bits, const uint32_t* rank, const int32_t* rowptr,
-                                                      const int32_t* adj_eid, int32_t* kk, int32_t* e_jk, int32_t* e_ki, int64_t m_pos,
+                                                      const int32_t* adj_eid, int32_t* kk, int32_t* e_jk, int32_t* e_ki, uint32_t* pk, int64_t m_pos,
                                                       int words, int nsample, uint64_t seed, int lds_cap) {
     extern __shared__ unsigned long long smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -273,9 +273,11 @@ __global__ __launch_bounds__(256) void k_cemp_samples(const int32_t* pos_edge, c
             const size_t wi = (size_t)i * words + (k >> 6), wj = (size_t)j * words + (k >> 6);
             const unsigned long long below = (1ull << (k & 63)) - 1ull;
             const int64_t c = l * nsample + t;
+            const int xi = (int)(rank[wi] + __popcll(bits[wi] & below)), xj = (int)(rank[wj] + __popcll(bits[wj] & below));     // idx_i(k), idx_j(k)
             kk[c] = k;
-            e_ki[c] = adj_eid[r0i + rank[wi] + __popcll(bits[wi] & below)];
-            e_jk[c] = adj_eid[r0j + rank[wj] + __popcll(bits[wj] & below)];
+            e_ki[c] = adj_eid[r0i + xi];
+            e_jk[c] = adj_eid[r0j + xj];
+            if (pk) pk[c] = (uint32_t)xi | (uint32_t)xj << 16;          // S({k,i}) / S({j,k}) inside the CSR-aligned rows i and j (csrc/cemp.hip)
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -550,10 +552,14 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
 }
 
 int build_cemp_samples_device(const desc_device_problem* dp, int32_t nsample, uint64_t seed, int64_t* m_pos,
-                              int32_t** o_pos, int32_t** o_k, int32_t** o_ejk, int32_t** o_eki) {
+                              int32_t** o_pos, int32_t** o_k, int32_t** o_ejk, int32_t** o_eki, uint32_t** o_pk, int32_t* o_max_deg) {
     const int64_t n = dp->n, m = dp->m;
     const int64_t words = (n + 63) / 64;
     *m_pos = 0; *o_pos = *o_k = *o_ejk = *o_eki = nullptr;
+    if (o_pk) *o_pk = nullptr;
+    int32_t max_deg = 0;
+    for (int64_t v = 0; v < n; ++v) max_deg = std::max(max_deg, dp->rowptr[v + 1] - dp->rowptr[v]);
+    if (o_max_deg) *o_max_deg = max_deg;
     if ((double)n * (double)words * 12.0 > 64.0 * 1073741824.0) return fail(DESC_ERR_TOO_LARGE, "adjacency bitmaps do not fit the device budget");
     DESC_HIP(hipSetDevice(dp->device));
     DevBuf D;
@@ -595,8 +601,10 @@ int build_cemp_samples_device(const desc_device_problem* dp, int32_t nsample, ui
         *out = (int32_t*)q;
         return DESC_OK;
     };
-    if ((rc = keep(o_pos, mp)) || (rc = keep(o_k, mc)) || (rc = keep(o_ejk, mc)) || (rc = keep(o_eki, mc))) {
+    const bool want_pk = o_pk != nullptr && max_deg < 65536;            // 16 bits per row position
+    if ((rc = keep(o_pos, mp)) || (rc = keep(o_k, mc)) || (rc = keep(o_ejk, mc)) || (rc = keep(o_eki, mc)) || (want_pk && (rc = keep((int32_t**)o_pk, mc)))) {
         for (int32_t** q : {o_pos, o_k, o_ejk, o_eki}) { if (*q) dev_free(*q); *q = nullptr; }
+        if (o_pk && *o_pk) { dev_free(*o_pk); *o_pk = nullptr; }
         return rc;
     }
     if (all_pos) hipLaunchKernelGGL(k_iota, dim3((unsigned)std::min<int64_t>(2048, (mp + 255) / 256)), dim3(256), 0, 0, *o_pos, mp);
@@ -606,7 +614,7 @@ int build_cemp_samples_device(const desc_device_problem* dp, int32_t nsample, ui
     const size_t lds = (size_t)4 * cap * 4;
     if (lds > 64 * 1024) DESC_HIP(hipFuncSetAttribute((const void*)k_cemp_samples, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_cemp_samples, dim3((unsigned)std::min<int64_t>(8192, (mp + 3) / 4)), dim3(256), lds, 0, *o_pos, d_ii, d_jj, d_bits, d_rank,
-                       d_rowptr, d_adj_eid, *o_k, *o_ejk, *o_eki, mp, (int)words, (int)nsample, seed, cap);
+                       d_rowptr, d_adj_eid, *o_k, *o_ejk, *o_eki, want_pk ? *o_pk : (uint32_t*)nullptr, mp, (int)words, (int)nsample, seed, cap);
     DESC_HIP(hipGetLastError());
     DESC_HIP(hipDeviceSynchronize());
     return DESC_OK;

@@ -28,3 +28,18 @@ def test_cemp_short_beta_vector_and_no_cycles():
     Ind = np.array([[1, 2], [2, 3], [3, 4]])
     R = np.repeat(np.eye(3)[:, :, None], 3, axis=2)
     assert np.array_equal(CEMP(Ind, R, dict(max_iter=3, reweighting=[1.0], nsample=10)), np.ones(3))
+
+
+@pytest.mark.parametrize("bi,jb", [(1, 32), (3, 32), (7, 50), (16, 40)])
+def test_cemp_tile_shapes_equal_plain_rounds(bi, jb, monkeypatch):
+    """The tile kernel of the rounds (CSR-aligned S, band rows in the LDS, j-block-major tiles) against the plain wave-per-edge kernel on the same
+    samples, for tile shapes whose bands straddle the j-blocks' ends: the same arithmetic in the same order, bit for bit (CEMP.m:107-128)."""
+    mo = Uniform_Topology(260, 0.5, 0.2, 0.1, "uniform", seed=9)
+    params = dict(max_iter=6, reweighting=2.0 ** np.arange(6), nsample=50, seed=5)
+    monkeypatch.setenv("DESC_DEBUG_CEMP_TILES", "0")
+    plain = CEMP(mo.Ind, mo.RijMat, params)
+    monkeypatch.setenv("DESC_DEBUG_CEMP_TILES", "1")
+    monkeypatch.setenv("DESC_DEBUG_CEMP_BI", str(bi))
+    monkeypatch.setenv("DESC_DEBUG_CEMP_JB", str(jb))
+    tiles = CEMP(mo.Ind, mo.RijMat, params)
+    assert np.array_equal(plain, tiles)
