@@ -154,7 +154,7 @@ def load_traffic(name):
     """HBM bytes per iteration from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the
     bench): FETCH_SIZE and WRITE_SIZE collected in separate runs, corrected as MI355X_MICROARCH.md prescribes
     (tools/pmc_traffic.py); null for workloads that have not been profiled."""
-    for fn in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for fn in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
                 t = json.load(f).get(name, {}).get("per_iteration_bytes")

@@ -514,7 +514,15 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
     // the block (the largest unwanted eigenvalue's estimate).  A plain power step (degree 1)
     // needs ~1/gap products when the top of the spectrum is clustered (GCW weights span many
     // orders of magnitude); the filter needs ~1/sqrt(gap).
+    // Round 4, tried and not adopted (profiles/r04_spectral_experiments.txt): (1) the degree of a pass chosen from the digits per product the
+    // previous pass achieved: 77 products instead of 52 at C4 -- what a pass gains is far from proportional to its degree (3e-2 -> 1.7e-6 with
+    // 16, -> 7e-3 with 8); (2) the lower end of the damped interval following the block's Ritz values (-2 |theta_6| instead of the norm bound
+    // -max degree, which lies ~20x below the bulk of the spectrum): the polynomial then grows > 1e8 faster on the three wanted directions than
+    // on the guard vectors, the Gram matrix of the filtered block is singular in double precision and the Cholesky-based orthogonalisation
+    // breaks down; it would need a QR (Householder) orthogonalisation of the 3n x 6 block on the device.
     constexpr int CHEB_DEG = 16;
+    const int cheb_deg = CHEB_DEG;
+    int deg_prev = 0;
     double *d_P, *d_Q;
     if ((rc = D.alloc(&d_P, rows * BW)) || (rc = D.alloc(&d_Q, rows * BW))) return rc;
     double theta[BW] = {}, Z[BW * BW], res = 1e300;
@@ -544,18 +552,21 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
             const double scale = std::max(std::fabs(theta[0]), sigma);
             for (int c = 0; c < 3; ++c) { double r2 = 0; for (int bb = 0; bb < ggrid; ++bb) r2 += part[(size_t)3 * bb + c]; res = std::max(res, std::sqrt(r2) / std::max(scale, 1e-300)); }
         }
+        if (timing) fprintf(stderr, "[desc_amd] spectral  outer %d: residual %.3e after %d products (last pass: degree %d)\n", it, res, products, deg_prev);
         if (res <= tol) { converged = true; break; }
+
         // ---- filter: P <- p(A) X with p small on [lo, cut], large above
         cut = theta[BW - 1];
         const double top = theta[0];
         if (!(cut > lo) || !(top > cut)) cut = lo + 0.5 * (top - lo);   // degenerate block: fall back to a mild filter
         const double e = 0.5 * (cut - lo), c = 0.5 * (cut + lo);
+        deg_prev = cheb_deg;
         double s_prev = e / (top - c);
         const double s1c = s_prev;
         // P = (A X - c X) * s_prev / e
         spmm(d_X, d_X, d_P, s_prev / e, -c * s_prev / e, 0.0);
         double* Xp = d_X; double* Pp = d_P; double* Qp = d_Q;  // X_{k-1}, X_k, scratch
-        for (int k = 2; k <= CHEB_DEG; ++k) {
+        for (int k = 2; k <= cheb_deg; ++k) {
             const double s_new = 1.0 / (2.0 / s1c - s_prev);
             // Q = (2 s_new / e) (A P - c P) - (s_prev s_new) X_{k-1}
             spmm(Pp, Xp, Qp, 2.0 * s_new / e, -2.0 * s_new * c / e, -s_prev * s_new);
