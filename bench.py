@@ -306,9 +306,26 @@ def dry_launch(args):
     t = torch.ones(1, dtype=torch.int64)
     dist.all_reduce(t)
     seen = int(t.item())
-    ok = seen == args.gpus == world
+    # the hand-over of the synthetic problem (rank 0 generates, the others map its arrays): every rank must end up with the same bytes,
+    # and only rank 0 may have run the generator
+    from desc_amd.sharded import TorchComm, shared_problem
+    calls = []
+
+    def gen(name):
+        calls.append(name)
+        return generate(name)
+
+    nn, ii, jj, rij, err = shared_problem("C1", rank, world, TorchComm(), gen)
+    digest = torch.tensor([float(nn), float(ii.sum()), float(jj.sum()), float(np.abs(rij).sum()), float(err.sum())], dtype=torch.float64)
+    lo, hi = digest.clone(), digest.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    ncalls = torch.tensor([len(calls)], dtype=torch.int64)
+    dist.all_reduce(ncalls)
+    shared_ok = bool(torch.equal(lo, hi)) and int(ncalls.item()) == 1 and len(calls) == (1 if rank == 0 else 0)
+    ok = seen == args.gpus == world and shared_ok
     if rank == 0:
-        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_counted": seen, "requested": args.gpus, "ok": ok}), flush=True)
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_counted": seen, "requested": args.gpus, "problem_shared": shared_ok,
+                          "generator_calls": int(ncalls.item()), "ok": ok}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
     return 0 if ok else 3

@@ -85,8 +85,17 @@ static hipError_t dev_alloc_impl(void** out, size_t bytes, bool uc) {
 void dev_free(void* p) {
     if (!p) return;
     // hipFree waits for the device before it releases a block; a parked block may be handed out again at once, so the same
-    // guarantee is kept here (idle device: microseconds)
+    // guarantee is kept here (idle device: microseconds) -- on the BLOCK's device, which need not be the thread's current one
+    int cur = 0, bdev = -1;
+    (void)hipGetDevice(&cur);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_live.find(p);
+        if (it != g_live.end()) bdev = it->second.dev;
+    }
+    if (bdev >= 0 && bdev != cur) (void)hipSetDevice(bdev);
     (void)hipDeviceSynchronize();
+    if (bdev >= 0 && bdev != cur) (void)hipSetDevice(cur);
     dev_free_idle(p);
 }
 void dev_free_idle(void* p) {
@@ -130,8 +139,8 @@ hipError_t stream_acquire(hipStream_t* out) {
 }
 void stream_release(hipStream_t s) {
     if (!s) return;
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess) {
+    int dev = hipGetStreamDeviceId(s);                // the stream's own device, not the thread's current one
+    if (dev >= 0) {
         std::lock_guard<std::mutex> lk(g_mu);
         if (g_streams.size() < 8) { g_streams.push_back(PooledStream{dev, s}); return; }
     } else (void)hipGetLastError();

@@ -514,15 +514,23 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
     // the block (the largest unwanted eigenvalue's estimate).  A plain power step (degree 1)
     // needs ~1/gap products when the top of the spectrum is clustered (GCW weights span many
     // orders of magnitude); the filter needs ~1/sqrt(gap).
-    // Round 4, tried and not adopted (profiles/r04_spectral_experiments.txt): (1) the degree of a pass chosen from the digits per product the
-    // previous pass achieved: 77 products instead of 52 at C4 -- what a pass gains is far from proportional to its degree (3e-2 -> 1.7e-6 with
-    // 16, -> 7e-3 with 8); (2) the lower end of the damped interval following the block's Ritz values (-2 |theta_6| instead of the norm bound
-    // -max degree, which lies ~20x below the bulk of the spectrum): the polynomial then grows > 1e8 faster on the three wanted directions than
-    // on the guard vectors, the Gram matrix of the filtered block is singular in double precision and the Cholesky-based orthogonalisation
-    // breaks down; it would need a QR (Householder) orthogonalisation of the 3n x 6 block on the device.
-    constexpr int CHEB_DEG = 16;
-    const int cheb_deg = CHEB_DEG;
-    int deg_prev = 0;
+    // Round 4 (profiles/r04_spectral_experiments.txt): the damped interval follows the spectrum instead of the norm bound.  lo = -sigma (max
+    // weighted degree) is safe, but for the graphs DESC meets it lies ~20x below the bulk of the spectrum (C4: -1100 against ~-57), and a
+    // Chebyshev polynomial scaled to [-1100, 57] grows only 4x per product at the wanted end (700) -- slower than the plain power method.
+    // After a first short pass with the safe bound the block's own Ritz values estimate the bulk: lo = -2 max(|theta_4|, |theta_6|), never above
+    // -2 % of sigma.  An eigenvalue below that is amplified too, but far less than the wanted ones, and Rayleigh-Ritz keeps it out of the top
+    // three; should the block drift to the negative end all the same (theta_6 <= lo, or the residual stops falling) the safe bound comes back
+    // for the rest of the call.  The degree of a pass is what takes the residual to 0.2 tol -- T_d((theta_3 - c) / e) >= res / (0.2 tol) -- but
+    // never more than what amplifies the wanted directions 1e6 times over the guard vectors: beyond ~1e8 the Gram matrix of the filtered
+    // 3n x 6 block is singular in double precision and the Cholesky-based orthogonalisation breaks down (the first form of this change did).
+    // Also tried: the degree from the digits per product of the previous pass -- 77 products instead of 52, a pass's gain is not proportional
+    // to its degree.  DESC_DEBUG_SPECTRAL_TIGHT=0: round 3's fixed scheme (three passes of degree 16 at C4: 52 products).
+    constexpr int CHEB_DEG = 16, CHEB_MIN = 2;
+    const int CHEB_FIRST = [] { const char* v = std::getenv("DESC_DEBUG_SPECTRAL_FIRST"); return v ? std::max(2, std::atoi(v)) : 8; }();      // degree of the first pass (safe bound)
+    const bool tight = [] { const char* v = std::getenv("DESC_DEBUG_SPECTRAL_TIGHT"); return v ? std::atoi(v) != 0 : true; }();
+    bool tight_ok = tight;
+    int cheb_deg = tight ? CHEB_FIRST : CHEB_DEG, deg_prev = 0;
+    double res_prev = -1.0;
     double *d_P, *d_Q;
     if ((rc = D.alloc(&d_P, rows * BW)) || (rc = D.alloc(&d_Q, rows * BW))) return rc;
     double theta[BW] = {}, Z[BW * BW], res = 1e300;
@@ -535,7 +543,7 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
         else hipLaunchKernelGGL(k_bsr_spmm<64>, dim3(sgrid), dim3(256), 0, 0, d_rowptr, d_adj, d_blocks, (int64_t)2 * m, x, z, y, (int)n, alpha, s1, s2);
         ++products;
     };
-    const double lo = -sigma;
+    double lo = -sigma;
     double cut = 0.0;                                         // set after the first Rayleigh-Ritz
     for (it = 1; it <= max_iters; ++it) {
         // ---- Rayleigh-Ritz on the current orthonormal basis X
@@ -558,9 +566,21 @@ static int spectral_impl(const desc_device_problem* dp, const double* weights, c
         // ---- filter: P <- p(A) X with p small on [lo, cut], large above
         cut = theta[BW - 1];
         const double top = theta[0];
+        if (tight_ok && it >= 2) {
+            if (theta[BW - 1] <= lo || (res_prev > 0.0 && res > res_prev)) { lo = -sigma; tight_ok = false; }          // drifting to the negative end: the safe bound
+            else lo = std::max(-sigma, -std::max(2.0 * std::max(std::fabs(theta[3]), std::fabs(theta[BW - 1])), 0.02 * sigma));
+        }
         if (!(cut > lo) || !(top > cut)) cut = lo + 0.5 * (top - lo);   // degenerate block: fall back to a mild filter
         const double e = 0.5 * (cut - lo), c = 0.5 * (cut + lo);
-        deg_prev = cheb_deg;
+        if (tight && it >= 2) {
+            const double xi3 = (theta[2] - c) / e;
+            cheb_deg = CHEB_DEG;
+            if (xi3 > 1.0 + 1e-6 && res > 0.0) {
+                const double want = std::acosh(std::max(2.0, res / (0.2 * tol))), cap = std::acosh(1e6);
+                cheb_deg = (int)std::max<double>(CHEB_MIN, std::min<double>(CHEB_DEG, std::ceil(std::min(want, cap) / std::acosh(xi3))));
+            }
+        }
+        res_prev = res; deg_prev = cheb_deg;
         double s_prev = e / (top - c);
         const double s1c = s_prev;
         // P = (A X - c X) * s_prev / e

@@ -89,6 +89,7 @@ def test_bench_starts_its_own_ranks():
     assert len(lines) == 1, r.stdout                      # exactly one JSON line, from rank 0
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["ranks_counted"] == 2 and rec["ok"] is True
+    assert rec["problem_shared"] is True and rec["generator_calls"] == 1      # rank 0 generated, rank 1 mapped the same arrays
     # launched with the wrong number of ranks (torchrun-style environment of ONE rank, --gpus 2): refuses
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"],
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=root,
