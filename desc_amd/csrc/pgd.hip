@@ -1072,11 +1072,24 @@ __device__ __forceinline__ void finalize_wave(const FinArgs f) {
     DevState* st = f.st;
     if (f.t <= 0 || st->stop) return;          // t == 0: no sweep to book-keep
     const int lane = threadIdx.x & 63;
-    // every lane adds its strided share in index order, then the fixed DPP butterfly
+    // Every lane adds its strided share of the (rank, index) pairs in that order -- the same sum on every rank --, then the fixed DPP butterfly.
+    // Eight pairs are loaded before any is added: one at a time the 8 x 1024 pairs of a world-8 run were 128 dependent round trips, ~90 us,
+    // and WERE the duration of k_unpack_S (round 4: a tile-ordered unpack changed nothing, profiles/r04_shard_w8_c4_unpack*.json).
     double o = 0.0, ch = 0.0;
-    for (int r = 0; r < max(f.nranks, 1); ++r) {      // rank order, then index order: the same sum on every rank
-        const double* q = f.partials + (int64_t)r * f.rank_stride;
-        for (int i = lane; i < f.nparts; i += 64) { o += q[2 * i]; ch += q[2 * i + 1]; }
+    const int E = max(f.nranks, 1) * f.nparts;
+    for (int base = lane; base < E; base += 64 * 8) {
+        double vo[8], vc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + 64 * u;
+            vo[u] = 0.0; vc[u] = 0.0;
+            if (idx < E) {
+                const double* q = f.partials + (int64_t)(idx / f.nparts) * f.rank_stride + 2 * (int64_t)(idx % f.nparts);
+                vo[u] = q[0]; vc[u] = q[1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { o += vo[u]; ch += vc[u]; }
     }
     o = group_sum<64>(o); ch = group_sum<64>(ch);
     if (lane != 0) return;
@@ -1635,8 +1648,10 @@ __global__ __launch_bounds__(256) void k_unpack_S(const int32_t* spos, int64_t n
     // once the stop rule has fired the slices hold the discarded sweep: the double buffers must keep the final iterate
     if (fin.st->stop || !S_a) return;
     // every CSR slot from its place in the gathered slices: coalesced writes; reads contiguous for the larger-neighbour half of a row
-    // (four independent position -> value chains in flight per thread: one at a time the pass ran at 60 G slots/s, latency-bound --
-    //  83 us for the 5 M slots of C4, profiles/r04_shard_w8_c4_before.json)
+    // (four independent position -> value chains in flight per thread.  Round 4, rocprofv3 over the eight emulated ranks of C4 on one card,
+    //  profiles/r04_shard_w8_c4_rocprof.txt: 73 us on average but 35 us at best -- the eight ranks' tables (8 x 80 MB) evict each other from the
+    //  256 MB Infinity Cache between a rank's turns, which a rank on its own GPU does not suffer.  A tile-ordered form -- slots visited
+    //  (tile of source nodes)-major so that the gathered values stay in the L2 -- measured 81 us on average, 53 at best: not adopted.)
     const int64_t stride = (int64_t)(gridDim.x - 1) * 256;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nslots; t += 4 * stride) {
         int32_t q[4]; double v[4];
