@@ -98,6 +98,22 @@ with torch.cuda.stream(stream):
     outs = [s.download() for s in shards]
 torch.cuda.synchronize()
 us = {k: [float(np.mean([a.elapsed_time(b) for a, b in ev[k][r]])) * 1e3 for r in range(world)] for k in pieces}
+# Second timing, one rank at a time WITHOUT the others in between: in the loop above the eight ranks' tables (8 x ~1 GB) evict each other from the
+# 256 MB Infinity Cache between a rank's turns, which a rank alone on its own GPU does not suffer.  The exchange buffers keep the last iteration's
+# content (the arithmetic is the same; the results of this phase are discarded).
+ev2 = {k: [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)] for _ in range(world)] for k in pieces}
+p2 = lib.default_params(); p2.iters = W + K + 4; p2.lr = 0.01; p2.patience = (1 << 31) - 1; p2.seed = 0
+with torch.cuda.stream(stream):
+    for r, s in enumerate(shards):
+        s.reset(p2); s.finish(1); s.finish(2)
+        for it in range(W + K):
+            k = it - W
+            for name, call in (("colsum", s.colsum), ("sweep", s.sweep), ("unpack", lambda: s.finish(0))):
+                if k >= 0: ev2[name][r][k][0].record(stream)
+                call()
+                if k >= 0: ev2[name][r][k][1].record(stream)
+torch.cuda.synchronize()
+us_alone = {k: [float(np.mean([a.elapsed_time(b) for a, b in ev2[k][r]])) * 1e3 for r in range(world)] for k in pieces}
 for o in outs[1:]:
     assert np.array_equal(o["S_vec"], outs[0]["S_vec"]) and np.array_equal(o["obj"], outs[0]["obj"])
 ranks = []
@@ -106,7 +122,8 @@ for r, s in enumerate(shards):
     ranks.append(dict(rank=r, cycles=int(s.info.cyc_hi - s.info.cyc_lo), segments=int(s.info.seg_hi - s.info.seg_lo), pieces=lay["pieces"],
                       colsum_entries=lay["colsum_entries"], band_row_entries_per_sweep=lay["piece_row_entries"],
                       hbm_bytes=int(foot[r]), sweep_kernel=s.solver.last_sweep(),
-                      us_colsum=us["colsum"][r], us_sweep=us["sweep"][r], us_unpack=us["unpack"][r]))
+                      us_colsum=us["colsum"][r], us_sweep=us["sweep"][r], us_unpack=us["unpack"][r],
+                      us_colsum_alone=us_alone["colsum"][r], us_sweep_alone=us_alone["sweep"][r], us_unpack_alone=us_alone["unpack"][r]))
 for s in shards: s.destroy()
 
 
@@ -120,14 +137,16 @@ out = dict(
     workload=bench.describe(args.workload), world=world, steps=K, warmup=W, n=nn, m=m, m_cycle=int(sum(x["cycles"] for x in ranks)),
     one_gpu=dict(kernel=solo_name, us_kernel_pair=ms_pair * 1e3, layout=solo_lay),
     ranks=ranks,
-    balance={k: stat(k) for k in ("cycles", "us_colsum", "us_sweep", "us_unpack", "hbm_bytes")},
+    balance={k: stat(k) for k in ("cycles", "us_colsum", "us_sweep", "us_unpack", "us_colsum_alone", "us_sweep_alone", "us_unpack_alone", "hbm_bytes")},
     compute_us_max_over_ranks=float(max(x["us_colsum"] + x["us_sweep"] + x["us_unpack"] for x in ranks)),
+    compute_us_max_over_ranks_alone=float(max(x["us_colsum_alone"] + x["us_sweep_alone"] + x["us_unpack_alone"] for x in ranks)),
     exchange=dict(
         reduce_scatter=dict(elements_per_rank_part=int(Lp), bytes_sent_per_rank=int(8 * Lp * (world - 1)), bytes_received_per_rank=int(8 * Lp * (world - 1)),
                             what="partial mirror sums T1 | T2 (DESC_PGD.m:189-190) of every other rank's edges out, the other ranks' partials of this rank's edges in"),
         all_gather=dict(slice_len=int(L), bytes_sent_per_rank=int(8 * L * (world - 1)), bytes_received_per_rank=int(8 * L * (world - 1)),
                         what="new S of the owned edges (DESC_PGD.m:229) + the workgroup partials of the objective / |dS| sums")),
     checks=dict(ranks_bitwise_equal=True, mean_abs_err_vs_truth=float(np.mean(np.abs(outs[0]["S_vec"] - mo.ErrVec)))),
-    note="per-rank times measured one rank at a time on ONE MI355X (a rank alone on the card = that rank on its own GPU); collectives emulated by hand and not timed",
+    note="per-rank times measured on ONE MI355X: us_* in a faithful loop over all ranks (their tables evict each other from the Infinity Cache between turns), "
+         "us_*_alone with one rank iterating by itself (closer to that rank on its own GPU); collectives emulated by hand and not timed",
 )
 print(json.dumps(out, indent=1))
