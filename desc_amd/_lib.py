@@ -76,7 +76,7 @@ class Result(C.Structure):
 class ShardInfo(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("t_len", C.c_int64), ("t_part", C.c_int64), ("slice_len", C.c_int64),
                 ("seg_lo", C.c_int64), ("seg_hi", C.c_int64), ("cyc_lo", C.c_int64), ("cyc_hi", C.c_int64),
-                ("m_pos", C.c_int64), ("m_cycle", C.c_int64)]
+                ("m_pos", C.c_int64), ("m_cycle", C.c_int64), ("xparts", C.c_int32), ("reserved", C.c_int32)]
 
 
 RS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)     # ncclReduceScatter

@@ -10,7 +10,7 @@ namespace desc {
 
 // row_cap > 0: bands = maximal runs of consecutive nodes whose CSR rows hold <= row_cap entries together (the band
 // sweep keeps them in the LDS); row_cap == 0: bands of a fixed number of nodes sized for the L2 (k_sweep_node).
-int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_deg, int world, int max_seg, int row_cap, NodePlan& P) {
+int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_deg, int world, int max_seg, int row_cap, NodePlan& P, int xparts) {
     const int64_t mp = s->m_pos, n = prob->n, m = prob->m;
     const bool timing = env_int("DESC_DEBUG_TIMING", 0) > 1;
     auto t_lap = std::chrono::steady_clock::now();
@@ -85,6 +85,8 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
     P.rank_node[0] = 0;
     cut_seg.assign((size_t)world + 1, mp);
     cut_seg[0] = 0;
+    hvec<int64_t> cut_band((size_t)world + 1, nb);            // band index of every rank's first band
+    cut_band[0] = 0;
     if (world > 1) {
         const int64_t total = P.cum2[mp];
         int64_t b = 0;
@@ -94,10 +96,35 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
             if (b > 0 && b <= nb && want - (int64_t)P.cum2[P.bstart[b - 1]] < (int64_t)P.cum2[P.bstart[std::min(b, nb)]] - want && P.bstart[b - 1] > cut_seg[r - 1]) --b;
             const int64_t bb = std::min(b, nb);
             cut_seg[r] = std::max<int64_t>(P.bstart[bb], cut_seg[r - 1]);
+            cut_band[r] = std::max<int64_t>(bb, cut_band[r - 1]);
             P.rank_node[r] = bb < nb ? P.band_lo[bb] : (int32_t)n;
             if (P.rank_node[r] < P.rank_node[r - 1]) P.rank_node[r] = P.rank_node[r - 1];
         }
     }
+    // exchange parts of every rank: whole bands again, cut where the cycles of the rank split most evenly
+    P.xparts = std::max(1, xparts);
+    P.vnode.assign((size_t)world * P.xparts + 1, (int32_t)n);
+    P.vseg.assign((size_t)world * P.xparts + 1, mp);
+    for (int r = 0; r < world; ++r) {
+        const int64_t b0 = cut_band[r], b1 = cut_band[r + 1];
+        const int64_t c0 = P.cum2[P.bstart[b0]], c1 = P.cum2[P.bstart[b1]];
+        int64_t b = b0;
+        for (int c = 0; c < P.xparts; ++c) {
+            if (c > 0) {
+                const int64_t want = c0 + (c1 - c0) * c / P.xparts;
+                while (b < b1 && (int64_t)P.cum2[P.bstart[b]] < want) ++b;
+                if (b > b0 && want - (int64_t)P.cum2[P.bstart[b - 1]] < (int64_t)P.cum2[P.bstart[b]] - want && b - 1 >= b0) --b;     // the nearer boundary
+            }
+            P.vnode[(size_t)r * P.xparts + c] = b < nb ? P.band_lo[b] : (int32_t)n;
+            P.vseg[(size_t)r * P.xparts + c] = P.bstart[b];
+        }
+    }
+    for (size_t t = 1; t < P.vnode.size(); ++t) {             // monotone (empty ranks / parts collapse)
+        if (P.vnode[t] < P.vnode[t - 1]) P.vnode[t] = P.vnode[t - 1];
+        if (P.vseg[t] < P.vseg[t - 1]) P.vseg[t] = P.vseg[t - 1];
+    }
+    // (the first part of a rank starts where the rank starts)
+    for (int r = 0; r < world; ++r) { P.vnode[(size_t)r * P.xparts] = P.rank_node[r]; P.vseg[(size_t)r * P.xparts] = cut_seg[r]; }
     P.chunk_seg.clear();
     P.chunk_seg.push_back(0);
     P.rank_chunk.assign((size_t)world + 1, 0);
@@ -128,7 +155,7 @@ int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_de
 //    that at any moment all workgroups gather from the same block of rows.
 // Host only: no device call (also reachable through desc_debug_band_plan, which the CPU tests and sanitizer builds use).
 void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const NodePlan& P, int64_t seg_lo, int64_t seg_hi, int64_t cyc_lo, int64_t mcl,
-                      int G, hvec<PieceDesc>& pieces, hvec<int32_t>& piece_ptr, int& band_rows, bool& jmajor_out, int* tail_first_out, int* n_tail_out) {
+                      int G, hvec<PieceDesc>& pieces, hvec<int32_t>& piece_ptr, int& band_rows, bool& jmajor_out, int* tail_first_out, int* n_tail_out, int max_tail) {
     const hvec<int32_t>& cum2 = P.cum2;
     const int64_t n = prob->n, m = prob->m;
     const bool timing = env_int("DESC_DEBUG_TIMING", 0) > 1;
@@ -245,7 +272,7 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
             //    kernel and 1.5-4 % in the queue: C4 996-1014 -> 984-999 us, C5 1585-1596 -> 1569-1580 (about -1 %, profiles/r03_piece_cost.txt):
             //    2 % is the default.
             const int64_t tail_target = tail_first_out ? mcl * std::max(0, std::min(500, env_int("DESC_DEBUG_TAIL", 20))) / 1000 : 0;
-            const int64_t tail_cap = std::max<int64_t>(4096, tail_target / (MAX_TAIL_PIECES - 64));
+            const int64_t tail_cap = std::max<int64_t>(4096, tail_target / std::max(1, max_tail - 64));
             const int64_t fit_from = mcl - mcl * std::max(0, std::min(500, env_int("DESC_DEBUG_FIT", 0))) / 1000;
             int64_t fit_target = -1;                         // common final load, fixed when the fitting phase starts
             int64_t dealt = 0;
@@ -261,7 +288,7 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
                     while (lo < e) {
                         int64_t x = reach(lo, e, cap);
                         if (x == lo) x = lo + 1;
-                        if (tail_target > 0 && dealt >= mcl - tail_target && (int64_t)tail.size() < MAX_TAIL_PIECES) {      // the rest of the sweep: queue
+                        if (tail_target > 0 && dealt >= mcl - tail_target && (int64_t)tail.size() < max_tail) {      // the rest of the sweep: queue
                             x = reach(lo, e, tail_cap);
                             if (x == lo) x = lo + 1;
                             tail.push_back(piece_of(bd, lo, x));

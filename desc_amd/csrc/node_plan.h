@@ -41,14 +41,21 @@ struct NodePlan {
     hvec<int32_t> chunk_seg;   // nchunks+1
     hvec<int64_t> rank_chunk;  // world+1
     hvec<int32_t> rank_node;   // world+1: rank r owns the nodes [rank_node[r], rank_node[r+1]) -- whole bands -- and the segments whose smaller endpoint they are
+    // Exchange parts (round 4): every rank's node range is cut once more into `xparts` sub-ranges of whole bands with about equal cycles.  The pair
+    // (rank r, part c) is a virtual owner vo = r * xparts + c of the exchange layout: the reduce-scatter of the mirror sums runs part by part, part
+    // c + 1 travels while part c is swept.  vnode / vseg: first node / first device-order segment of every virtual owner, + the end.
+    int xparts = 1;
+    hvec<int32_t> vnode;       // world * xparts + 1
+    hvec<int64_t> vseg;        // world * xparts + 1
 };
 
 // row_cap > 0: bands = maximal runs of consecutive nodes whose CSR rows hold <= row_cap entries together (the band
 // sweep keeps them in the LDS); row_cap == 0: bands of a fixed number of nodes sized for the L2 (k_sweep_node).
-int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_deg, int world, int max_seg, int row_cap, NodePlan& P);
+int make_node_plan(const desc_problem* prob, const desc_structure* s, int max_deg, int world, int max_seg, int row_cap, NodePlan& P, int xparts = 1);
 // the work of every workgroup of the band sweep as a list of pieces (see node_plan.cpp)
 void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const NodePlan& P, int64_t seg_lo, int64_t seg_hi, int64_t cyc_lo, int64_t mcl,
-                      int G, hvec<PieceDesc>& pieces, hvec<int32_t>& piece_ptr, int& band_rows, bool& jmajor_out, int* tail_first_out = nullptr, int* n_tail_out = nullptr);
+                      int G, hvec<PieceDesc>& pieces, hvec<int32_t>& piece_ptr, int& band_rows, bool& jmajor_out, int* tail_first_out = nullptr, int* n_tail_out = nullptr,
+                      int max_tail = MAX_TAIL_PIECES);
 // LDS budget of a band's rows (DESC_DEBUG_ROW_CAP shrinks it for tests)
 int band_row_cap(int max_deg);
 

@@ -1203,7 +1203,7 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
                                                      const int2* node_run, int n_long, int copies, double fx_scale) {
     if (blockIdx.x == gridDim.x - 1) {
         if (threadIdx.x < 64 && fin.st) finalize_wave(fin);
-        if (threadIdx.x == 0 && tail_ticket) *tail_ticket = 0;          // the sweep that follows hands out its tail pieces from 0
+        if (threadIdx.x < 8 && tail_ticket) tail_ticket[threadIdx.x] = 0;      // the sweep launches that follow (one per exchange part) hand out their tail pieces from 0
         return;
     }
     if (st->stop) return;
@@ -1539,39 +1539,44 @@ __global__ __launch_bounds__(256) void k_node_runs(const int32_t* rowptr, const 
     runs[v] = run;
 }
 __device__ __forceinline__ int owner_of_node(const int32_t* node_lo, int world, int v) { int r = 0; while (r + 1 < world && v >= node_lo[r + 1]) ++r; return r; }
-// xpos[t]: where the column sum of CSR slot t = (v, u) goes in the send buffer; spos[t]: where S of edge {v, u} sits in the gathered slices
+// Exchange parts (round 4): the owners of the layout are VIRTUAL -- vo = rank * xparts + part, node ranges node_lo[vo .. vo + 1), nv = world * xparts of
+// them -- and the send buffer is part-major: block (part * world + rank) holds [T1 | T2] of that virtual owner's edges, so that the reduce-scatter of
+// part c is ONE collective over the contiguous blocks [c * world, (c + 1) * world) and can travel while part c - 1 is swept.  xparts = 1: round 3's layout.
+__device__ __forceinline__ int xblock_of(int vo, int xparts, int world) { return (vo % xparts) * world + vo / xparts; }
+// xpos[t]: where the column sum of CSR slot t = (v, u) goes in the send buffer; spos[t]: where S of edge {v, u} sits in the gathered slices (per REAL rank)
 __global__ __launch_bounds__(256) void k_xpos(const int32_t* rowptr, const int32_t* adj, const int32_t* adj_eid, const int32_t* node_lo, const int32_t* e_lo,
-                                              const int32_t* prefB, int world, int64_t t_part, int64_t slice_len, int32_t* xpos, int32_t* spos, int n) {
+                                              const int32_t* prefB, int nv, int xparts, int world, int64_t t_part, int64_t slice_len, int32_t* xpos, int32_t* spos, int n) {
     const int l16 = threadIdx.x & 15;
     const int row0 = (blockIdx.x * 256 + threadIdx.x) >> 4, nrows = (gridDim.x * 256) >> 4;
     const int64_t t_half = t_part / 2;
     for (int v = row0; v < n; v += nrows) {
         const int r0 = rowptr[v], r1 = rowptr[v + 1];
-        const int rv = owner_of_node(node_lo, world, v);
+        const int ov = owner_of_node(node_lo, nv, v);
         for (int t = r0 + l16; t < r1; t += 16) {
             const int u = adj[t], e = adj_eid[t];
             if (u > v) {                                         // T1 of edge (v, u); S of the edge: both with the owner of v
-                xpos[t] = (int32_t)((int64_t)rv * t_part + (e - e_lo[rv]));
-                spos[t] = (int32_t)((int64_t)rv * slice_len + (e - e_lo[rv]));
+                xpos[t] = (int32_t)((int64_t)xblock_of(ov, xparts, world) * t_part + (e - e_lo[ov]));
+                spos[t] = (int32_t)((int64_t)(ov / xparts) * slice_len + (e - e_lo[(ov / xparts) * xparts]));
             } else {                                             // column u of node v = T2 of edge (u, v), owned by the owner of u
-                const int ru = owner_of_node(node_lo, world, u);
-                const int first = nbrs_below(adj, r0, r1, node_lo[ru]);          // first smaller neighbour of v that ru owns
-                xpos[t] = (int32_t)((int64_t)ru * t_part + t_half + prefB[(int64_t)ru * n + v] + ((t - r0) - first));
-                spos[t] = (int32_t)((int64_t)ru * slice_len + (e - e_lo[ru]));
+                const int ou = owner_of_node(node_lo, nv, u);
+                const int first = nbrs_below(adj, r0, r1, node_lo[ou]);          // first smaller neighbour of v that ou owns
+                xpos[t] = (int32_t)((int64_t)xblock_of(ou, xparts, world) * t_part + t_half + prefB[(int64_t)ou * n + v] + ((t - r0) - first));
+                spos[t] = (int32_t)((int64_t)(ou / xparts) * slice_len + (e - e_lo[(ou / xparts) * xparts]));
             }
         }
     }
 }
-// {ta, tb} of the segments this rank owns (device order): positions of their T1 / T2 in its part of the exchange buffer
+// {ta, tb} of the segments this rank owns (device order): positions of their T1 / T2 inside the block of their virtual owner (= inside the part's
+// reduce-scattered sums); ta + (first edge of the part - first edge of the rank) is the segment's place in the rank's all-gather slice
 __global__ __launch_bounds__(256) void k_xt(const int32_t* pos_edge2, const EdgeInfo* einfo, const int32_t* ind_i, const int32_t* ind_j, const int32_t* rowptr,
-                                            const int32_t* adj, const int32_t* node_lo, const int32_t* e_lo, const int32_t* prefB, int rank, int64_t t_half,
+                                            const int32_t* adj, const int32_t* node_lo, const int32_t* e_lo, const int32_t* prefB, int nv, int64_t t_half,
                                             int seg_lo, int seg_hi, int2* xt, int n) {
     for (int q = seg_lo + blockIdx.x * 256 + threadIdx.x; q < seg_hi; q += gridDim.x * 256) {
-        const int e = pos_edge2[q], j = ind_j[e];
+        const int e = pos_edge2[q], i = ind_i[e], j = ind_j[e];
+        const int vo = owner_of_node(node_lo, nv, i);
         const int r0 = rowptr[j], r1 = rowptr[j + 1];
-        const int first = nbrs_below(adj, r0, r1, node_lo[rank]);
-        xt[q] = int2{e - e_lo[rank], (int)(t_half + prefB[(int64_t)rank * n + j] + ((einfo[q].slot_b - r0) - first))};
-        (void)ind_i;
+        const int first = nbrs_below(adj, r0, r1, node_lo[vo]);
+        xt[q] = int2{e - e_lo[vo], (int)(t_half + prefB[(int64_t)vo * n + j] + ((einfo[q].slot_b - r0) - first))};
     }
 }
 
@@ -1748,6 +1753,7 @@ struct desc_pgd {
     desc_collectives coll{};            // fused protocol: the caller's collectives (RCCL entry points + communicator)
     hipStream_t comm_stream = nullptr;  // second stream: exchange + unpack overlap the next column-sum pass
     hipEvent_t ev_col = nullptr, ev_rs = nullptr, ev_sw = nullptr, ev_ag = nullptr;
+    StepArgs cur_step{}; bool cur_adam = false;      // sharded sweeps: the step of the sweep in progress (its exchange parts are separate launches)
     int unpack_pending = 0;             // fused protocol: sweep whose all-gathered S still has to be unpacked (on the compute stream, behind ev_ag)
     bool own_xbuf = false, force_coll = false;
     hvec<int64_t> rank_seg;      // world+1 segment boundaries
@@ -1756,7 +1762,12 @@ struct desc_pgd {
     int32_t* d_xpos = nullptr;          // 2m: CSR slot -> position of its column sum in x_T (k_xpos)
     int32_t* d_spos = nullptr;          // 2m: CSR slot -> position of its edge's S in the gathered slices x_sall
     int2* d_xt = nullptr;               // m_pos (device order; owned segments filled): {ta, tb} = places of T1 / T2 in x_Trecv, ta also in the slice
-    int64_t t_part = 0;
+    int64_t t_part = 0;                 // words per block of the exchange layout (one block per virtual owner = (rank, part))
+    int xparts = 1;                     // exchange parts per rank (NodePlan::xparts): one reduce-scatter and one sweep launch each
+    hvec<int64_t> xseg;                 // xparts + 1: device-order segment boundaries of this rank's parts
+    hvec<int64_t> xslice_off;           // xparts: first edge of the part - first edge of the rank (offset of the part's S in the rank's slice)
+    hvec<int> xpiece_base, xpiece_ptr_base, xtail_first, xntail;      // per part: where its pieces / piece_ptr start in d_pieces / d_piece_ptr, its shared tail
+    hipEvent_t ev_rsx[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // fused protocol: reduce-scatter of part c done
     double* x_sall = nullptr;           //   world * slice_len
     bool borrowed_stream = false, objective_done = false;
     int last_parts = 0;                 // workgroup partials the last sharded sweep wrote
@@ -1819,6 +1830,7 @@ void free_all(desc_pgd* h) {
     (void)hipDeviceSynchronize();                              // once for all blocks and both streams (dev_free would wait per block)
     for (void* q : h->allocs) dev_free_idle(q);
     for (hipEvent_t e : {h->ev_col, h->ev_rs, h->ev_sw, h->ev_ag}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_rsx) if (e) (void)hipEventDestroy(e);
     stream_release(h->comm_stream);
     if (!h->borrowed_stream) stream_release(h->stream);
     delete h;
@@ -1925,9 +1937,11 @@ void launch_band_shape(desc_pgd* h, const BandSweepArgs& b) {
     else hipLaunchKernelGGL((k_sweep_band<LPS, E, STEP, NT, false>), dim3(h->band_grid), dim3(NT), h->band_lds, h->stream, b);
 }
 template <int STEP>
-void launch_band(desc_pgd* h, const NodeSweepArgs& a) {
+void launch_band(desc_pgd* h, const NodeSweepArgs& a, int part = 0) {
     const BandShape sh = band_shape(h, STEP == DESC_STEP_HYBRID);
-    BandSweepArgs b{a, h->d_pieces, h->d_piece_ptr, h->band_rows, h->d_wg_clock, h->band_tail_first, h->band_ntail, h->d_ticket};
+    // the plan of exchange part `part` (one-rank handles: the only one)
+    BandSweepArgs b{a, h->d_pieces + h->xpiece_base[part], h->d_piece_ptr + h->xpiece_ptr_base[part], h->band_rows, h->d_wg_clock, h->xtail_first[part], h->xntail[part],
+                    h->d_ticket + part};
     if constexpr (STEP == DESC_STEP_HYBRID) {
         switch (sh.lps * 8 + sh.E) {
             case 16 * 8 + 1: launch_band_shape<16, 1, STEP, 512>(h, b); break;
@@ -1945,9 +1959,9 @@ void launch_band(desc_pgd* h, const NodeSweepArgs& a) {
         }
     }
 }
-void launch_sweep_node_layout(desc_pgd* h, const NodeSweepArgs& a, bool adam) {
-    if (h->band_ok && !adam) launch_band<DESC_STEP_CONSTANT>(h, a);
-    else if (adam && band_adam_ok(h)) launch_band<DESC_STEP_HYBRID>(h, a);
+void launch_sweep_node_layout(desc_pgd* h, const NodeSweepArgs& a, bool adam, int part = 0) {
+    if (h->band_ok && !adam) launch_band<DESC_STEP_CONSTANT>(h, a, part);
+    else if (adam && band_adam_ok(h)) launch_band<DESC_STEP_HYBRID>(h, a, part);
     else if (adam) launch_node<DESC_STEP_HYBRID>(h, a);
     else launch_node<DESC_STEP_CONSTANT>(h, a);
 }
@@ -2147,7 +2161,11 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     const int force_band = env_int("DESC_DEBUG_VARIANT", 0);
     h->band_ok = force_band != VARIANT_NODE && h->max_cnt <= MAX_SEG_CYCLES && h->max_deg <= BAND_ROW_CAP && (h->m_cycle >= (2 << 20) || force_band == 3) &&
                  (int64_t)2 * m * 8 < (1ll << 32);          // 32-bit byte offsets into the CSR-aligned arrays (buffer instructions): m < 2.7e8 edges
-    if ((rc = make_node_plan(prob, s, h->max_deg, h->world, h->max_cnt <= 32 ? 32 : h->max_cnt <= 128 ? 16 : 8, h->band_ok ? band_row_cap(h->max_deg) : 0, P))) return rc;   // 8 waves x 64/lps segments
+    // exchange parts: the reduce-scatter of part c + 1 travels while part c is swept (band sweep only; DESC_SHARD_PARTS overrides, 1 = one reduce-scatter)
+    // (segments of up to 64 cycles: every step plugin then runs on the band sweep; longer ones fall back to k_sweep_node for Adam, which sweeps in one launch)
+    const int xparts = (h->world > 1 && h->band_ok && h->max_cnt <= 64) ? std::max(1, std::min(8, env_int("DESC_SHARD_PARTS", 2))) : 1;
+    if ((rc = make_node_plan(prob, s, h->max_deg, h->world, h->max_cnt <= 32 ? 32 : h->max_cnt <= 128 ? 16 : 8, h->band_ok ? band_row_cap(h->max_deg) : 0, P, xparts))) return rc;   // 8 waves x 64/lps segments
+    h->xparts = P.xparts;
     h->band = P.band;
     lap("plan");
     const hvec<int32_t>& cum2 = P.cum2;
@@ -2159,16 +2177,23 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     h->rank_seg.assign((size_t)h->world + 1, 0);
     int64_t max_local = 0;
     for (int r = 0; r <= h->world; ++r) h->rank_seg[r] = P.chunk_seg[P.rank_chunk[r]];
-    // exchange layout (k_xpos): a rank owns the edges whose smaller endpoint lies in its node range -- a contiguous range of the sorted edge list
-    hvec<int32_t> e_lo((size_t)h->world + 1, (int32_t)m);
-    for (int r = 0; r <= h->world; ++r)
-        e_lo[r] = (int32_t)(std::lower_bound(prob->ind_i, prob->ind_i + m, P.rank_node[r]) - prob->ind_i);
-    for (int r = 0; r < h->world; ++r) max_local = std::max<int64_t>(max_local, e_lo[r + 1] - e_lo[r]);
+    // exchange layout (k_xpos): a (virtual) owner has the edges whose smaller endpoint lies in its node range -- a contiguous range of the sorted edge list
+    const int nv = h->world * h->xparts;
+    hvec<int32_t> e_lo((size_t)nv + 1, (int32_t)m);
+    for (int vo = 0; vo <= nv; ++vo)
+        e_lo[vo] = (int32_t)(std::lower_bound(prob->ind_i, prob->ind_i + m, P.vnode[vo]) - prob->ind_i);
+    int64_t max_local_v = 0;
+    for (int r = 0; r < h->world; ++r) max_local = std::max<int64_t>(max_local, e_lo[(size_t)(r + 1) * h->xparts] - e_lo[(size_t)r * h->xparts]);
+    for (int vo = 0; vo < nv; ++vo) max_local_v = std::max<int64_t>(max_local_v, e_lo[vo + 1] - e_lo[vo]);
     h->slice_len = max_local + 2 * SHARD_PARTS;     // S of the owned edges (edge order), then the workgroup partials (see k_unpack_S)
     h->slice_S = max_local;
-    h->t_part = 2 * std::max<int64_t>(max_local, 1);
-    if ((int64_t)h->world * h->t_part >= (1ll << 31) - 1 || (int64_t)h->world * h->slice_len >= (1ll << 31) - 1)
+    h->t_part = 2 * std::max<int64_t>(max_local_v, 1);
+    if ((int64_t)nv * h->t_part >= (1ll << 31) - 1 || (int64_t)h->world * h->slice_len >= (1ll << 31) - 1)
         return fail(DESC_ERR_TOO_LARGE, "exchange buffers of %d ranks x %lld edges exceed the 32-bit positions of the exchange layout", h->world, (long long)max_local);
+    h->xseg.assign((size_t)h->xparts + 1, 0); h->xslice_off.assign((size_t)h->xparts, 0);
+    for (int c = 0; c <= h->xparts; ++c) h->xseg[c] = c < h->xparts ? std::min(std::max(P.vseg[(size_t)h->rank * h->xparts + c], h->seg_lo), h->seg_hi) : h->seg_hi;
+    h->xseg[0] = h->seg_lo;
+    for (int c = 0; c < h->xparts; ++c) h->xslice_off[c] = e_lo[(size_t)h->rank * h->xparts + c] - e_lo[(size_t)h->rank * h->xparts];
     const int64_t mcl = h->cyc_hi - h->cyc_lo;            // local cycles
     const int64_t nsl = h->seg_hi - h->seg_lo;            // local segments
     // band sweep: the work of every workgroup as a list of pieces (plan_band_pieces)
@@ -2176,7 +2201,21 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     if (h->band_ok) {
         h->band_grid = ncu;
         bool jmajor = false;
-        plan_band_pieces(prob, s, P, h->seg_lo, h->seg_hi, h->cyc_lo, mcl, h->band_grid, pieces, piece_ptr, h->band_rows, jmajor, &h->band_tail_first, &h->band_ntail);
+        // one plan per exchange part (its segments only): a part is swept by a launch of its own
+        h->xpiece_base.assign((size_t)h->xparts, 0); h->xpiece_ptr_base.assign((size_t)h->xparts, 0); h->xtail_first.assign((size_t)h->xparts, 0); h->xntail.assign((size_t)h->xparts, 0);
+        h->band_rows = 0;
+        for (int c = 0; c < h->xparts; ++c) {
+            hvec<PieceDesc> pc; hvec<int32_t> pp; int rows_c = 0, tf = 0, nt = 0;
+            const int64_t q0 = h->xseg[c], q1 = h->xseg[c + 1];
+            const int max_tail = h->world > 1 ? std::max(0, std::min(MAX_TAIL_PIECES, SHARD_PARTS / h->xparts - h->band_grid)) : MAX_TAIL_PIECES;
+            plan_band_pieces(prob, s, P, q0, q1, cum2[q0], (int64_t)cum2[q1] - cum2[q0], h->band_grid, pc, pp, rows_c, jmajor, &tf, &nt, max_tail);
+            h->xpiece_base[c] = (int)pieces.size(); h->xpiece_ptr_base[c] = (int)piece_ptr.size(); h->xtail_first[c] = tf; h->xntail[c] = nt;
+            pieces.insert(pieces.end(), pc.begin(), pc.end());
+            piece_ptr.insert(piece_ptr.end(), pp.begin(), pp.end());
+            h->band_rows = std::max(h->band_rows, rows_c);
+        }
+        h->band_tail_first = h->xtail_first[0]; h->band_ntail = h->xntail[0];
+        for (int c = 1; c < h->xparts; ++c) h->band_ntail = std::max(h->band_ntail, h->xntail[c]);       // sweep_parts(): the largest part's count
         h->band_jmajor = jmajor;
         h->n_pieces = (int64_t)pieces.size(); h->n_bands = (int64_t)P.band_lo.size() - 1;
         for (const PieceDesc& pd : pieces) h->piece_row_entries += pd.row_len;
@@ -2293,8 +2332,8 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         if ((rc = dalloc(h, &h->d_pieces, pieces.size()))) return rc;
         if ((rc = dalloc(h, &h->d_piece_ptr, piece_ptr.size()))) return rc;
         if (env_int("DESC_DEBUG_WGCLOCK", 0) && (rc = dalloc(h, &h->d_wg_clock, 3 * (size_t)h->band_grid))) return rc;
-        if ((rc = dalloc(h, &h->d_ticket, 1))) return rc;
-        DESC_HIP(hipMemsetAsync(h->d_ticket, 0, sizeof(int32_t), h->stream));
+        if ((rc = dalloc(h, &h->d_ticket, 8))) return rc;                    // one ticket counter per exchange part
+        DESC_HIP(hipMemsetAsync(h->d_ticket, 0, 8 * sizeof(int32_t), h->stream));
     }
     lap("alloc");
     int32_t *d_ii = nullptr, *d_jj = nullptr, *d_adj = nullptr, *d_adj_eid = nullptr, *d_pos_edge2 = nullptr;
@@ -2461,16 +2500,16 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     }
     {   // exchange layout of the sharded runs (both paths have the CSR index, the edge list and the segment tables on the device by now)
         int32_t *d_node_lo = nullptr, *d_elo = nullptr, *d_prefB = nullptr;
-        if ((rc = dalloc(h, &d_node_lo, (size_t)h->world + 1)) || (rc = dalloc(h, &d_elo, (size_t)h->world + 1)) || (rc = dalloc(h, &d_prefB, (size_t)h->world * std::max<int64_t>(n, 1)))) return rc;
-        if ((rc = upload(h, d_node_lo, P.rank_node.data(), (size_t)h->world + 1)) || (rc = upload(h, d_elo, e_lo.data(), (size_t)h->world + 1))) return rc;
+        if ((rc = dalloc(h, &d_node_lo, (size_t)nv + 1)) || (rc = dalloc(h, &d_elo, (size_t)nv + 1)) || (rc = dalloc(h, &d_prefB, (size_t)nv * std::max<int64_t>(n, 1)))) return rc;
+        if ((rc = upload(h, d_node_lo, P.vnode.data(), (size_t)nv + 1)) || (rc = upload(h, d_elo, e_lo.data(), (size_t)nv + 1))) return rc;
         if (n > 0) {
             const unsigned g16 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256));
-            hipLaunchKernelGGL(k_prefB, dim3(h->world), dim3(1024), 0, h->stream, h->d_rowptr, d_adj, d_node_lo, d_prefB, (int)n);
-            hipLaunchKernelGGL(k_xpos, dim3(g16), dim3(256), 0, h->stream, h->d_rowptr, d_adj, d_adj_eid, d_node_lo, d_elo, d_prefB, h->world, h->t_part, h->slice_len,
+            hipLaunchKernelGGL(k_prefB, dim3(nv), dim3(1024), 0, h->stream, h->d_rowptr, d_adj, d_node_lo, d_prefB, (int)n);
+            hipLaunchKernelGGL(k_xpos, dim3(g16), dim3(256), 0, h->stream, h->d_rowptr, d_adj, d_adj_eid, d_node_lo, d_elo, d_prefB, nv, h->xparts, h->world, h->t_part, h->slice_len,
                                h->d_xpos, h->d_spos, (int)n);
             if (nsl > 0)
                 hipLaunchKernelGGL(k_xt, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (nsl + 255) / 256))), dim3(256), 0, h->stream, d_pos_edge2, h->d_einfo,
-                                   d_ii, d_jj, h->d_rowptr, d_adj, d_node_lo, d_elo, d_prefB, h->rank, h->t_part / 2, (int)h->seg_lo, (int)h->seg_hi, h->d_xt, (int)n);
+                                   d_ii, d_jj, h->d_rowptr, d_adj, d_node_lo, d_elo, d_prefB, nv, h->t_part / 2, (int)h->seg_lo, (int)h->seg_hi, h->d_xt, (int)n);
         }
         DESC_HIP(hipStreamSynchronize(h->stream));            // e_lo / rank_node: host sources of the copies
         DESC_HIP(hipGetLastError());
@@ -2708,10 +2747,14 @@ int desc_pgd_reset(desc_pgd* h, const desc_params* p) {
     }
     if (h->m_pos > 0) {
         int g = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (h->m_pos + 3) / 4));
-        if (h->variant == VARIANT_NODE)
-            hipLaunchKernelGGL(k_init_node, dim3(g), dim3(256), 0, h->stream, h->d_cum + h->seg_lo, h->d_einfo + h->seg_lo, h->d_S0, h->d_w[0], h->d_S[0], h->d_S[1], (int)(h->seg_hi - h->seg_lo),
-                               h->x_sall ? h->x_sall + (int64_t)h->rank * h->slice_len : (double*)nullptr, h->d_xt + h->seg_lo);
-        else
+        if (h->variant == VARIANT_NODE) {
+            for (int c = 0; c < h->xparts; ++c) {        // per exchange part: its segments' initial S goes behind the parts before it in the slice
+                const int64_t q0 = h->xseg[c], q1 = h->xseg[c + 1];
+                if (q1 > q0)
+                    hipLaunchKernelGGL(k_init_node, dim3(g), dim3(256), 0, h->stream, h->d_cum + q0, h->d_einfo + q0, h->d_S0, h->d_w[0], h->d_S[0], h->d_S[1], (int)(q1 - q0),
+                                       h->x_sall ? h->x_sall + (int64_t)h->rank * h->slice_len + h->xslice_off[c] : (double*)nullptr, h->d_xt + q0);
+            }
+        } else
             hipLaunchKernelGGL(k_init, dim3(g), dim3(256), 0, h->stream, h->d_cum, h->d_pos_edge, h->d_S0, h->d_w[0], h->d_S[0], h->d_S[1], (int)h->m_pos);
     }
     DESC_HIP(hipGetLastError());
@@ -2938,7 +2981,7 @@ int desc_pgd_run(desc_pgd* h, const desc_params* p, desc_result* r) {
 int desc_pgd_shard_info(const desc_pgd* h, desc_shard_info* info) {
     if (!h || !info) return fail(DESC_ERR_INVALID, "NULL argument");
     info->rank = h->rank; info->world = h->world;
-    info->t_len = (int64_t)h->world * h->t_part + 1; info->t_part = h->t_part; info->slice_len = h->slice_len;
+    info->t_len = (int64_t)h->world * h->xparts * h->t_part + 1; info->t_part = h->t_part; info->slice_len = h->slice_len; info->xparts = h->xparts;
     info->seg_lo = h->seg_lo; info->seg_hi = h->seg_hi; info->cyc_lo = h->cyc_lo; info->cyc_hi = h->cyc_hi;
     info->m_pos = h->m_pos; info->m_cycle = h->m_cycle;
     return DESC_OK;
@@ -2951,9 +2994,9 @@ int desc_pgd_shard_bind(desc_pgd* h, double* T_send, double* T_recv, double* sal
     DESC_HIP(hipStreamSynchronize(h->stream));
     if (sweep_parts(h, false) > SHARD_PARTS || h->grid > SHARD_PARTS) return fail(DESC_ERR_STATE, "sweep grid exceeds the partials area of the exchange slice");
     if (!T_send && !T_recv && !sall) {       // library-owned exchange buffers (the fused protocol does not need torch tensors)
-        const int64_t t_len = (int64_t)h->world * h->t_part + 1;
+        const int64_t t_len = (int64_t)h->world * h->xparts * h->t_part + 1;
         if ((rc = dalloc(h, &T_send, (size_t)t_len))) return rc;
-        if (h->world > 1) { if ((rc = dalloc(h, &T_recv, (size_t)h->t_part))) return rc; }
+        if (h->world > 1) { if ((rc = dalloc(h, &T_recv, (size_t)h->xparts * h->t_part))) return rc; }
         else T_recv = T_send;                // one rank: the owner-sorted partial sums ARE the totals
         if ((rc = dalloc(h, &sall, (size_t)(h->world * h->slice_len)))) return rc;
         DESC_HIP(hipMemsetAsync(T_send, 0, sizeof(double) * t_len, h->stream));
@@ -2984,22 +3027,35 @@ int shard_enqueue_colsum(desc_pgd* h, hipStream_t st) {
     return DESC_OK;
 }
 double* my_slice(desc_pgd* h) { return h->x_sall + (int64_t)h->rank * h->slice_len; }
-int shard_enqueue_sweep(desc_pgd* h, hipStream_t st) {
-    if (h->t_done + 1 > h->iters_cap) return fail(DESC_ERR_INVALID, "iterating past params.iters = %d", h->p.iters);
-    const int t = ++h->t_done, rd = (t - 1) & 1, wr = t & 1;
-    bool adam = false;
-    const StepArgs sa = make_step(h, &adam, rd, wr);
-    NodeSweepArgs a{};
-    a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
-    a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.Tfull = h->x_Trecv; a.xt = h->d_xt; a.nv_tab = h->d_nv;
-    a.s_slice = my_slice(h); a.partials = my_slice(h) + h->slice_S;       // S and the workgroup partials go straight into the slice
-    a.csr_bytes = (uint32_t)(16 * h->m); a.t_bytes = (uint32_t)(8 * h->t_part); a.slice_bytes = (uint32_t)(8 * h->slice_S); a.seg_count = (uint32_t)h->m_pos; a.fx_inv = std::ldexp(1.0, -h->colsum_fx_bits);
-    if (shard_direct(h)) { a.Tfull = h->d_T; a.xt = nullptr; a.s_slice = nullptr; a.t_bytes = a.csr_bytes; }
-    a.state = h->d_state; a.st = sa; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks;
-    a.max_cnt = h->max_cnt;
-    const hipStream_t keep = h->stream; h->stream = st;
-    launch_sweep_node_layout(h, a, adam);
-    h->stream = keep;
+// sweep number t of the exchange parts [part_lo, part_hi): one launch each (part c reads the sums of ITS reduce-scatter: x_Trecv + c * t_part).
+// first: this call opens sweep t (plugin step, iteration counter); the parts of one sweep share the step.
+int shard_enqueue_sweep(desc_pgd* h, hipStream_t st, int part_lo = 0, int part_hi = -1) {
+    if (part_hi < 0) part_hi = h->xparts;
+    const bool first = part_lo == 0;
+    if (first && h->t_done + 1 > h->iters_cap) return fail(DESC_ERR_INVALID, "iterating past params.iters = %d", h->p.iters);
+    if (first) { ++h->t_done; h->cur_step = make_step(h, &h->cur_adam, (h->t_done - 1) & 1, h->t_done & 1); }
+    const int t = h->t_done, rd = (t - 1) & 1, wr = t & 1;
+    const bool adam = h->cur_adam;
+    // a handle on the band sweep runs its parts as separate launches; k_sweep_node (tiny graphs, Adam on long segments) has one part
+    const bool by_parts = adam ? band_adam_ok(h) : h->band_ok;
+    for (int c = part_lo; c < part_hi; ++c) {
+        if (!by_parts && c > 0) break;
+        NodeSweepArgs a{};
+        a.cum = h->d_cum; a.einfo = h->d_einfo; a.pk = h->d_pk; a.S0 = h->d_S0; a.w_old = h->d_w[rd]; a.w_new = h->d_w[wr];
+        a.S_old = h->d_S[rd]; a.S_new = h->d_S[wr]; a.xt = h->d_xt; a.nv_tab = h->d_nv;
+        a.Tfull = h->x_Trecv + (int64_t)c * h->t_part;
+        // S and the workgroup partials go straight into the slice: the part's S behind the parts before it, its partials in its share of the partial area
+        a.s_slice = my_slice(h) + h->xslice_off[c];
+        a.partials = my_slice(h) + h->slice_S + 2 * (int64_t)c * (SHARD_PARTS / h->xparts);
+        a.csr_bytes = (uint32_t)(16 * h->m); a.t_bytes = (uint32_t)(8 * h->t_part); a.slice_bytes = (uint32_t)(8 * (h->slice_S - h->xslice_off[c]));
+        a.seg_count = (uint32_t)h->m_pos; a.fx_inv = std::ldexp(1.0, -h->colsum_fx_bits);
+        if (shard_direct(h)) { a.Tfull = h->d_T; a.xt = nullptr; a.s_slice = nullptr; a.t_bytes = a.csr_bytes; }
+        a.state = h->d_state; a.st = h->cur_step; a.chunk_desc = h->d_chunk_desc + h->ch_lo; a.nchunks = h->nchunks;
+        a.max_cnt = h->max_cnt;
+        const hipStream_t keep = h->stream; h->stream = st;
+        launch_sweep_node_layout(h, a, adam, c);
+        h->stream = keep;
+    }
     h->last_parts = sweep_parts(h, adam);
     DESC_HIP(hipGetLastError());
     return DESC_OK;
@@ -3082,6 +3138,7 @@ int desc_pgd_shard_set_collectives(desc_pgd* h, const desc_collectives* c) {
     if (!h->comm_stream) {
         DESC_HIP(stream_acquire(&h->comm_stream));
         for (hipEvent_t* e : {&h->ev_col, &h->ev_rs, &h->ev_sw, &h->ev_ag}) DESC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (int c = 0; c < 8; ++c) DESC_HIP(hipEventCreateWithFlags(&h->ev_rsx[c], hipEventDisableTiming));
     }
     return DESC_OK;
 }
@@ -3139,13 +3196,18 @@ int desc_pgd_shard_iterate(desc_pgd* h, int32_t n_iters) {
         if (exchange) {
             DESC_HIP(hipEventRecord(h->ev_col, h->stream));
             DESC_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_col, 0));
-            const int rcc = h->coll.reduce_scatter(h->x_T, h->x_Trecv, (size_t)h->t_part, 4 /* ncclInt64: fixed-point mirror sums, order-independent */, 0 /* ncclSum */, h->coll.comm, h->comm_stream);
-            if (rcc) return coll_fail(rcc, "reduce_scatter");
-            DESC_HIP(hipEventRecord(h->ev_rs, h->comm_stream));
+            for (int c = 0; c < h->xparts; ++c) {                          // part c: blocks [c * world, (c + 1) * world) of the send buffer
+                const int rcc = h->coll.reduce_scatter(h->x_T + (int64_t)c * h->world * h->t_part, h->x_Trecv + (int64_t)c * h->t_part, (size_t)h->t_part,
+                                                       4 /* ncclInt64: fixed-point mirror sums, order-independent */, 0 /* ncclSum */, h->coll.comm, h->comm_stream);
+                if (rcc) return coll_fail(rcc, "reduce_scatter");
+                DESC_HIP(hipEventRecord(h->ev_rsx[c], h->comm_stream));
+            }
         }
         if ((rc = shard_unpack_pending(h))) return rc;                  // S of the previous sweep into the CSR-aligned replica, under the reduce-scatter
-        if (exchange) DESC_HIP(hipStreamWaitEvent(h->stream, h->ev_rs, 0));
-        if ((rc = shard_enqueue_sweep(h, h->stream))) return rc;
+        for (int c = 0; c < h->xparts; ++c) {                           // part c is swept while part c + 1 is still on the wire
+            if (exchange) DESC_HIP(hipStreamWaitEvent(h->stream, h->ev_rsx[c], 0));
+            if ((rc = shard_enqueue_sweep(h, h->stream, c, c + 1))) return rc;
+        }
         DESC_HIP(hipEventRecord(h->ev_sw, h->stream));
         DESC_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_sw, 0));
         if ((rc = shard_all_gather(h))) return rc;

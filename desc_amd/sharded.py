@@ -122,11 +122,12 @@ class HipShard:
             # the mirror sums are exchanged as 64-bit fixed-point integers (k_colsum_node): integer sums do not depend on the order the
             # collective adds the ranks' parts in, so S_vec comes out bitwise the same for every number of ranks
             self.T = torch.zeros(self.info.t_len, dtype=torch.int64, device=dev)        # send: zero padding stays zero
-            self.T_recv = torch.zeros(self.info.t_part, dtype=torch.int64, device=dev)
+            self.T_recv = torch.zeros(self.info.xparts * self.info.t_part, dtype=torch.int64, device=dev)
             self.sall = torch.zeros(self.info.world * self.info.slice_len, dtype=torch.float64, device=dev)
         self.stream.synchronize()
         self.solver.shard_bind(self.T.data_ptr(), self.T_recv.data_ptr(), self.sall.data_ptr(), self.stream.cuda_stream)
         self.slice_len = self.info.slice_len
+        self.xparts, self.t_part = int(self.info.xparts), int(self.info.t_part)
 
     def stream_ctx(self):
         return self.torch.cuda.stream(self.stream)
@@ -165,7 +166,7 @@ class ShardedDriver:
         with self._ctx():
             for _ in range(n):
                 s.colsum()
-                c.reduce_scatter_sum(s.T_recv, s.T)
+                reduce_scatter_parts(c, s)
                 s.sweep()
                 c.all_gather_slices(s.sall, s.slice_len)
                 s.finish(0)
@@ -188,6 +189,18 @@ class ShardedDriver:
             if left > 0 and self.shard.stopped():    # identical on every rank
                 break
         return self.finish()
+
+
+def reduce_scatter_parts(comm, shard):
+    """The reduce-scatter of the mirror sums, one exchange part at a time (desc_shard_info.xparts; shards without the attribute have one part):
+    part c = blocks [c * world, (c + 1) * world) of T -> block c of T_recv."""
+    X = int(getattr(shard, "xparts", 1))
+    if X == 1:
+        comm.reduce_scatter_sum(shard.T_recv, shard.T)
+        return
+    L, W = int(shard.t_part), comm.world
+    for c in range(X):
+        comm.reduce_scatter_sum(shard.T_recv[c * L:(c + 1) * L], shard.T[c * W * L:(c + 1) * W * L + 1])
 
 
 class RcclComm:

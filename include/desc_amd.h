@@ -219,21 +219,26 @@ const char* desc_pgd_kernel_name(const desc_pgd* h);
  * every rank adds the gathered scalar partials in rank order. */
 typedef struct desc_shard_info {
     int32_t rank, world;
-    int64_t t_len;            /* doubles in T_send = world*t_part + 1 (owner-sorted mirror sums, last = unused slot) */
-    int64_t t_part;           /* doubles in T_recv: T1, T2 of every owned edge-with-cycles, padded to the largest shard */
+    int64_t t_len;            /* 8-byte words in T_send = world*xparts*t_part + 1 (mirror sums as fixed-point integers, one block of t_part words per
+                                 (exchange part, rank), part-major; last = unused slot) */
+    int64_t t_part;           /* words per block: T1 | T2 of the edges of one (rank, part), padded to the largest; T_recv holds xparts blocks */
     int64_t slice_len;        /* doubles per rank in sall: S of the owned edges (padded to the largest shard), then the
                                  workgroup partials (objective, sum |dS|) of the rank's last sweep                      */
     int64_t seg_lo, seg_hi;   /* owned range of edges-with-cycles (library order)             */
     int64_t cyc_lo, cyc_hi;   /* owned range of cycles                                        */
     int64_t m_pos, m_cycle;   /* global counts                                                */
+    int32_t xparts;           /* exchange parts per rank (round 4): the reduce-scatter runs part by part -- for c in 0..xparts-1:
+                                 reduce_scatter(T_send + c*world*t_part  ->  T_recv + c*t_part, t_part words) -- so that part c + 1 travels
+                                 while part c is swept (the fused protocol does; the piecewise calls sweep all parts in desc_pgd_shard_sweep) */
+    int32_t reserved;
 } desc_shard_info;
 int desc_pgd_create_shard(const desc_problem* prob, const desc_structure* s, int32_t device,
                           int32_t rank, int32_t world, desc_pgd** out);
 int desc_pgd_shard_info(const desc_pgd* h, desc_shard_info* info);
 /* T_send: t_len 8-byte words, zero-initialised by the caller (this rank's partial mirror sums, grouped by
- * owning rank: part r = [r*t_part, (r+1)*t_part)); the words are 64-bit fixed-point INTEGERS: the caller's
- * reduce-scatter must add them as int64 (ncclInt64 / torch.int64), not as doubles.  T_recv: t_part words (the caller's
- * reduce-scatter(sum) of every rank's T_send); sall: world*slice_len doubles, zero-initialised; all on `device`.
+ * owning (part, rank): block b = part*world + rank = [b*t_part, (b+1)*t_part)); the words are 64-bit fixed-point INTEGERS: the caller's
+ * reduce-scatter must add them as int64 (ncclInt64 / torch.int64), not as doubles.  T_recv: xparts*t_part words (the caller's
+ * reduce-scatter(sum) of every rank's T_send, part by part: see desc_shard_info.xparts); sall: world*slice_len doubles, zero-initialised; all on `device`.
  * All three NULL: the library allocates them itself (the fused protocol below needs no caller buffers).
  * hip_stream: the stream the caller's collectives are ordered on (NULL keeps the handle's own). */
 int desc_pgd_shard_bind(desc_pgd* h, double* T_send, double* T_recv, double* sall, void* hip_stream);

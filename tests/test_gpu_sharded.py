@@ -32,13 +32,14 @@ def _emulate(lib, nn, ii, jj, rij, p, world, check_every=5, where=None, nmin=30)
             for s in shards:
                 s.sall.view(world, L)[r].copy_(piece)
 
-    def reduce_scatter():
-        Lp = shards[0].info.t_part
-        tot = torch.zeros(world * Lp, dtype=shards[0].T.dtype, device=shards[0].T.device)
-        for s in shards:
-            tot += s.T[:world * Lp]
-        for r, s in enumerate(shards):
-            s.T_recv.copy_(tot.view(world, Lp)[r])
+    def reduce_scatter():                                    # part by part (desc_shard_info.xparts): blocks [c * world, (c + 1) * world) -> block c
+        Lp, X = shards[0].info.t_part, shards[0].info.xparts
+        for c in range(X):
+            tot = torch.zeros(world * Lp, dtype=shards[0].T.dtype, device=shards[0].T.device)
+            for s in shards:
+                tot += s.T[c * world * Lp:(c + 1) * world * Lp]
+            for r, s in enumerate(shards):
+                s.T_recv[c * Lp:(c + 1) * Lp].copy_(tot.view(world, Lp)[r])
 
     for s in shards: s.reset(p)
     for s in shards: s.finish(1)
@@ -296,28 +297,30 @@ def test_exchange_layout_invariants(lib, world, row_cap, monkeypatch):
         layouts.append(sv.shard_layout()); infos.append(sv.shard_info())
         sv.destroy()
     st.free()
-    t_part, slice_len = infos[0].t_part, infos[0].slice_len
-    assert all(i.t_part == t_part and i.slice_len == slice_len for i in infos)
+    t_part, slice_len, X = infos[0].t_part, infos[0].slice_len, infos[0].xparts
+    assert all(i.t_part == t_part and i.slice_len == slice_len and i.xparts == X for i in infos)
     xpos, spos = layouts[0]["xpos"], layouts[0]["spos"]
     for lay in layouts[1:]:                                   # the layout is global: identical on every rank
         assert np.array_equal(lay["xpos"], xpos) and np.array_equal(lay["spos"], spos)
-    assert np.unique(xpos).size == 2 * m and xpos.min() >= 0 and xpos.max() < world * t_part          # injective
-    # the owner of a slot's column sum = the owner of the SMALLER endpoint of its edge; owners own contiguous edge ranges
-    owner = xpos // t_part
+    assert np.unique(xpos).size == 2 * m and xpos.min() >= 0 and xpos.max() < world * X * t_part       # injective
+    # block b = part * world + rank: the owner of a slot's column sum = the owner of the SMALLER endpoint of its edge
+    block = xpos // t_part
+    owner, part = block % world, block // world
+    vowner = owner * X + part                                 # virtual owners in node order
     small = np.minimum(row_of, adj)
-    for r in range(world):
-        mine = small[owner == r]
-        others = small[owner != r]
-        if mine.size:
-            assert not np.any((others >= mine.min()) & (others <= mine.max())), r               # node ranges do not interleave
-    e_owner = np.zeros(m, dtype=np.int64); e_owner[adj_eid] = owner
-    assert np.all(np.diff(e_owner) >= 0)                      # edge list sorted by (i, j): ranks own consecutive ranges
-    e_lo = np.searchsorted(e_owner, np.arange(world))
+    for vo in np.unique(vowner):
+        mine, others = small[vowner == vo], small[vowner != vo]
+        assert not np.any((others >= mine.min()) & (others <= mine.max())), vo                      # node ranges do not interleave
+    e_vowner = np.zeros(m, dtype=np.int64); e_vowner[adj_eid] = vowner
+    assert np.all(np.diff(e_vowner) >= 0)                     # edge list sorted by (i, j): (rank, part) own consecutive ranges
+    e_owner = e_vowner // X
+    e_lo = np.searchsorted(e_owner, np.arange(world))         # first edge of every rank
+    e_lo_v = np.searchsorted(e_vowner, np.arange(world * X))  # ... of every (rank, part)
     assert np.array_equal(spos, e_owner[adj_eid] * slice_len + (adj_eid - e_lo[e_owner[adj_eid]]))
-    # T1 half: edge order; T2 half behind it
+    # T1 half of a block: edge order; T2 half behind it
     upper = adj > row_of
-    assert np.array_equal(xpos[upper], owner[upper] * t_part + (adj_eid[upper] - e_lo[owner[upper]]))
-    assert np.all(xpos[~upper] - owner[~upper] * t_part >= t_part // 2)
+    assert np.array_equal(xpos[upper], block[upper] * t_part + (adj_eid[upper] - e_lo_v[vowner[upper]]))
+    assert np.all(xpos[~upper] - block[~upper] * t_part >= t_part // 2)
     covered = 0
     for r, (lay, info) in enumerate(zip(layouts, infos)):
         nsl = int(info.seg_hi - info.seg_lo)
@@ -325,9 +328,10 @@ def test_exchange_layout_invariants(lib, world, row_cap, monkeypatch):
         if nsl == 0:
             continue
         sa, sb = lay["slot_ab"][:, 0], lay["slot_ab"][:, 1]
-        assert np.array_equal(lay["xt"][:, 0], xpos[sa] - r * t_part) and np.array_equal(lay["xt"][:, 1], xpos[sb] - r * t_part)
-        assert np.all(owner[sa] == r) and np.all(owner[sb] == r)
-        assert np.array_equal(spos[sa], r * slice_len + lay["xt"][:, 0]) and np.array_equal(spos[sa], spos[sb])
+        assert np.all(owner[sa] == r) and np.all(owner[sb] == r) and np.array_equal(block[sa], block[sb])
+        assert np.array_equal(lay["xt"][:, 0], xpos[sa] - block[sa] * t_part) and np.array_equal(lay["xt"][:, 1], xpos[sb] - block[sb] * t_part)
+        # place in the rank's all-gather slice = place inside the part + the edges of the parts before it
+        assert np.array_equal(spos[sa], r * slice_len + lay["xt"][:, 0] + (e_lo_v[vowner[sa]] - e_lo[r])) and np.array_equal(spos[sa], spos[sb])
         covered += nsl
     assert covered == infos[0].m_pos
     if not row_cap:

@@ -61,12 +61,14 @@ def all_gather():
             s.sall.view(world, L)[r].copy_(piece)
 
 
-def reduce_scatter():
-    tot = torch.zeros(world * Lp, dtype=shards[0].T.dtype, device=dev)
-    for s in shards:
-        tot += s.T[:world * Lp]
-    for r, s in enumerate(shards):
-        s.T_recv.copy_(tot.view(world, Lp)[r])
+def reduce_scatter():                                        # part by part (desc_shard_info.xparts)
+    X = shards[0].info.xparts
+    for c in range(X):
+        tot = torch.zeros(world * Lp, dtype=shards[0].T.dtype, device=dev)
+        for s in shards:
+            tot += s.T[c * world * Lp:(c + 1) * world * Lp]
+        for r, s in enumerate(shards):
+            s.T_recv[c * Lp:(c + 1) * Lp].copy_(tot.view(world, Lp)[r])
 
 
 pieces = ("colsum", "sweep", "unpack")
@@ -141,7 +143,8 @@ out = dict(
     compute_us_max_over_ranks=float(max(x["us_colsum"] + x["us_sweep"] + x["us_unpack"] for x in ranks)),
     compute_us_max_over_ranks_alone=float(max(x["us_colsum_alone"] + x["us_sweep_alone"] + x["us_unpack_alone"] for x in ranks)),
     exchange=dict(
-        reduce_scatter=dict(elements_per_rank_part=int(Lp), bytes_sent_per_rank=int(8 * Lp * (world - 1)), bytes_received_per_rank=int(8 * Lp * (world - 1)),
+        reduce_scatter=dict(parts=int(shards[0].info.xparts), elements_per_block=int(Lp), bytes_sent_per_rank=int(8 * Lp * shards[0].info.xparts * (world - 1)),
+                            bytes_received_per_rank=int(8 * Lp * shards[0].info.xparts * (world - 1)),
                             what="partial mirror sums T1 | T2 (DESC_PGD.m:189-190) of every other rank's edges out, the other ranks' partials of this rank's edges in"),
         all_gather=dict(slice_len=int(L), bytes_sent_per_rank=int(8 * L * (world - 1)), bytes_received_per_rank=int(8 * L * (world - 1)),
                         what="new S of the owned edges (DESC_PGD.m:229) + the workgroup partials of the objective / |dS| sums")),
