@@ -1068,20 +1068,20 @@ struct FinArgs {
     int64_t m; double stop_tol; int32_t nparts, t, patience, last_only;      // t == 0: nothing to do
     int64_t rank_stride; int32_t nranks;     // sharded runs: the partials of rank r start at partials + r * rank_stride (0 / 0: one rank)
 };
-__device__ __forceinline__ void finalize_wave(const FinArgs f) {
-    DevState* st = f.st;
-    if (f.t <= 0 || st->stop) return;          // t == 0: no sweep to book-keep
-    const int lane = threadIdx.x & 63;
-    // Every lane adds its strided share of the (rank, index) pairs in that order -- the same sum on every rank --, then the fixed DPP butterfly.
-    // Eight pairs are loaded before any is added: one at a time the 8 x 1024 pairs of a world-8 run were 128 dependent round trips, ~90 us,
-    // and WERE the duration of k_unpack_S (round 4: a tile-ordered unpack changed nothing, profiles/r04_shard_w8_c4_unpack*.json).
-    double o = 0.0, ch = 0.0;
+// The sum of the workgroup partials is defined over 256 VIRTUAL lanes: virtual lane v adds the (rank, index) pairs v, v + 256, ... in that order, the
+// 64 virtual lanes of a quarter are combined by the fixed DPP butterfly and the four quarters are added in index order.  A 256-thread block
+// (finalize_block: the bookkeeping workgroup of the column-sum and unpack launches) gives a quarter to each of its waves; a single wave
+// (finalize_wave: k_finalize) walks the four quarters one after the other -- the SAME bits either way, and the same on every rank.  Eight pairs are
+// loaded before any is added (one at a time the 8 x 1024 pairs of a world-8 run were 128 dependent round trips for one wave: ~50 of the 85 us of
+// k_unpack_S, profiles/r04_shard_w8_c4_rocprof.txt -- 35 us in the launches that book-keep nothing).
+__device__ __forceinline__ void finalize_quarter(const FinArgs& f, int quarter, int lane, double& o, double& ch) {
+    o = 0.0; ch = 0.0;
     const int E = max(f.nranks, 1) * f.nparts;
-    for (int base = lane; base < E; base += 64 * 8) {
+    for (int base = 64 * quarter + lane; base < E; base += 256 * 8) {
         double vo[8], vc[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int idx = base + 64 * u;
+            const int idx = base + 256 * u;
             vo[u] = 0.0; vc[u] = 0.0;
             if (idx < E) {
                 const double* q = f.partials + (int64_t)(idx / f.nparts) * f.rank_stride + 2 * (int64_t)(idx % f.nparts);
@@ -1092,7 +1092,32 @@ __device__ __forceinline__ void finalize_wave(const FinArgs f) {
         for (int u = 0; u < 8; ++u) { o += vo[u]; ch += vc[u]; }
     }
     o = group_sum<64>(o); ch = group_sum<64>(ch);
-    if (lane != 0) return;
+}
+__device__ __forceinline__ void finalize_book(const FinArgs& f, double o, double ch);
+// called by all 256 threads of a block
+__device__ __forceinline__ void finalize_block(const FinArgs f) {
+    __shared__ double s_fin[4][2];
+    if (f.t <= 0 || f.st->stop) return;          // t == 0: no sweep to book-keep (uniform over the block)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double o, ch;
+    finalize_quarter(f, wv, lane, o, ch);
+    if (lane == 0) { s_fin[wv][0] = o; s_fin[wv][1] = ch; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        finalize_book(f, ((s_fin[0][0] + s_fin[1][0]) + s_fin[2][0]) + s_fin[3][0], ((s_fin[0][1] + s_fin[1][1]) + s_fin[2][1]) + s_fin[3][1]);
+}
+// called by one full wave
+__device__ __forceinline__ void finalize_wave(const FinArgs f) {
+    if (f.t <= 0 || f.st->stop) return;
+    const int lane = threadIdx.x & 63;
+    double q0[4], q1[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) finalize_quarter(f, w, lane, q0[w], q1[w]);
+    if (lane == 0) finalize_book(f, ((q0[0] + q0[1]) + q0[2]) + q0[3], ((q1[0] + q1[1]) + q1[2]) + q1[3]);
+}
+// traces and the stop rule of DESC_PGD.m:232-257 for the iteration whose sums just became known (one thread)
+__device__ __forceinline__ void finalize_book(const FinArgs& f, double o, double ch) {
+    DevState* st = f.st;
     // last_only: the partials come from the objective kernel after the final sweep t and
     // hold obj(t).  Otherwise they come from sweep t: obj(t-1) and sum|dS| of sweep t.
     const int t = f.t;
@@ -1202,7 +1227,7 @@ __global__ __launch_bounds__(256) void k_colsum_node(const int32_t* rowptr, cons
                                                      double* Tfull, int n, int stride_cols, const DevState* st, const int32_t* xpos, FinArgs fin, int32_t* tail_ticket, const int32_t* node_order,
                                                      const int2* node_run, int n_long, int copies, double fx_scale) {
     if (blockIdx.x == gridDim.x - 1) {
-        if (threadIdx.x < 64 && fin.st) finalize_wave(fin);
+        if (fin.st) finalize_block(fin);
         if (threadIdx.x < 8 && tail_ticket) tail_ticket[threadIdx.x] = 0;      // the sweep launches that follow (one per exchange part) hand out their tail pieces from 0
         return;
     }
@@ -1646,8 +1671,8 @@ __global__ __launch_bounds__(256) void k_reorder_cycles(const int32_t* cum, cons
 // partials in rank order (identical sums, hence identical stop decisions, on every rank) and runs the stop rule.
 constexpr int SHARD_PARTS = 1024;           // >= band grid + tail pieces (MAX_TAIL_PIECES)
 __global__ __launch_bounds__(256) void k_unpack_S(const int32_t* spos, int64_t nslots, const double* sall, double* S_a, double* S_b, FinArgs fin) {
-    if (blockIdx.x == gridDim.x - 1) {
-        if (fin.t > 0 && threadIdx.x < 64) finalize_wave(fin);
+    if (blockIdx.x == 0) {                      // the bookkeeping workgroup: dispatched first, runs under the copy
+        if (fin.t > 0) finalize_block(fin);
         return;
     }
     // once the stop rule has fired the slices hold the discarded sweep: the double buffers must keep the final iterate
@@ -1658,7 +1683,7 @@ __global__ __launch_bounds__(256) void k_unpack_S(const int32_t* spos, int64_t n
     //  256 MB Infinity Cache between a rank's turns, which a rank on its own GPU does not suffer.  A tile-ordered form -- slots visited
     //  (tile of source nodes)-major so that the gathered values stay in the L2 -- measured 81 us on average, 53 at best: not adopted.)
     const int64_t stride = (int64_t)(gridDim.x - 1) * 256;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nslots; t += 4 * stride) {
+    for (int64_t t = (int64_t)(blockIdx.x - 1) * 256 + threadIdx.x; t < nslots; t += 4 * stride) {
         int32_t q[4]; double v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) q[u] = spos[min(t + u * stride, nslots - 1)];
