@@ -70,6 +70,74 @@ __global__ __launch_bounds__(256) void k_cemp_s0(const int32_t* pos_edge, const 
     }
 }
 
+// The same with the rotation blocks of node i's row staged in the LDS (round 4; CSR-aligned path: `pk` holds the position of k in row i): one
+// 512-thread workgroup per node i, its edges (i, j) -- consecutive in the (i, j)-sorted list: node_seg[i] .. node_seg[i + 1] -- a wave each, R_ki of
+// every sample an LDS read (80 B per slot for 16-byte reads); R_jk stays a gather from the edge table.  Same arithmetic in the same order.
+__global__ __launch_bounds__(512) void k_cemp_s0_staged(const int32_t* pos_edge, const int32_t* ind_i, const int32_t* ind_j, const int32_t* kk, const int32_t* e_jk,
+                                                        const uint32_t* pk, const int32_t* rowptr, const int32_t* adj_eid, const int32_t* node_seg, const double* rij, double* S0,
+                                                        double* S_a, double* S_b, int n, int nsample, const int32_t* slot_a, const int32_t* slot_b) {
+    extern __shared__ double s_blk[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int l0 = node_seg[i], l1 = node_seg[i + 1];
+        if (l0 == l1) continue;
+        const int r0 = rowptr[i], d = rowptr[i + 1] - r0;
+        __syncthreads();
+        for (int t = threadIdx.x; t < d; t += 512) {
+            double Bk[9];
+            load_block9(rij + 9 * (int64_t)adj_eid[r0 + t], Bk);
+            for (int q = 0; q < 9; ++q) s_blk[10 * t + q] = Bk[q];
+        }
+        __syncthreads();
+        for (int64_t l = l0 + wv; l < l1; l += 8) {
+            const int e = pos_edge[l], j = ind_j[e];
+            double A[9];
+            load_block9(rij + 9 * (int64_t)e, A);
+            double acc = 0.0;
+            for (int s = lane; s < nsample; s += 64) {
+                const int64_t c = l * nsample + s;
+                const int k = kk[c];
+                double pb[9], pc[9];
+                load_block9(rij + 9 * (int64_t)e_jk[c], pb);
+                const double* sb = s_blk + 10 * (int)(pk[c] & 0xFFFFu);
+                const double2 c0 = *reinterpret_cast<const double2*>(sb), c1 = *reinterpret_cast<const double2*>(sb + 2), c2 = *reinterpret_cast<const double2*>(sb + 4),
+                              c3 = *reinterpret_cast<const double2*>(sb + 6);
+                pc[0] = c0.x; pc[1] = c0.y; pc[2] = c1.x; pc[3] = c1.y; pc[4] = c2.x; pc[5] = c2.y; pc[6] = c3.x; pc[7] = c3.y; pc[8] = sb[8];
+                const bool tb = !(j < k), tc = !(k < i);
+                double tr = 0.0;
+                for (int r = 0; r < 3; ++r) {
+                    double P[3];
+                    for (int q = 0; q < 3; ++q) {
+                        double a2 = 0.0;
+                        for (int u = 0; u < 3; ++u) a2 = a2 + A[r + 3 * u] * (tb ? pb[q + 3 * u] : pb[u + 3 * q]);
+                        P[q] = a2;
+                    }
+                    double a3 = 0.0;
+                    for (int u = 0; u < 3; ++u) a3 = a3 + P[u] * (tc ? pc[r + 3 * u] : pc[u + 3 * r]);
+                    tr = tr + a3;
+                }
+                const double dd = abs_acos_ext_c((tr - 1.0) / 2.0) / M_PI;
+                S0[c] = dd;
+                acc += dd;
+            }
+            acc = group_sum<64>(acc);
+            if (lane == 0) {                                                                                 // :102
+                const double mean = acc / (double)nsample;
+                const int sa = slot_a[e], sb2 = slot_b[e];
+                S_a[sa] = mean; S_a[sb2] = mean; S_b[sa] = mean; S_b[sb2] = mean;
+            }
+        }
+    }
+}
+// first natural segment (edge with cycles, ascending edge id) whose smaller endpoint is >= v; node_seg[n] = m_pos
+__global__ __launch_bounds__(256) void k_cemp_node_seg(const int32_t* pos_edge, const int32_t* ind_i, int64_t m_pos, int n, int32_t* node_seg) {
+    for (int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x; l < m_pos; l += (int64_t)gridDim.x * 256) {
+        const int i = ind_i[pos_edge[l]], prev = l > 0 ? ind_i[pos_edge[l - 1]] : -1;
+        for (int v = prev + 1; v <= i; ++v) node_seg[v] = (int32_t)l;
+        if (l == m_pos - 1) for (int v = i + 1; v <= n; ++v) node_seg[v] = (int32_t)m_pos;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_cemp_round(const int32_t* pos_edge, const int32_t* e_jk, const int32_t* e_ki, const double* S0,
                                                     const double* S_old, double* S_new, int m_pos, int nsample, double beta) {
     const int lane = threadIdx.x & 63;
@@ -332,6 +400,15 @@ extern "C" int desc_cemp_run_dev(const desc_device_problem* dp, const double* be
     int cur = 0;
     if (mp) {
         const int g = (int)std::min<int64_t>(8192, (mp + 3) / 4);
+        const size_t lds0 = (size_t)max_deg * 10 * sizeof(double);
+        if (tiles && lds0 <= 150 * 1024 && env_int_c("DESC_DEBUG_STAGED_LAYOUT", 1) != 0) {       // node i's rotation blocks in the LDS
+            int32_t* d_node_seg = nullptr;
+            if ((rc = D.alloc(&d_node_seg, n + 1))) return rc;
+            hipLaunchKernelGGL(k_cemp_node_seg, dim3((unsigned)std::min<int64_t>(4096, (mp + 255) / 256)), dim3(256), 0, 0, d_pos, d_ii, mp, (int)n, d_node_seg);
+            if (lds0 > 64 * 1024) DESC_HIP(hipFuncSetAttribute((const void*)k_cemp_s0_staged, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0));
+            hipLaunchKernelGGL(k_cemp_s0_staged, dim3((unsigned)std::max<int64_t>(1, n)), dim3(512), lds0, 0, d_pos, d_ii, d_jj, d_k, d_ejk, d_pk, dp->d_rowptr, dp->d_adj_eid, d_node_seg, d_rij,
+                               d_S0, d_S[0], d_S[1], (int)n, nsample, d_slot_a, d_slot_b);
+        } else
         hipLaunchKernelGGL(k_cemp_s0, dim3(g), dim3(256), 0, 0, d_pos, d_ii, d_jj, d_k, d_ejk, d_eki, d_rij, d_S0, d_S[0], d_S[1], (int)mp, nsample,
                            tiles ? d_slot_a : (const int32_t*)nullptr, tiles ? d_slot_b : (const int32_t*)nullptr);
         // tile shape: the band's rows in <= 32 KiB of LDS (several workgroups per CU), the rows of a j-block ~2.5 MiB (they share an XCD's L2 with the streams)

@@ -142,6 +142,30 @@ __device__ __forceinline__ double cycle_trace(const double* A, const double* pb,
     return tr;
 }
 
+// the same with the third factor already loaded (k_layout_node_dev<.., STAGED>: node i's blocks sit in the LDS)
+__device__ __forceinline__ double cycle_trace_regs(const double* A, const double* pb, bool tb, const double* Cm, bool tc) {
+    double Bm[9], B[9], C[9];
+    load_block9(pb, Bm);
+    for (int r = 0; r < 3; ++r)
+        for (int s = 0; s < 3; ++s) {
+            B[r + 3 * s] = tb ? Bm[s + 3 * r] : Bm[r + 3 * s];
+            C[r + 3 * s] = tc ? Cm[s + 3 * r] : Cm[r + 3 * s];
+        }
+    double tr = 0.0;
+    for (int r = 0; r < 3; ++r) {
+        double P[3];
+        for (int s = 0; s < 3; ++s) {
+            double acc = 0.0;
+            for (int u = 0; u < 3; ++u) acc = acc + A[r + 3 * u] * B[u + 3 * s];
+            P[s] = acc;
+        }
+        double acc = 0.0;
+        for (int u = 0; u < 3; ++u) acc = acc + P[u] * C[u + 3 * r];
+        tr = tr + acc;
+    }
+    return tr;
+}
+
 // deterministic workgroup partials (blockDim 256 or 512)
 __device__ __forceinline__ void block_partials(double obj_acc, double chg_acc, double* partials, int lb) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -1320,17 +1344,37 @@ __global__ __launch_bounds__(256) void k_layout_node(const int32_t* cum, const i
 // was sampled iff (key(e_ik, j), j) <= (tau, ktau) of edge {i,k} -- and does the within-segment
 // re-ordering [(ik;j) only | both mirrors | (jk;i) only | none] in the wave (stable: ascending k
 // inside a class, exactly like the host path).  Segments have <= MAX_SEG_CYCLES cycles (pieces of 64).
-template <int NP>                                    // pieces of 64 cycles per segment: 1, 2 or 4
-__global__ __launch_bounds__(256) void k_layout_node_dev(const int32_t* cum, const int32_t* src_start, const int32_t* pos_edge,
+// STAGED (round 4; natural order only: the segments of a node are then consecutive, node_seg[i] .. node_seg[i + 1]): one workgroup per node i
+// first copies the rotation blocks of ALL edges incident to i -- row i of the CSR, 72 B per slot, 80 B apart in the LDS for 16-byte reads -- so that
+// R_ki of every cycle of every segment (i, .) is an LDS read; R_jk stays a gather from the edge table.  Half of the kernel's 2 x 72 B of gathers per
+// cycle (125 M cycles at C4: 18 GB out of the caches) become 0.36 GB of staging.
+template <int NP, bool STAGED>                       // NP: pieces of 64 cycles per segment: 1, 2 or 4; STAGED: 512 threads (8 waves share a node's blocks), else 256
+__global__ __launch_bounds__(STAGED ? 512 : 256) void k_layout_node_dev(const int32_t* cum, const int32_t* src_start, const int32_t* pos_edge,
                                                          const int32_t* ind_i, const int32_t* ind_j, const int32_t* nat_k,
                                                          const unsigned long long* tau, const int32_t* ktau,
                                                          uint64_t seed, const int32_t* rowptr, const unsigned long long* bits,
                                                          const uint32_t* rank, int words, const int32_t* adj_eid, const double* rij,
-                                                         uint32_t* pk, double* S0, uint8_t* seg_perm, uint32_t* seg_counts, int m_pos) {
+                                                         uint32_t* pk, double* S0, uint8_t* seg_perm, uint32_t* seg_counts, int m_pos, const int32_t* node_seg, int n_nodes) {
+    extern __shared__ double s_blk[];                // STAGED: 10 doubles per slot of row i (9 used)
     const int lane = threadIdx.x & 63;
     const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * 256) >> 6;
-    for (int64_t l = wid; l < m_pos; l += nw) {
+    const int n_outer = STAGED ? n_nodes : 1;
+    for (int node = STAGED ? blockIdx.x : 0; node < n_outer; node += STAGED ? gridDim.x : 1) {
+    int64_t l_first = wid, l_end = m_pos, l_step = nw;
+    if (STAGED) {
+        l_first = node_seg[node] + (threadIdx.x >> 6); l_end = node_seg[node + 1]; l_step = 8;
+        if (node_seg[node] == l_end) continue;       // no segment with this smaller endpoint (uniform over the workgroup)
+        const int r0n = rowptr[node], dn = rowptr[node + 1] - r0n;
+        __syncthreads();                             // the previous node's blocks are no longer read
+        for (int t = threadIdx.x; t < dn; t += 512) {
+            double Bk[9];
+            load_block9(rij + 9 * (int64_t)adj_eid[r0n + t], Bk);
+            for (int q = 0; q < 9; ++q) s_blk[10 * t + q] = Bk[q];
+        }
+        __syncthreads();
+    }
+    for (int64_t l = l_first; l < l_end; l += l_step) {
         const int base = cum[l], cnt = cum[l + 1] - base, src = src_start[l];
         const int e = pos_edge[l], i = ind_i[e], j = ind_j[e];
         const int ri = rowptr[i], di = rowptr[i + 1] - ri, rj = rowptr[j], dj = rowptr[j + 1] - rj;
@@ -1383,12 +1427,30 @@ __global__ __launch_bounds__(256) void k_layout_node_dev(const int32_t* cum, con
                 const int k = kk[pc];
                 pk[(int64_t)base + o] = word[pc];
                 seg_perm[(int64_t)base + o] = (uint8_t)(pc * 64 + lane);
-                const double tr = cycle_trace(A, rij + 9 * (int64_t)ejk[pc], !(j < k), rij + 9 * (int64_t)eik[pc], !(k < i));
+                double tr;
+                if (STAGED) {
+                    double Cm[9];
+                    const double* sb = s_blk + 10 * (int)(word[pc] & 0x7FFFu);          // slot idx_i(k) of row i: the block of edge {i, k}
+                    const double2 c0 = *reinterpret_cast<const double2*>(sb), c1 = *reinterpret_cast<const double2*>(sb + 2), c2 = *reinterpret_cast<const double2*>(sb + 4),
+                                  c3 = *reinterpret_cast<const double2*>(sb + 6);
+                    Cm[0] = c0.x; Cm[1] = c0.y; Cm[2] = c1.x; Cm[3] = c1.y; Cm[4] = c2.x; Cm[5] = c2.y; Cm[6] = c3.x; Cm[7] = c3.y; Cm[8] = sb[8];
+                    tr = cycle_trace_regs(A, rij + 9 * (int64_t)ejk[pc], !(j < k), Cm, !(k < i));
+                } else tr = cycle_trace(A, rij + 9 * (int64_t)ejk[pc], !(j < k), rij + 9 * (int64_t)eik[pc], !(k < i));
                 S0[(int64_t)base + o] = abs_acos_ext((tr - 1.0) / 2.0) / M_PI;
             }
 #pragma unroll
             for (int c2 = 0; c2 < 4; ++c2) seen[c2] += __popcll(cm[pc][c2]);
         }
+    }
+    }
+}
+// node_seg[v] = first natural segment (edge with cycles, ascending edge id) whose smaller endpoint is >= v; node_seg[n] = m_pos.  Ind is sorted by
+// (i, j): the thread at every change of i fills the gap of nodes without segments below it.
+__global__ __launch_bounds__(256) void k_node_seg_start(const int32_t* pos_edge, const int32_t* ind_i, int64_t m_pos, int n, int32_t* node_seg) {
+    for (int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x; l < m_pos; l += (int64_t)gridDim.x * 256) {
+        const int i = ind_i[pos_edge[l]], prev = l > 0 ? ind_i[pos_edge[l - 1]] : -1;
+        for (int v = prev + 1; v <= i; ++v) node_seg[v] = (int32_t)l;
+        if (l == m_pos - 1) for (int v = i + 1; v <= n; ++v) node_seg[v] = (int32_t)m_pos;
     }
 }
 // Device-order segment tables from the plan's permutation (device-built structures): segment q of the device order is the
@@ -2149,14 +2211,19 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
     // per-edge tables and the cycle layout are then made by kernels and the host only plans.
     const bool dev_cycles = s->dev == h->device && s->d_k != nullptr;
     double* d_rij = nullptr;
+    // node_seg != NULL: the staged form (natural order: one workgroup per node, the node's rotation blocks in the LDS)
     auto launch_layout_dev = [&](const int32_t* cum, const int32_t* src_start, const int32_t* pos, const int32_t* rowptr_d, uint32_t* pk, double* S0, uint8_t* perm,
-                                 uint32_t* counts, int64_t nseg) {
-        const int g = (int)std::min<int64_t>(4096, (nseg + 3) / 4);
-        auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, h->stream, cum, src_start, pos, s->d_ii, s->d_jj, s->d_k, s->d_tau, s->d_ktau, (uint64_t)s->seed, rowptr_d,
-                               s->d_bits, s->d_rank, (int)s->words, s->d_adj_eid, d_rij, pk, S0, perm, counts, (int)nseg);
+                                 uint32_t* counts, int64_t nseg, const int32_t* node_seg) -> int {
+        const int g = node_seg ? (int)std::max<int64_t>(1, n) : (int)std::min<int64_t>(4096, (nseg + 3) / 4);
+        const size_t lds = node_seg ? (size_t)h->max_deg * 10 * sizeof(double) : 0;
+        auto go = [&](auto kern) -> int {
+            if (lds > 64 * 1024) DESC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(g), dim3(node_seg ? 512 : 256), lds, h->stream, cum, src_start, pos, s->d_ii, s->d_jj, s->d_k, s->d_tau, s->d_ktau, (uint64_t)s->seed, rowptr_d,
+                               s->d_bits, s->d_rank, (int)s->words, s->d_adj_eid, d_rij, pk, S0, perm, counts, (int)nseg, node_seg, (int)n);
+            return DESC_OK;
         };
-        if (h->max_cnt <= 64) go(k_layout_node_dev<1>); else if (h->max_cnt <= 128) go(k_layout_node_dev<2>); else go(k_layout_node_dev<4>);
+        if (node_seg) return h->max_cnt <= 64 ? go(k_layout_node_dev<1, true>) : h->max_cnt <= 128 ? go(k_layout_node_dev<2, true>) : go(k_layout_node_dev<4, true>);
+        return h->max_cnt <= 64 ? go(k_layout_node_dev<1, false>) : h->max_cnt <= 128 ? go(k_layout_node_dev<2, false>) : go(k_layout_node_dev<4, false>);
     };
     // One rank: packed words, S0_long (DESC_PGD.m:129-147) and the class order of every segment are computed NOW, in the structure's natural
     // order, under the host-side planning below; k_permute_segments moves them into the band-major order once that exists.  (Round 3 ran this
@@ -2171,8 +2238,15 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         }
         if ((rc = dalloc(h, &d_pk_nat, h->m_cycle + 8)) || (rc = dalloc(h, &d_S0_nat, h->m_cycle + 8)) || (rc = dalloc(h, &d_perm_nat, h->m_cycle + 8)) ||
             (rc = dalloc(h, &d_counts_nat, mp))) return rc;
+        // the rotation blocks of a node's row in the LDS (80 B per slot) when the longest row fits: R_ki is then an LDS read (k_layout_node_dev<., STAGED>)
+        int32_t* d_node_seg = nullptr;
+        const bool staged = (size_t)h->max_deg * 80 <= 150 * 1024 && env_int("DESC_DEBUG_STAGED_LAYOUT", 1) != 0;
+        if (staged) {
+            if ((rc = dalloc(h, &d_node_seg, (size_t)n + 1))) return rc;
+            hipLaunchKernelGGL(k_node_seg_start, dim3((unsigned)std::min<int64_t>(4096, (mp + 255) / 256)), dim3(256), 0, h->stream, s->d_pos, s->d_ii, mp, (int)n, d_node_seg);
+        }
         if (s->ev_fill) DESC_HIP(hipStreamWaitEvent(h->stream, (hipEvent_t)s->ev_fill, 0));
-        launch_layout_dev(s->d_cum, s->d_cum, s->d_pos, s->d_rowptr, d_pk_nat, d_S0_nat, d_perm_nat, d_counts_nat, mp);
+        if ((rc = launch_layout_dev(s->d_cum, s->d_cum, s->d_pos, s->d_rowptr, d_pk_nat, d_S0_nat, d_perm_nat, d_counts_nat, mp, d_node_seg))) return rc;
         DESC_HIP(hipGetLastError());
     }
     // band sweep (i-rows of S in the LDS): segments of up to 64 cycles, every CSR row fits the LDS; DESC_DEBUG_VARIANT=2 keeps
@@ -2516,7 +2590,7 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
             hipLaunchKernelGGL(k_permute_segments, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, (mp + 3) / 4))), dim3(256), 0, h->stream,
                                d_order_keep, s->d_cum, h->d_cum, d_pk_nat, d_S0_nat, d_perm_nat, d_counts_nat, h->d_pk, h->d_S0, h->d_seg_perm, d_counts, mp);
         } else if (nsl > 0)
-            launch_layout_dev(h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo, d_pos_edge2 + h->seg_lo, h->d_rowptr, h->d_pk, h->d_S0, h->d_seg_perm, d_counts + h->seg_lo, nsl);
+            if ((rc = launch_layout_dev(h->d_cum + h->seg_lo, h->d_src_start + h->seg_lo, d_pos_edge2 + h->seg_lo, h->d_rowptr, h->d_pk, h->d_S0, h->d_seg_perm, d_counts + h->seg_lo, nsl, nullptr))) return rc;
         hipLaunchKernelGGL(k_adj_seg, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (n * 16 + 255) / 256))), dim3(256), 0, h->stream,
                            h->d_rowptr, d_adj, d_adj_eid, d_devpos, h->d_cum, d_counts, (int)h->seg_lo, (int)h->seg_hi, h->d_adj_seg, (int)n);
         DESC_HIP(hipStreamSynchronize(h->stream));
