@@ -396,3 +396,23 @@ def test_fused_protocol_forced_collectives_c2(lib, monkeypatch):
     assert out["iters_run"] == 30
     assert np.array_equal(out["S_vec"], one["S_vec"])
     assert np.allclose(out["obj"], one["obj"], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("parts", ["1", "3", "4"])
+def test_exchange_parts_other_counts(lib, oracle, parts, monkeypatch):
+    """DESC_SHARD_PARTS other than the default 2 (1 = one reduce-scatter as in round 3; 3, 4: parts that need not divide a rank's bands evenly; some
+    may be empty): the same bits as one rank, for world 3 on a graph of ~24 bands."""
+    monkeypatch.setenv("DESC_DEBUG_VARIANT", "3")
+    monkeypatch.setenv("DESC_DEBUG_ROW_CAP", "560")
+    monkeypatch.setenv("DESC_SHARD_PARTS", parts)
+    mo, nn, ii, jj, rij = make_problem("uniform", n=150, p=0.6, q=0.2, sigma=0.1, seed=8)
+    st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=3, iters=25, lr=0.01)
+    outs, segs = _emulate(lib, nn, ii, jj, rij, c_params(25, lr=0.01, seed=3), 3, where=lib.BUILD_DEVICE)
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    dst = lib.Structure.build(prob, 30, 3, lib.BUILD_DEVICE, 0)
+    one = _unsharded(lib, prob, dst, c_params(25, lr=0.01, seed=3))
+    dst.free()
+    for out in outs:
+        assert ",XT>" in out["last_sweep"]
+        assert np.abs(out["S_vec"] - ref["S_vec"]).max() <= TOL and np.array_equal(out["S_vec"], one["S_vec"])
+        assert np.allclose(out["obj"], ref["obj"], rtol=1e-12, atol=1e-9)
