@@ -20,8 +20,6 @@
 #include <type_traits>
 #include <vector>
 
-#include <hipcub/hipcub.hpp>
-
 #include "device_utils.h"
 
 namespace desc {
@@ -347,24 +345,77 @@ struct DevBuf {
     }
 };
 
-// Compaction of the edges with cycles (DESC_PGD.m:36-37) and their sampled cycle counts min(codeg, n_sample) (:45): flags and counts here,
-// two exclusive scans (hipCUB), then the scatter below.
-__global__ __launch_bounds__(256) void k_flag_count(const int32_t* codeg, int n_sample, int32_t* flag, int32_t* cnt, int64_t m) {
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < m; e += (int64_t)gridDim.x * 256) {
-        const int32_t cd = codeg[e];
-        flag[e] = cd > 0 ? 1 : 0;
-        cnt[e] = cd > 0 ? min(cd, n_sample) : 0;
+// Compaction of the edges with cycles (DESC_PGD.m:36-37) and the prefix sums of their sampled cycle counts min(codeg, n_sample) (:45-49), as three
+// launches: per tile of 1024 edges the number of edges with cycles and of their cycles (k_tile_sums), an exclusive scan of the tile totals by one
+// workgroup (k_scan_tiles), and the scatter with the in-tile scan redone in the LDS (k_compact_tiles).  (The first form used hipCUB's device scans:
+// 2.4 ms of host time per build in their size queries and launches, profiles/r04_e2e_laps_c4.txt "compaction (launched)".)
+constexpr int SCAN_TILE = 1024;
+__device__ __forceinline__ void tile_counts(const int32_t* codeg, int n_sample, int64_t m, int64_t e0, int f[4], int c[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int32_t cd = e0 + u < m ? codeg[e0 + u] : 0;
+        f[u] = cd > 0 ? 1 : 0;
+        c[u] = cd > 0 ? min(cd, n_sample) : 0;
+    }
+}
+__global__ __launch_bounds__(256) void k_tile_sums(const int32_t* codeg, int n_sample, int64_t m, int32_t* tile_f, long long* tile_c) {
+    __shared__ int sf[4], sc[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int f[4], c[4];
+    tile_counts(codeg, n_sample, m, (int64_t)blockIdx.x * SCAN_TILE + 4 * threadIdx.x, f, c);
+    int tf = f[0] + f[1] + f[2] + f[3], tc = c[0] + c[1] + c[2] + c[3];
+    tf = wave_incl_scan(tf, lane); tc = wave_incl_scan(tc, lane);
+    if (lane == 63) { sf[wv] = tf; sc[wv] = tc; }
+    __syncthreads();
+    if (threadIdx.x == 0) { tile_f[blockIdx.x] = sf[0] + sf[1] + sf[2] + sf[3]; tile_c[blockIdx.x] = (long long)sc[0] + sc[1] + sc[2] + sc[3]; }
+}
+// exclusive scan of the tile totals, in place, by ONE workgroup of 1024 threads (a few thousand tiles)
+__global__ __launch_bounds__(1024) void k_scan_tiles(int32_t* tile_f, long long* tile_c, int nt) {
+    __shared__ long long sa[1024], sb[1024];
+    __shared__ long long carry_f, carry_c;
+    if (threadIdx.x == 0) { carry_f = 0; carry_c = 0; }
+    __syncthreads();
+    for (int base = 0; base < nt; base += 1024) {
+        const int t = base + threadIdx.x;
+        const long long vf = t < nt ? tile_f[t] : 0, vc = t < nt ? tile_c[t] : 0;
+        sa[threadIdx.x] = vf; sb[threadIdx.x] = vc;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const long long xf = threadIdx.x >= d ? sa[threadIdx.x - d] : 0, xc = threadIdx.x >= d ? sb[threadIdx.x - d] : 0;
+            __syncthreads();
+            sa[threadIdx.x] += xf; sb[threadIdx.x] += xc;
+            __syncthreads();
+        }
+        if (t < nt) { tile_f[t] = (int32_t)(carry_f + sa[threadIdx.x] - vf); tile_c[t] = carry_c + sb[threadIdx.x] - vc; }
+        __syncthreads();
+        if (threadIdx.x == 1023) { carry_f += sa[1023]; carry_c += sb[1023]; }
+        __syncthreads();
     }
 }
 // pos[l] = e, poe[e] = l (-1: no cycles), cum[l] = cycles before edge-with-cycles l (int32 for the kernels, int64 for the host's cum_ind)
-__global__ __launch_bounds__(256) void k_compact_edges(const int32_t* flag, const int32_t* cnt, const int32_t* posidx, const long long* cum64, int32_t* pos, int32_t* poe,
+__global__ __launch_bounds__(256) void k_compact_tiles(const int32_t* codeg, int n_sample, const int32_t* tile_f, const long long* tile_c, int32_t* pos, int32_t* poe,
                                                        int32_t* cum, long long* cumc, int64_t m, int64_t mp) {
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < m; e += (int64_t)gridDim.x * 256) {
-        if (!flag[e]) { poe[e] = -1; continue; }
-        const int32_t l = posidx[e];
+    __shared__ int sf[4], sc[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t e0 = (int64_t)blockIdx.x * SCAN_TILE + 4 * threadIdx.x;
+    int f[4], c[4];
+    tile_counts(codeg, n_sample, m, e0, f, c);
+    const int tf = f[0] + f[1] + f[2] + f[3], tc = c[0] + c[1] + c[2] + c[3];
+    const int inf = wave_incl_scan(tf, lane), inc = wave_incl_scan(tc, lane);
+    if (lane == 63) { sf[wv] = inf; sc[wv] = inc; }
+    __syncthreads();
+    int l = tile_f[blockIdx.x] + inf - tf;
+    long long cy = tile_c[blockIdx.x] + inc - tc;
+    for (int w = 0; w < wv; ++w) { l += sf[w]; cy += sc[w]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t e = e0 + u;
+        if (e >= m) break;
+        if (!f[u]) { poe[e] = -1; continue; }
         pos[l] = (int32_t)e; poe[e] = l;
-        cum[l] = (int32_t)cum64[e]; cumc[l] = cum64[e];
-        if (l == mp - 1) { cum[mp] = (int32_t)(cum64[e] + cnt[e]); cumc[mp] = cum64[e] + cnt[e]; }
+        cum[l] = (int32_t)cy; cumc[l] = cy;
+        if (l == mp - 1) { cum[mp] = (int32_t)(cy + c[u]); cumc[mp] = cy + c[u]; }
+        ++l; cy += c[u];
     }
 }
 
@@ -475,37 +526,27 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
     s->pos_edge.resize((size_t)mp);
     s->cum_ind.assign((size_t)mp + 1, 0);
     if (mp > 0) {
-        // Round 4: the compaction of the edges with cycles and the prefix sums of their cycle counts (DESC_PGD.m:36-37, 45-54) are two device
-        // scans (hipCUB) + one scatter pass on a stream of their own, the cycle-sampling kernel follows on the same stream at once, and the
+        // Round 4: the compaction of the edges with cycles and the prefix sums of their cycle counts (DESC_PGD.m:36-37, 45-54) are a tiled device
+        // scan + scatter (three launches) on a stream of their own, the cycle-sampling kernel follows on the same stream at once, and the
         // host copies pos_edge / cum_ind / codeg down for its planning WHILE that kernel runs.  (Round 3 did the compaction on the host: 4.2 ms
         // at C4 with the device idle, the three tables went back up, and only then was the sampling kernel launched.)
         hipStream_t fs = nullptr;
         DESC_HIP(stream_acquire(&fs));
         s->fill_stream = (void*)fs;
-        int32_t *d_flag = nullptr, *d_cnt = nullptr, *d_posidx = nullptr; long long *d_cum64 = nullptr, *d_cumc = nullptr;
-        auto tmp = [&](int slot, auto** out, size_t count) -> int {
+        int32_t* d_tile_f = nullptr; long long *d_tile_c = nullptr, *d_cumc = nullptr;
+        auto tmp = [&](auto** out, size_t count) -> int {
             void* q = nullptr;
             DESC_HIP(dev_alloc(&q, sizeof(**out) * (count ? count : 1)));
-            (void)slot;
             s->d_build_blocks.push_back(q);
             *out = (std::remove_reference_t<decltype(*out)>)q;
             return DESC_OK;
         };
+        const int nt = (int)((m + SCAN_TILE - 1) / SCAN_TILE);
         if ((rc = keep(&s->d_pos, mp)) || (rc = keep(&s->d_cum, mp + 1)) || (rc = keep(&s->d_poe, m)) || (rc = keep(&s->d_k, mc)) ||
-            (rc = keep(&s->d_tau, m)) || (rc = keep(&s->d_ktau, m)) || (rc = tmp(0, &d_flag, 2 * (size_t)m)) || (rc = tmp(1, &d_posidx, m)) ||
-            (rc = tmp(2, &d_cum64, m)) || (rc = tmp(3, &d_cumc, mp + 1))) return rc;
-        d_cnt = d_flag + m;
-        size_t tb1 = 0, tb2 = 0;
-        DESC_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, d_flag, d_posidx, (int)m, fs));
-        DESC_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, d_cnt, d_cum64, (int)m, fs));
-        char* d_scan_tmp = nullptr;
-        size_t tb = std::max(tb1, tb2);
-        if ((rc = tmp(4, &d_scan_tmp, tb))) return rc;
-        const unsigned ge = (unsigned)std::min<int64_t>(4096, (m + 255) / 256);
-        hipLaunchKernelGGL(k_flag_count, dim3(ge), dim3(256), 0, fs, d_codeg, (int)n_sample, d_flag, d_cnt, m);
-        DESC_HIP(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, tb, d_flag, d_posidx, (int)m, fs));
-        DESC_HIP(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, tb, d_cnt, d_cum64, (int)m, fs));
-        hipLaunchKernelGGL(k_compact_edges, dim3(ge), dim3(256), 0, fs, d_flag, d_cnt, d_posidx, d_cum64, s->d_pos, s->d_poe, s->d_cum, d_cumc, m, mp);
+            (rc = keep(&s->d_tau, m)) || (rc = keep(&s->d_ktau, m)) || (rc = tmp(&d_tile_f, nt)) || (rc = tmp(&d_tile_c, nt)) || (rc = tmp(&d_cumc, mp + 1))) return rc;
+        hipLaunchKernelGGL(k_tile_sums, dim3(nt), dim3(256), 0, fs, d_codeg, (int)n_sample, m, d_tile_f, d_tile_c);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, fs, d_tile_f, d_tile_c, nt);
+        hipLaunchKernelGGL(k_compact_tiles, dim3(nt), dim3(256), 0, fs, d_codeg, (int)n_sample, d_tile_f, d_tile_c, s->d_pos, s->d_poe, s->d_cum, d_cumc, m, mp);
         DESC_HIP(hipGetLastError());
         hipEvent_t ev_c = nullptr;
         DESC_HIP(hipEventCreateWithFlags(&ev_c, hipEventDisableTiming));
