@@ -1043,7 +1043,10 @@ __global__ __launch_bounds__(NT, 1) void k_sweep_band(BandSweepArgs b) {     // 
         {
             // up to 19 loads in flight per thread: one batch for 1024 threads, two for 512 (38 at once cost the 64 x 4 instance 3.5 %)
             constexpr int RL = (BAND_ROW_CAP + 1023) / 1024;
-            // 16 bytes per lane (half the address-unit cycles per byte, see PAIR): thread t takes the doubles 2 t, 2 t + 1 of every batch of 2 NT
+            // 16 bytes per lane (half the address-unit cycles per byte, see PAIR): thread t takes the doubles 2 t, 2 t + 1 of every batch of 2 NT.
+            // The clamped load of a one-entry band would end one double past the rows -- such a band (one node of degree 1, no triangle) never has a
+            // segment and therefore never a piece; all the same rs_S carries the array's real length (the read returns 0) and the CSR-aligned arrays
+            // are allocated two doubles longer.
             constexpr int RL2 = (RL + 1) / 2;
             for (int base = 0; base < pd.row_len; base += 2 * RL2 * NT) {
                 double v0[RL2], v1[RL2];

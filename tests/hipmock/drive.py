@@ -110,6 +110,34 @@ def main():
                 s.reset(c_params(3, seed=1)); s.shard_finish(1); s.shard_colsum(); s.shard_sweep(); s.shard_finish(0)
                 s.destroy()
         st.free()
+    # round 4: the band sweep forced on a graph cut into many bands -- exchange parts (virtual owners, per-part piece plans), the ranks' column-sum
+    # node lists, and the fused two-stream protocol with the reduce-scatter in parts (collectives: callbacks that do nothing)
+    rs_calls, ag_calls = [], []
+    rs_cb = lib.RS_FN(lambda send, recv, count, dtype, op, comm, stream: rs_calls.append((count, dtype)) or 0)
+    ag_cb = lib.AG_FN(lambda send, recv, count, dtype, comm, stream: ag_calls.append((count, dtype)) or 0)
+    os.environ["DESC_DEBUG_VARIANT"] = "3"; os.environ["DESC_DEBUG_ROW_CAP"] = "200"
+    try:
+        mo, nn, ii, jj, rij = make_problem("uniform", n=120, p=0.5, q=0.2, sigma=0.1, seed=4)
+        prob2 = lib.ProblemArrays(nn, ii, jj, rij)
+        st = lib.Structure.build(prob2, 30, 1, lib.BUILD_HOST, 0)
+        for world, parts in ((3, "2"), (8, "2"), (3, "3"), (2, "1")):
+            os.environ["DESC_SHARD_PARTS"] = parts
+            for rank in range(world):
+                s = lib.Solver(prob2, st, 0, rank, world)
+                info = s.shard_info()
+                assert info.xparts == int(parts) and info.t_len == world * info.xparts * info.t_part + 1
+                s.shard_layout()
+                s.shard_set_collectives(None, rs_cb, ag_cb)
+                n_rs = len(rs_calls)
+                s.shard_start(c_params(4, seed=1)); s.shard_iterate(3); s.sync(); s.stopped()
+                assert len(rs_calls) - n_rs == 3 * int(parts) and all(c == (info.t_part, 4) for c in rs_calls[n_rs:])      # one int64 reduce-scatter per part and iteration
+                s.download()
+                s.destroy()
+        st.free()
+    finally:
+        for k in ("DESC_DEBUG_VARIANT", "DESC_DEBUG_ROW_CAP", "DESC_SHARD_PARTS"):
+            os.environ.pop(k, None)
+    print("ok exchange parts / fused protocol", flush=True)
     lib.verify_guards()
     lib.trim_memory()
     assert L.hipmock_live_blocks() == 0, "device blocks leaked"
