@@ -528,7 +528,8 @@ def bench_sharded(args, WORKLOADS, describe, generate, cpu_baseline):
         "rccl_ranks": rccl_ranks, "rccl_ranks_source": rccl_source,
         "config": {"workload": r["workload"], "n": r["nn"], "m": r["m"], "m_pos": r["m_pos"], "m_cycle": r["m_cycle"],
                    "n_sample": r["n_sample"], "sampling_seed": args.seed,
-                   "parallelism": f"edges sharded over {world} GPUs; reduce-scatter of the mirror sums (2 m_pos f64) + all-gather S per iteration; " + r["driver"]},
+                   "parallelism": f"edges sharded over {world} GPUs by node ranges; per iteration: reduce-scatter of the mirror sums (2 m_pos int64 fixed-point words, "
+                                  f"in exchange parts under the sweep) + all-gather of S; " + r["driver"]},
         "roofline": {"bound": "hbm", "achieved": bytes_iter / (dt / K) / 1e9, "peak": 8000.0 * world, "unit": "GB/s",
                      "frac": bytes_iter / (dt / K) / 1e9 / (8000.0 * world), "traffic": None,
                      "kernel": "whole iteration incl. collectives (aggregate over ranks)", "bytes_per_launch": bytes_iter},
