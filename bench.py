@@ -235,7 +235,8 @@ def measure(lib, name, K, W, seed, convergence, keep_arrays, n_sample_min=30):
     # weight, S0, packed word), the column sums' 10 bytes per (cycle, endpoint) whose mirror was sampled (weight + 16-bit column index),
     # 12 bytes per segment (record + new S).  The 72-byte count above prices four 8-byte gathers per cycle that the band layout serves from
     # the LDS and the caches: on graphs that fit the caches `frac` can therefore exceed 1 -- it is the contract's figure, not an HBM fraction.
-    floor_bytes = 28.0 * m_cycle + 10.0 * lay.get("colsum_entries", 0) + 12.0 * m_pos if ("node" in kname or "band" in kname) else bytes_per_launch
+    node_layout = any(x in kname for x in ("node", "band", "small"))
+    floor_bytes = 28.0 * m_cycle + 10.0 * lay.get("colsum_entries", 0) + 12.0 * m_pos if node_layout else bytes_per_launch
     sec = ms_kernel * 1e-3 if ms_kernel else float("inf")
     res = dict(
         name=name, mo=mo, nn=nn, ii=ii, jj=jj, rij=rij, prob=prob, arrays=arrays, dt=dt, out=out, m=m, m_pos=m_pos, m_cycle=m_cycle,
@@ -248,7 +249,7 @@ def measure(lib, name, K, W, seed, convergence, keep_arrays, n_sample_min=30):
                   "note": "frac = 72-byte algorithmic count / kernel time / 8 TB/s (the contract's figure; it prices gathers the band layout serves "
                           "from LDS and caches, so it can exceed 1 on cache-resident graphs); frac_traffic = PMC-measured HBM bytes over the same time",
                   "layout": lay,
-                  "kernel": ("k_colsum_node + " + kname + "0> (one iteration = both launches)") if ("node" in kname or "band" in kname) else kname,
+                  "kernel": ("k_colsum_node + " + kname + "0> (one iteration = both launches)") if node_layout else kname,
                   "bytes_per_launch": bytes_per_launch, "kernel_ms": ms_kernel},
         setup_ms={"generate": t_gen * 1e3, "structure_device": t_struct * 1e3, "upload_layout_cycle_d": t_create * 1e3},
         end_to_end={"ms": t_e2e * 1e3, "what": "one timed desc_pgd_solve call: host arrays in -> S_vec out, 100 iterations, warm HIP context, every block allocated afresh",

@@ -678,6 +678,51 @@ __global__ __launch_bounds__(SWEEP_THREADS, STEP == DESC_STEP_HYBRID ? 3 : 4) vo
     block_partials(obj_acc, chg_acc, a.partials, lb);
 }
 
+// SMALL graphs (round 4; the reference's own demo sizes, Demo/compare_algorithms.m:10: n = 100-200, configs[0]): an iteration of a few hundred
+// thousand cycles is not bandwidth- but latency-bound -- k_sweep_node's staged chunk pipeline is a chain of ~6 dependent memory round trips for one
+// chunk per workgroup (C1: 11.7 us per sweep for ~1 us of traffic).  Here a lane group of G lanes takes a whole segment (one cycle per lane) straight
+// from global memory: records -> packed words / weights / S0 -> the gathers of S and the mirror sums -> arithmetic -> stores, three dependent round
+// trips.  Same per-segment arithmetic as the gather layout's k_sweep (group reductions over G lanes, Michelot threshold), on the node layout's arrays.
+template <int G, int STEP>
+__global__ __launch_bounds__(256) void k_sweep_small(NodeSweepArgs a, int n_seg) {
+    if (a.state->stop) return;
+    constexpr int EPW = 64 / G;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = lane / G, gl = lane % G;
+    double obj_acc = 0.0, chg_acc = 0.0;
+    for (int l0 = ((int)blockIdx.x * 4 + wv) * EPW; l0 < n_seg; l0 += (int)gridDim.x * 4 * EPW) {
+        const int l = l0 + sub;
+        const bool seg_ok = l < n_seg;
+        int base = 0, cnt = 0;
+        EdgeInfo ei{0, 0, 0, 0};
+        if (seg_ok) { base = a.cum[l]; cnt = a.cum[l + 1] - base; ei = a.einfo[l]; }
+        const bool act0 = gl < cnt;
+        const int64_t c = (int64_t)base + gl;
+        uint32_t p = 0; double w = 0.0, d = 0.0, ssum = 0.0;
+        if (act0) {
+            p = a.pk[c]; w = a.w_old[c]; d = a.S0[c];
+            ssum = a.S_old[ei.rb_j + (int)((p >> 16) & 0x7FFFu)] + a.S_old[ei.rb_i + (int)(p & 0x7FFFu)];          // S(jk) + S(ki)
+        }
+        double T1 = 0.0, T2 = 0.0, So = 0.0;
+        if (seg_ok) { T1 = fx_to_double(a.Tfull[ei.slot_a], a.fx_inv); T2 = fx_to_double(a.Tfull[ei.slot_b], a.fx_inv); So = a.S_old[ei.slot_a]; }
+        obj_acc += w * ssum;                                                                                     // :233, one sweep late
+        double g = ssum + (((p & 0x8000u) ? T1 : 0.0) + ((p & 0x80000000u) ? T2 : 0.0)) * d;                     // :193
+        const double nv = act0 ? a.nv_tab[cnt] : 0.0;
+        const double dot = group_sum<G>(act0 ? g * nv : 0.0);                                                    // :199-201
+        g = g - dot * nv;
+        const double ws = act0 ? apply_step<STEP>(a.st, w, g, c) : 0.0;                                          // :207
+        const double T = simplex_threshold<G>(ws, act0, lane);                                                   // :215-223
+        const double wn = act0 ? fmax(ws - T, 0.0) : 0.0;                                                        // :224
+        const double snew = group_sum<G>(wn * d);                                                                // :229
+        if (act0) a.w_new[c] = wn;
+        if (seg_ok && cnt > 0 && gl == 0) {
+            chg_acc += fabs(snew - So);                                                                          // :232
+            a.S_new[ei.slot_a] = snew; a.S_new[ei.slot_b] = snew;
+        }
+    }
+    block_partials(obj_acc, chg_acc, a.partials, blockIdx.x);
+}
+
 // ===========================================================================
 // BAND sweep: the same arithmetic with the i-rows of S in the LDS
 // ===========================================================================
@@ -1803,6 +1848,8 @@ struct desc_pgd {
     int64_t n_pieces = 0, n_bands = 0, piece_row_entries = 0;    // band sweep plan: pieces, bands, CSR entries of band rows loaded per sweep
     int band = 0;
     bool band_ok = false;       // k_sweep_band applies (segments <= 64 cycles, rows fit the LDS)
+    bool small_ok = false;      // k_sweep_small: one rank, < 2 M cycles, segments of at most 64 cycles (the reference's demo sizes)
+    int small_grid = 0, small_g = 64;
     int band_grid = 0, band_rows = 0;
     size_t band_lds = 0;
     PieceDesc* d_pieces = nullptr;
@@ -2049,18 +2096,33 @@ void launch_band(desc_pgd* h, const NodeSweepArgs& a, int part = 0) {
         }
     }
 }
+template <int STEP>
+void launch_small(desc_pgd* h, const NodeSweepArgs& a) {
+    const dim3 grid(h->small_grid), block(256);
+    { char nm[64]; snprintf(nm, sizeof nm, "k_sweep_small<%d,%d>", h->small_g, STEP); h->last_sweep = nm; }
+    const int ns = (int)(h->seg_hi - h->seg_lo);
+    switch (h->small_g) {
+        case 16: hipLaunchKernelGGL((k_sweep_small<16, STEP>), grid, block, 0, h->stream, a, ns); break;
+        case 32: hipLaunchKernelGGL((k_sweep_small<32, STEP>), grid, block, 0, h->stream, a, ns); break;
+        default: hipLaunchKernelGGL((k_sweep_small<64, STEP>), grid, block, 0, h->stream, a, ns); break;
+    }
+}
 void launch_sweep_node_layout(desc_pgd* h, const NodeSweepArgs& a, bool adam, int part = 0) {
-    if (h->band_ok && !adam) launch_band<DESC_STEP_CONSTANT>(h, a, part);
+    if (h->small_ok && a.partials == h->d_partials) { if (adam) launch_small<DESC_STEP_HYBRID>(h, a); else launch_small<DESC_STEP_CONSTANT>(h, a); }      // the plain one-rank path only
+    else if (h->band_ok && !adam) launch_band<DESC_STEP_CONSTANT>(h, a, part);
     else if (adam && band_adam_ok(h)) launch_band<DESC_STEP_HYBRID>(h, a, part);
     else if (adam) launch_node<DESC_STEP_HYBRID>(h, a);
     else launch_node<DESC_STEP_CONSTANT>(h, a);
 }
 // workgroups (= partial pairs) of the sweep kernel that serves this step kind
-int sweep_parts(const desc_pgd* h, bool adam) { return h->variant == VARIANT_NODE && (adam ? band_adam_ok(h) : h->band_ok) ? h->band_grid + h->band_ntail : h->grid; }
+int sweep_parts(const desc_pgd* h, bool adam, bool plain_path = false) {
+    if (plain_path && h->variant == VARIANT_NODE && h->small_ok) return h->small_grid;
+    return h->variant == VARIANT_NODE && (adam ? band_adam_ok(h) : h->band_ok) ? h->band_grid + h->band_ntail : h->grid;
+}
 
 // second half of d_partials: the objective kernel of a download writes there, so the partials of the last sweep stay intact and
 // book-keeping that sweep again (a replayed column-sum launch after a flush or a download) rewrites the same numbers
-size_t parts_cap(const desc_pgd* h) { return (size_t)std::max(std::max(h->grid, h->obj_grid), h->band_grid + h->band_ntail); }
+size_t parts_cap(const desc_pgd* h) { return (size_t)std::max(std::max(std::max(h->grid, h->obj_grid), h->band_grid + h->band_ntail), h->small_grid); }
 double* obj_partials(const desc_pgd* h) { return h->d_partials + 2 * parts_cap(h); }
 FinArgs fin_args(const desc_pgd* h, const double* partials, int nparts, int t, int last_only) {
     return FinArgs{partials, h->d_state, h->d_obj, h->d_avg, h->m, h->p.stop_tol, nparts, t, h->p.patience, last_only, 0, 1};
@@ -2114,7 +2176,7 @@ int enqueue_sweep(desc_pgd* h, int t, hipEvent_t ev0 = nullptr, hipEvent_t ev1 =
         if (adam) launch_gather<DESC_STEP_HYBRID>(h, a); else launch_gather<DESC_STEP_CONSTANT>(h, a);
     }
     if (ev1) (void)hipEventRecord(ev1, h->stream);
-    h->pending_fin = t; h->pending_parts = sweep_parts(h, adam);
+    h->pending_fin = t; h->pending_parts = sweep_parts(h, adam, true);
     if (h->variant != VARIANT_NODE) flush_finalize(h);         // no column-sum launch to ride on
     DESC_HIP(hipGetLastError());
     return DESC_OK;
@@ -2571,8 +2633,13 @@ int setup_node(desc_pgd* h, const desc_problem* prob, const desc_structure* s, c
         for (const void* kb : {band_kernel<DESC_STEP_CONSTANT, false>(h), band_kernel<DESC_STEP_HYBRID, false>(h), band_kernel<DESC_STEP_CONSTANT, true>(h), band_kernel<DESC_STEP_HYBRID, true>(h)})
             if (kb && hipFuncSetAttribute(kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->band_lds) != hipSuccess) { (void)hipGetLastError(); h->band_ok = false; }
     }
+    // the reference's demo sizes: the latency-lean sweep (DESC_DEBUG_VARIANT = 2 / 3 keep k_sweep_node / the band sweep for the cross-checks)
+    h->small_ok = force_band == 0 && !h->band_ok && h->world == 1 && h->max_cnt <= 64 && h->m_cycle < (2 << 20) && env_int("DESC_DEBUG_SMALL", 1) != 0;
+    h->small_g = h->max_cnt <= 16 ? 16 : h->max_cnt <= 32 ? 32 : 64;
+    h->small_grid = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (nsl + 4 * (64 / h->small_g) - 1) / (4 * (64 / h->small_g))));
     char nm[64];
-    if (h->band_ok) { const BandShape sh = band_shape(h, false); snprintf(nm, sizeof nm, "k_sweep_band<%d,%d,", sh.lps, sh.E); }
+    if (h->small_ok) snprintf(nm, sizeof nm, "k_sweep_small<%d,", h->small_g);
+    else if (h->band_ok) { const BandShape sh = band_shape(h, false); snprintf(nm, sizeof nm, "k_sweep_band<%d,%d,", sh.lps, sh.E); }
     else snprintf(nm, sizeof nm, "k_sweep_node<%d,%d,", h->lps, h->G);
     h->kname = nm;
 

@@ -311,7 +311,7 @@ def test_device_resident_structure_layout(lib, oracle, n, p, seed, kind):
     dev_st = lib.Structure.build(prob, 30, 21, lib.BUILD_DEVICE, 0)
     solver = lib.Solver(prob, dev_st, 0)          # before any .arrays(): the host copy does not exist yet
     try:
-        assert "node" in solver.kernel_name() or "band" in solver.kernel_name()
+        assert any(x in solver.kernel_name() for x in ("node", "band", "small"))      # the node layout (not the gather fallback); "small": its latency-lean sweep for tiny graphs
         s0 = solver.s0()
         out = solver.run(c_params(60, seed=21, **step), want_w=True)
     finally:
@@ -566,3 +566,30 @@ def test_fuzz_case_945063979_is_roundoff(lib, oracle):
             assert err <= (1e-12 if iters == 7 else 4 * yard), (variant, iters, err, yard)
         assert yard < (2e-13 if iters == 7 else 5e-10)
         assert np.array_equal(outs["band"]["w"], outs["node"]["w"]) and np.array_equal(outs["band"]["S_vec"], outs["node"]["S_vec"])
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_small_graph_sweep_matches_oracle_and_node_kernel(lib, oracle, kind, monkeypatch):
+    """The latency-lean sweep of small graphs (k_sweep_small, the default below 2 M cycles: the reference's demo sizes, Demo/compare_algorithms.m:10)
+    against the oracle and against k_sweep_node on the same handle layout, all three step plugins."""
+    mo, nn, ii, jj, rij = make_problem("uniform", n=200, p=0.5, q=0.2, sigma=0.1, seed=31)
+    step = dict(step_kind=kind, lr=0.01)
+    st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=2, iters=50, **step)
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    outs = {}
+    for small in ("1", "0"):
+        monkeypatch.setenv("DESC_DEBUG_SMALL", small)
+        dst = lib.Structure.build(prob, 30, 2, lib.BUILD_DEVICE, 0)
+        solver = lib.Solver(prob, dst, 0)
+        dst.free()
+        assert ("small" in solver.kernel_name()) == (small == "1")
+        outs[small] = solver.run(c_params(50, seed=2, **step), want_w=True)
+        outs[small]["last"] = solver.last_sweep()
+        solver.destroy()
+    assert "k_sweep_small" in outs["1"]["last"] and "k_sweep_node" in outs["0"]["last"]
+    tol = 1e-9 if kind == 2 else TOL
+    for out in outs.values():
+        assert out["iters_run"] == ref["iters_run"]
+        assert np.abs(out["S_vec"] - ref["S_vec"]).max() <= tol and np.abs(out["w"] - ref["w"]).max() <= tol
+        assert np.allclose(out["obj"], ref["obj"], rtol=1e-12, atol=1e-9)
+    assert np.abs(outs["1"]["S_vec"] - outs["0"]["S_vec"]).max() <= 1e-12
