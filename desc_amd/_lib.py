@@ -30,6 +30,7 @@ EXPORTS = [
     "desc_pgd_create_shard", "desc_pgd_shard_info", "desc_pgd_shard_bind", "desc_pgd_shard_colsum", "desc_pgd_shard_sweep",
     "desc_pgd_shard_finish", "desc_pgd_shard_objective", "desc_pgd_shard_set_collectives", "desc_pgd_shard_start",
     "desc_pgd_shard_iterate", "desc_pgd_shard_run", "desc_pgd_stopped", "desc_device_synchronize", "desc_memcpy_d2h", "desc_memcpy_h2d", "desc_debug_band_plan", "desc_debug_spmm_variants", "desc_debug_wg_clock", "desc_debug_wg_plan", "desc_debug_last_sweep", "desc_debug_shard_layout", "desc_trim_memory", "desc_spectral_run", "desc_cemp_run", "desc_refine_run",
+    "desc_marshal_edges", "desc_marshal_rij",
 ]
 
 I32P = C.POINTER(C.c_int32)
@@ -157,6 +158,8 @@ def load():
     L.desc_pgd_get_s0.argtypes = [C.c_void_p, F64P]
     L.desc_pgd_sizes.argtypes = [C.c_void_p, I64P, I64P, I64P, I32P]
     L.desc_pgd_solve.argtypes = [C.POINTER(Problem), C.POINTER(Params), C.POINTER(Result)]
+    L.desc_marshal_edges.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, I32P, I32P, I64P, I32P]
+    L.desc_marshal_rij.argtypes = [F64P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, I64P, F64P]
     L.desc_pgd_create_shard.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.desc_pgd_shard_info.argtypes = [C.c_void_p, C.POINTER(ShardInfo)]
     L.desc_pgd_shard_bind.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -520,6 +523,32 @@ class Solver:
             self.destroy()
         except Exception:
             pass
+
+
+DTYPE_CODES = {np.dtype(np.float64): 0, np.dtype(np.int64): 1, np.dtype(np.int32): 2}      # DESC_DTYPE_*
+
+
+def marshal_edges_native(Ind):
+    """desc_marshal_edges: m x 2 array of 1-based node ids (float64 / int64 / int32, any strides) -> (n, ind_i, ind_j, sorted)."""
+    if Ind.dtype not in DTYPE_CODES:
+        Ind = Ind.astype(np.int64 if np.issubdtype(Ind.dtype, np.integer) else np.float64)
+    m = Ind.shape[0]
+    ii = np.empty(m, dtype=np.int32)
+    jj = np.empty(m, dtype=np.int32)
+    n, srt = C.c_int64(0), C.c_int32(0)
+    item = Ind.dtype.itemsize
+    check(load().desc_marshal_edges(C.c_void_p(Ind.ctypes.data), DTYPE_CODES[Ind.dtype], m, Ind.strides[0] // item, Ind.strides[1] // item,
+                                    ptr(ii, I32P), ptr(jj, I32P), C.byref(n), C.byref(srt)))
+    return int(n.value), ii, jj, bool(srt.value)
+
+
+def marshal_rij_native(R, perm=None):
+    """desc_marshal_rij: (3, 3, m) float64 array with any strides (+ edge permutation) -> the ABI's (m * 9,) buffer."""
+    m = R.shape[2]
+    out = np.empty(9 * m, dtype=np.float64)
+    pp = None if perm is None else np.ascontiguousarray(perm, dtype=np.int64)
+    check(load().desc_marshal_rij(ptr(R, F64P), m, R.strides[0] // 8, R.strides[1] // 8, R.strides[2] // 8, ptr(pp, I64P), ptr(out, F64P)))
+    return out
 
 
 def solve(prob: ProblemArrays, params: Params, want_w=False):

@@ -57,31 +57,32 @@ def marshal_edges(Ind, RijMat=None):
     if Ind.ndim != 2 or Ind.shape[1] != 2:
         raise ValueError("Ind must be m x 2")
     m = Ind.shape[0]
-    Ii = Ind[:, 0].astype(np.int64)
-    Ij = Ind[:, 1].astype(np.int64)
-    if m and (np.any(Ii != Ind[:, 0]) or np.any(Ij != Ind[:, 1])):
+    if Ind.dtype.kind not in "iuf":
         raise ValueError("Ind must hold integer node ids")
-    if m and (Ii.min() < 1 or np.any(Ii >= Ij)):
-        raise ValueError("Ind rows must be 1-based with Ind(:,1) < Ind(:,2)")
-    n = int(Ind.max()) if m else 0                                # DESC_PGD.m:21
+    try:        # one threaded pass of the library (desc_marshal_edges): checks, 0-based int32 endpoints, n = max(Ind(:)) (DESC_PGD.m:21), order
+        n, ii, jj, is_sorted = _lib.marshal_edges_native(Ind)
+    except _lib.DescError as e:
+        if e.code != _lib.ERR_INVALID:
+            raise
+        raise ValueError(str(e).split(": ", 1)[-1]) from None
     perm = None
-    if m > 1:
-        key = Ii * (n + 1) + Ij
-        if np.any(key[1:] <= key[:-1]):
-            perm = np.lexsort((Ij, Ii))
-            if np.any(np.diff(key[perm]) == 0):
-                raise ValueError("Ind lists an edge twice")
-            Ii, Ij = Ii[perm], Ij[perm]
+    if not is_sorted:
+        perm = np.lexsort((jj, ii))
+        ii, jj = ii[perm], jj[perm]
+        if m > 1 and np.any((ii[1:] == ii[:-1]) & (jj[1:] == jj[:-1])):
+            raise ValueError("Ind lists an edge twice")
     rij = None
     if RijMat is not None:
         R = np.asarray(RijMat, dtype=np.float64)
         if R.shape != (3, 3, m):
             raise ValueError("RijMat must be 3 x 3 x m")
-        if perm is not None:
-            R = R[:, :, perm]
-        # MATLAB memory order of a 3x3xm array: r + 3c + 9l
-        rij = np.ascontiguousarray(np.transpose(R, (2, 1, 0))).reshape(-1)
-    return n, (Ii - 1).astype(np.int32), (Ij - 1).astype(np.int32), rij, perm
+        if perm is None and R.flags.f_contiguous:
+            rij = R.reshape(-1, order="F")            # MATLAB memory order of a 3x3xm array, r + 3c + 9l: the ABI's own, no copy
+        else:
+            if any(st % 8 for st in R.strides):
+                R = np.ascontiguousarray(R)
+            rij = _lib.marshal_rij_native(R, perm)    # any other strides (NumPy's C order) and / or the edge permutation: one threaded pass
+    return n, ii, jj, rij, perm
 
 
 def gradient_to_params(G, p: _lib.Params):
@@ -151,6 +152,23 @@ def DESC_PGD(Ind, RijMat, params, return_info=False, _marshalled=None):
         cb = _lib.PROGRESS_FN(_line)
         p.progress = C.cast(cb, C.c_void_p)
         p.verbose = 0
+    hybrid_state = isinstance(G, HybridGradient) and G.strategy == 0       # carries m_cycle-long moment vectors in and out
+    if _marshalled is None and not make_plots and not return_info and not hybrid_state:
+        # the reference's own signature, S_vec = DESC_PGD(Ind, RijMat, params): ONE C call (desc_pgd_solve), in which the rotations go up
+        # while the structure is built (C4: 13 ms hidden)
+        if verbose:
+            print("compute R cycle")                      # DESC_PGD.m:132
+            print("S0Mat")                                # :145
+            print("Initialization completed!")            # :160
+            print("Reweighting Procedure Started ...")    # :162
+        out = _lib.solve(prob, p)
+        if isinstance(G, (PiecewiseStepSize, HybridGradient)):
+            G.t = int(out["t_end"])
+        if perm is None:
+            return out["S_vec"]
+        S_vec = np.empty_like(out["S_vec"])
+        S_vec[perm] = out["S_vec"]
+        return S_vec
     try:
         st = _lib.Structure.build(prob, p.n_sample_min, p.seed, p.build_where, p.device)
     except _lib.DescError as e:

@@ -339,6 +339,23 @@ int desc_refine_run_dev(const desc_device_problem* dp, const double* s_vec, cons
  * uploads, runs, downloads, frees. */
 int desc_pgd_solve(const desc_problem* prob, const desc_params* p, desc_result* r);
 
+/* Host-side marshalling of the reference's argument formats (no device code; a binding that already holds 0-based int32 endpoints and
+ * MATLAB's own 3 x 3 x m memory -- the MEX shim -- needs neither).
+ * desc_marshal_edges: `Ind` as the caller of DESC_PGD.m:14 holds it -- m x 2 node ids, 1-based, Ind(:,1) < Ind(:,2), as doubles (MATLAB),
+ * int64 or int32 -- read through element strides (row_stride, col_stride: MATLAB's column-major m x 2 = (1, m), NumPy's row-major = (2, 1))
+ * into the ABI's 0-based int32 endpoints in ONE threaded pass.  *n_out = max(Ind(:)) (DESC_PGD.m:21); *sorted_out = 1 if the rows are
+ * strictly ascending by (i, j) (what DESC_PGD.m:5 requires and desc_problem expects), 0 if the caller still has to sort (and to look for
+ * duplicates).  DESC_ERR_INVALID: a value that is not an integer, an id < 1, or a row with Ind(:,1) >= Ind(:,2) (first offending row in the text).
+ * desc_marshal_rij: out[9 l + r + 3 c] = R[r stride_r + c stride_c + perm[l] stride_l] -- any strided 3 x 3 x m array of doubles (NumPy's
+ * C order: strides (3m, m, 1); MATLAB's order (1, 3, 9) is the ABI's own and needs no call) into desc_problem.rij, edges permuted by
+ * `perm` (sorted position -> caller's row; NULL: identity). */
+#define DESC_DTYPE_F64 0
+#define DESC_DTYPE_I64 1
+#define DESC_DTYPE_I32 2
+int desc_marshal_edges(const void* ind, int32_t dtype, int64_t m, int64_t row_stride, int64_t col_stride,
+                       int32_t* ind_i, int32_t* ind_j, int64_t* n_out, int32_t* sorted_out);
+int desc_marshal_rij(const double* R, int64_t m, int64_t stride_r, int64_t stride_c, int64_t stride_l, const int64_t* perm, double* out);
+
 /* The library parks the device blocks of destroyed handles / structures / problems for reuse by the next call (up to
  * DESC_CACHE_MB megabytes per process, default 8192: hipFree + hipMalloc of the gigabyte-sized per-cycle arrays cost 10-20 ms
  * per solve), and likewise the large host-side index vectors of its setup (up to DESC_HOST_CACHE_MB, default 1024: first-touch

@@ -73,19 +73,27 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     p.verbose = 0;
     if (field_or(prhs[2], "verbose", 0) != 0) p.progress = mex_progress;    /* per-iteration lines through mexPrintf, as they happen */
 
-    /* sizes of the per-cycle vectors are only known after the structure is built */
+    const int make_plots = field_or(prhs[2], "make_plots", 0) != 0;
+    /* The common call -- no per-iteration GCW, no moment vectors to carry -- is ONE library call (desc_pgd_solve): the rotations go up
+     * while the structure is built.  Otherwise the structure comes first: the per-cycle vectors (HybridGradient.m_t / v_t) are sized by it. */
+    const int one_call = !make_plots && !(p.step_kind == DESC_STEP_HYBRID && p.hybrid_strategy == 0);
     desc_structure* st = NULL;
-    int rc = desc_structure_build(&prob, p.n_sample_min, p.seed, p.build_where, p.device, &st);
-    if (rc == DESC_ERR_TOO_LARGE && p.build_where == DESC_BUILD_DEVICE)   /* beyond the device builder's staging budget */
-        rc = desc_structure_build(&prob, p.n_sample_min, p.seed, DESC_BUILD_HOST, p.device, &st);
-    if (rc != DESC_OK) mexErrMsgIdAndTxt("desc_amd:structure", "%s", desc_last_error());
-    desc_structure_info v;                     /* O(1): the structure stays in HBM */
-    if (desc_structure_sizes(st, &v) != DESC_OK) {
-        desc_structure_free(st);
-        mexErrMsgIdAndTxt("desc_amd:structure", "%s", desc_last_error());
+    int rc = DESC_OK;
+    mwSize mc = 0;
+    double ms_structure = 0.0;
+    if (!one_call) {
+        rc = desc_structure_build(&prob, p.n_sample_min, p.seed, p.build_where, p.device, &st);
+        if (rc == DESC_ERR_TOO_LARGE && p.build_where == DESC_BUILD_DEVICE)   /* beyond the device builder's staging budget */
+            rc = desc_structure_build(&prob, p.n_sample_min, p.seed, DESC_BUILD_HOST, p.device, &st);
+        if (rc != DESC_OK) mexErrMsgIdAndTxt("desc_amd:structure", "%s", desc_last_error());
+        desc_structure_info v;                     /* O(1): the structure stays in HBM */
+        if (desc_structure_sizes(st, &v) != DESC_OK) {
+            desc_structure_free(st);
+            mexErrMsgIdAndTxt("desc_amd:structure", "%s", desc_last_error());
+        }
+        mc = (mwSize)v.m_cycle;
+        ms_structure = v.ms_build;
     }
-    const mwSize mc = (mwSize)v.m_cycle;
-    const double ms_structure = v.ms_build;
 
     plhs[0] = mxCreateDoubleMatrix(1, m, mxREAL);
     mxArray* obj = mxCreateDoubleMatrix(1, p.iters > 0 ? p.iters : 1, mxREAL);
@@ -107,10 +115,12 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     r.avg_change_trace = mxGetPr(avg);
     if (p.step_kind == DESC_STEP_HYBRID && p.hybrid_strategy == 0) { r.adam_m = mxGetPr(am); r.adam_v = mxGetPr(av); }
 
-    const int make_plots = field_or(prhs[2], "make_plots", 0) != 0;
     mxArray *se = NULL, *rall = NULL;
     desc_pgd* h = NULL;
-    if (!make_plots) {
+    if (one_call) {
+        rc = desc_pgd_solve(&prob, &p, &r);
+        ms_structure = r.ms_structure;
+    } else if (!make_plots) {
         rc = desc_pgd_create(&prob, st, p.device, &h);
         desc_structure_free(st);
         if (rc == DESC_OK) rc = desc_pgd_run(h, &p, &r);

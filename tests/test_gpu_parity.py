@@ -277,6 +277,36 @@ def test_desc_pgd_wrapper_unsorted_input_and_plugin_state(lib, oracle):
     assert np.abs(H.m_t - am).max() < 1e-9 and np.abs(H.v_t - av).max() < 1e-9
 
 
+def test_desc_pgd_wrapper_one_call_path_equals_the_three_call_path(lib, oracle):
+    """S_vec = DESC_PGD(Ind, RijMat, params) -- the reference's own signature -- is ONE desc_pgd_solve call (rotations uploaded under the structure
+    build); with return_info the wrapper builds the structure first.  Same bits either way, whatever memory order and element type the caller's
+    arrays have (desc_marshal_edges / desc_marshal_rij), permuted rows included; Piecewise counter carried on both paths."""
+    from desc_amd import DESC_PGD, ConstantStepSize, PiecewiseStepSize
+    mo, nn, ii, jj, rij = make_problem("uniform", n=120, p=0.5, q=0.2, sigma=0.1, seed=8)
+    st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=4, iters=25, lr=0.01)
+    par = lambda: dict(iters=25, Gradient=ConstantStepSize(0.01), seed=4, verbose=False)
+    S_info, info = DESC_PGD(mo.Ind, mo.RijMat, par(), return_info=True)
+    assert np.abs(S_info - ref["S_vec"]).max() <= TOL and info["iters_run"] == ref["iters_run"]
+    perm = np.random.default_rng(5).permutation(mo.Ind.shape[0])
+    for Ind, R, back in ((mo.Ind, mo.RijMat, None), (mo.Ind.astype(np.int32), np.ascontiguousarray(mo.RijMat), None),
+                         (np.asfortranarray(mo.Ind.astype(np.float64)), mo.RijMat.copy(order="C"), None),
+                         (mo.Ind[perm], np.ascontiguousarray(mo.RijMat[:, :, perm]), perm)):
+        S = DESC_PGD(Ind, R, par())
+        assert np.array_equal(S, S_info if back is None else S_info[back])
+    # the big-input branch of desc_pgd_solve (rotations on a helper thread), forced on this small graph
+    os.environ["DESC_DEBUG_OVERLAP_UPLOAD"] = "2"
+    try:
+        assert np.array_equal(DESC_PGD(mo.Ind, mo.RijMat, par()), S_info)
+    finally:
+        del os.environ["DESC_DEBUG_OVERLAP_UPLOAD"]
+    Ga, Gb = PiecewiseStepSize(0.05, 4), PiecewiseStepSize(0.05, 4)
+    for _ in range(2):
+        Sa = DESC_PGD(mo.Ind, mo.RijMat, dict(iters=6, Gradient=Ga, seed=4, verbose=False))
+        Sb, _i = DESC_PGD(mo.Ind, mo.RijMat, dict(iters=6, Gradient=Gb, seed=4, verbose=False), return_info=True)
+        assert np.array_equal(Sa, Sb) and Ga.t == Gb.t
+    assert Ga.t == 12
+
+
 @pytest.mark.parametrize("kind,n,p", [("uniform", 12, 0.6), ("uniform", 40, 0.5), ("uniform", 150, 0.55), ("uniform", 500, 0.1),
                                       ("nonuniform", 120, 0.4), ("uniform", 300, 0.9)])
 def test_device_structure_build_bit_exact(lib, oracle, kind, n, p):

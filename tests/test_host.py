@@ -170,6 +170,58 @@ def test_marshal_edges_sorts_and_unpermutes():
         marshal_edges(mo.Ind, mo.RijMat[:, :, :-1])
 
 
+def _marshal_reference(Ind, R):
+    """What marshal_edges has to return for sorted input, stated with plain NumPy."""
+    Ind = np.asarray(Ind)
+    ii, jj = (Ind[:, 0] - 1).astype(np.int32), (Ind[:, 1] - 1).astype(np.int32)
+    rij = np.stack([np.asarray(R)[r, c, :] for c in range(3) for r in range(3)], axis=1).reshape(-1)      # r + 3c + 9l
+    return int(Ind.max()), ii, jj, rij
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.int64, np.int32, np.float32, np.uint16])
+def test_marshal_natives_formats_and_strides(lib, dtype):
+    """desc_marshal_edges / desc_marshal_rij (the caller's side of DESC_PGD.m:14): every element type and memory order a NumPy or MATLAB
+    caller may hold gives the same ABI arrays."""
+    mo = Uniform_Topology(30, 0.5, 0.2, 0.1, seed=9)
+    m = mo.Ind.shape[0]
+    n0, ii0, jj0, rij0 = _marshal_reference(mo.Ind, mo.RijMat)
+    wide = np.zeros((m, 6), dtype=dtype); wide[:, 1] = mo.Ind[:, 0]; wide[:, 4] = mo.Ind[:, 1]
+    big = np.zeros((3, 3, 2 * m)); big[:, :, ::2] = mo.RijMat
+    for Ind in (mo.Ind.astype(dtype), np.asfortranarray(mo.Ind.astype(dtype)), wide[:, 1::3]):
+        for R in (np.ascontiguousarray(mo.RijMat), np.asfortranarray(mo.RijMat), big[:, :, ::2], np.ascontiguousarray(mo.RijMat.transpose(2, 0, 1)).transpose(1, 2, 0)):
+            n, ii, jj, rij, perm = marshal_edges(Ind, R)
+            assert perm is None and n == n0 and ii.dtype == np.int32 and jj.dtype == np.int32
+            assert np.array_equal(ii, ii0) and np.array_equal(jj, jj0) and np.array_equal(rij, rij0)
+    # reversed rows: unsorted, the permutation brings the caller's order back
+    n, ii, jj, rij, perm = marshal_edges(mo.Ind[::-1].astype(dtype), mo.RijMat[:, :, ::-1])
+    assert np.array_equal(ii, ii0) and np.array_equal(jj, jj0) and np.array_equal(rij, rij0) and np.array_equal(perm, np.arange(m)[::-1])
+    # the natives themselves, as the header documents them
+    nn, i2, j2, srt = lib.marshal_edges_native(mo.Ind.astype(np.float64))
+    assert (nn, srt) == (n0, True) and np.array_equal(i2, ii0) and np.array_equal(j2, jj0)
+    assert lib.marshal_edges_native(mo.Ind[::-1].astype(np.int64))[3] is False
+    assert lib.marshal_edges_native(np.zeros((0, 2)))[0] == 0
+    pp = np.random.default_rng(1).permutation(m)
+    assert np.array_equal(lib.marshal_rij_native(np.ascontiguousarray(mo.RijMat), pp).reshape(m, 9), rij0.reshape(m, 9)[pp])
+
+
+def test_marshal_edges_rejects_what_the_reference_cannot_index():
+    mo = Uniform_Topology(25, 0.5, 0.2, 0.1, seed=4)
+    Ind = mo.Ind.astype(np.float64)
+    bad_row = 11
+    for spoil, text in ((0.5, "integer"), (np.nan, "integer"), (np.inf, "integer"), (-3.0, "1-based"), (0.0, "1-based")):
+        bad = Ind.copy(); bad[bad_row, 0] = bad[bad_row, 0] + spoil if spoil == 0.5 else spoil
+        with pytest.raises(ValueError, match=text) as ei:
+            marshal_edges(bad, None)
+        assert "row %d" % bad_row in str(ei.value)
+    loop = Ind.copy(); loop[3, 1] = loop[3, 0]
+    with pytest.raises(ValueError, match="1-based"):
+        marshal_edges(loop, None)                                   # i == j
+    with pytest.raises(ValueError, match="integer"):
+        marshal_edges(np.array([["a", "b"]]), None)
+    with pytest.raises(ValueError):
+        marshal_edges(np.vstack([Ind[::-1], Ind[:1]]), None)        # unsorted AND a duplicate
+
+
 def test_params_translation():
     p, G = make_c_params(dict(iters=7, Gradient=ConstantStepSize(0.5), learning_rate=123.0))
     assert (p.iters, p.step_kind, p.lr) == (7, 0, 0.5)          # learning_rate is never read (DESC_PGD.m:169)
