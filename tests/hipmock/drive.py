@@ -73,6 +73,22 @@ def main():
             solve_once(nn, ii, jj, rij, c_params(3, lr=0.01, seed=5), variant, lib.BUILD_HOST)
         dp = lib.DeviceProblem(lib.ProblemArrays(nn, ii, jj, rij)); dp.free()
     print("ok long segments / threads", flush=True)
+    # the marshalling natives on strided views, multithreaded sizes, with and without a permutation; error rows inside a later thread's range
+    from desc_amd.algorithms import marshal_edges
+    big = 700000
+    e = np.arange(big)
+    Ind = np.stack([e // 3 + 1, e // 3 + 2 + e % 3], axis=1)
+    wide = np.zeros((big, 5)); wide[:, 1] = Ind[:, 0]; wide[:, 3] = Ind[:, 1]
+    R = np.random.default_rng(0).standard_normal((3, 3, big))
+    n1, i1, j1, r1, p1 = marshal_edges(wide[:, 1::2], R)
+    n2, i2, j2, r2, p2 = marshal_edges(Ind[::-1].astype(np.int32), R[:, :, ::-1])
+    assert p1 is None and np.array_equal(i1, i2) and np.array_equal(j1, j2) and np.array_equal(r1, r2) and r1[9 * 5 + 1 + 3 * 2] == R[1, 2, 5]
+    bad = wide.copy(); bad[big - 7, 1] = np.nan
+    try:
+        marshal_edges(bad[:, 1::2], None); raise AssertionError("NaN accepted")
+    except ValueError as e:
+        assert "row %d" % (big - 7) in str(e)
+    print("ok marshalling", flush=True)
     # device-resident problem + one-shot solve + the next rows' host sides
     mo, nn, ii, jj, rij = make_problem("uniform", n=90, p=0.5, q=0.2, sigma=0.1, seed=8)
     prob = lib.ProblemArrays(nn, ii, jj, rij)
