@@ -18,6 +18,10 @@
  *     (element (r,c) at rij[9*l + r + 3*c]), i.e. mxGetDoubles(RijMat) unchanged;
  *   - all arithmetic is IEEE double (the reference has no single precision).
  *   - the caller owns every host buffer it passes; the library owns device memory.
+ *   - threads: any entry point may be called from any host thread, and DISTINCT objects (structures, device problems,
+ *     solver handles, one-shot solves) may be in use on distinct threads at the same time -- a MATLAB worker pool or a
+ *     serving process; the block / stream pools are locked, desc_last_error() is per thread.  One object must not be
+ *     used from two threads at once.  (tests/test_gpu_parity.py::test_concurrent_solves_from_several_host_threads)
  */
 #ifndef DESC_AMD_H
 #define DESC_AMD_H

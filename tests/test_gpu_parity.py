@@ -623,3 +623,44 @@ def test_small_graph_sweep_matches_oracle_and_node_kernel(lib, oracle, kind, mon
         assert np.abs(out["S_vec"] - ref["S_vec"]).max() <= tol and np.abs(out["w"] - ref["w"]).max() <= tol
         assert np.allclose(out["obj"], ref["obj"], rtol=1e-12, atol=1e-9)
     assert np.abs(outs["1"]["S_vec"] - outs["0"]["S_vec"]).max() <= 1e-12
+
+
+def test_concurrent_solves_from_several_host_threads(lib, oracle):
+    """Distinct problems solved from distinct host threads at the same time (a serving process): every call owns its handle, streams and
+    blocks; the shared parts of the library (block and stream pools, the upload-order counter, the error text) are per-thread or locked.
+    Each result must be bitwise the result of the same call made alone, for the one-call path and the three-call path."""
+    import threading
+    from desc_amd import DESC_PGD, ConstantStepSize
+    cases = [make_problem("uniform", n=n, p=p, q=0.2, sigma=0.1, seed=sd) for n, p, sd in ((60, 0.5, 1), (110, 0.4, 2), (150, 0.55, 3), (90, 0.6, 4))]
+    par = lambda: dict(iters=40, Gradient=ConstantStepSize(0.01), seed=6, verbose=False)
+    alone = [DESC_PGD(c[0].Ind, c[0].RijMat, par()) for c in cases]
+    st, S0, ref = oracle_reference(oracle, cases[2][1], cases[2][2], cases[2][3], cases[2][4], seed=6, iters=40, lr=0.01)
+    assert np.abs(alone[2] - ref["S_vec"]).max() <= TOL
+    os.environ["DESC_DEBUG_OVERLAP_UPLOAD"] = "2"          # the helper-thread upload of desc_pgd_solve on these small graphs too
+    errors, results = [], {}
+
+    def worker(t):
+        try:
+            for rep in range(6):
+                c = (t + rep) % len(cases)
+                mo = cases[c][0]
+                if (t + rep) % 2:
+                    S = DESC_PGD(mo.Ind, mo.RijMat, par())
+                else:
+                    S, _info = DESC_PGD(mo.Ind, mo.RijMat, par(), return_info=True)
+                results[(t, rep)] = (c, S)
+        except Exception as e:          # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    try:
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    finally:
+        del os.environ["DESC_DEBUG_OVERLAP_UPLOAD"]
+    assert not errors, errors
+    assert len(results) == 24
+    for (t, rep), (c, S) in results.items():
+        assert np.array_equal(S, alone[c]), (t, rep, c)
