@@ -154,6 +154,39 @@ def main():
         for k in ("DESC_DEBUG_VARIANT", "DESC_DEBUG_ROW_CAP", "DESC_SHARD_PARTS"):
             os.environ.pop(k, None)
     print("ok exchange parts / fused protocol", flush=True)
+    # several host threads at once, each with its own problem (tests/test_gpu_parity.py::test_concurrent_solves_from_several_host_threads):
+    # what ThreadSanitizer is here for -- the block / stream pools, the upload-order counter, the per-thread error text
+    import threading
+    probs = []
+    for n, p, seed in ((40, 0.5, 1), (70, 0.4, 2), (90, 0.5, 3)):
+        mo, nn, ii, jj, rij = make_problem("uniform", n=n, p=p, q=0.2, sigma=0.1, seed=seed)
+        probs.append(lib.ProblemArrays(nn, ii, jj, rij))
+    failed = []
+
+    def worker(t):
+        try:
+            for rep in range(3):
+                pr = probs[(t + rep) % len(probs)]
+                pp = c_params(6, seed=1); pp.build_where = lib.BUILD_HOST
+                if (t + rep) % 2:
+                    lib.solve(pr, pp)
+                else:
+                    st_ = lib.Structure.build(pr, 30, 1, lib.BUILD_HOST, 0)
+                    s_ = lib.Solver(pr, st_, 0); s_.run(pp); s_.destroy(); st_.free()
+                try:
+                    lib.Structure.build(lib.ProblemArrays(3, np.array([0, 0], dtype=np.int32), np.array([1, 1], dtype=np.int32)))
+                except lib.DescError as e:
+                    assert "sorted" in str(e) or "edge" in str(e), str(e)          # this thread's own error text
+        except Exception as e:          # noqa: BLE001
+            failed.append((t, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not failed, failed
+    print("ok concurrent host threads", flush=True)
     lib.verify_guards()
     lib.trim_memory()
     assert L.hipmock_live_blocks() == 0, "device blocks leaked"
