@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_cemp_round_tile(const int32_t* rowptr, 
     const int i0 = ib * BI, i1 = min(n, i0 + BI);
     const int j_lo = jb * JB, j_hi = min(n, j_lo + JB);
     if (j_hi <= i0 + 1) return;                    // every j of the block is <= every i of the band: no edge (i, j), i < j
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row_lo = rowptr[i0], row_len = rowptr[i1] - row_lo;
     if (tid < i1 - i0) {                           // the band's edges with j in the block: a contiguous run of row i's slots
         const int i = i0 + tid, r0 = rowptr[i], d = rowptr[i + 1] - r0;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_cemp_round_tile(const int32_t* rowptr, 
         // one sample per lane: CEMP_U edges of the tile per wave and trip, every stage's loads of all of them issued before any is used (each edge is
         // a chain of four dependent memory round trips -- slot -> row start of j and the packed word -> the gather in row j -> ... --: one edge at a
         // time the round measured 1.46 ms at C4, profiles/r04_cemp_tiles.txt)
-        constexpr int CEMP_U = 4;
+        constexpr int CEMP_U = 4;                  // 2 / 4 / 6 / 8 edges in flight: 0.98 / 0.97 / 0.98 / 1.04 ms (profiles/r04_cemp_scalar_setup.txt): the round is issue-bound
         for (int x0 = wv; x0 < total; x0 += 4 * CEMP_U) {
             int rbi[CEMP_U], slot[CEMP_U], ee[CEMP_U], jn[CEMP_U]; bool on[CEMP_U];
 #pragma unroll
@@ -236,15 +236,16 @@ __global__ __launch_bounds__(256) void k_cemp_round_tile(const int32_t* rowptr, 
                 on[u] = x < total;
                 int t = 0, y = on[u] ? x : 0;
                 while (y >= s_cnt[t]) { y -= s_cnt[t]; ++t; }
-                rbi[u] = s_rb[t]; slot[u] = s_a[t] + y;
-                ee[u] = adj_eid[slot[u]]; jn[u] = adj[slot[u]];
+                // everything about the edge is the same in all 64 lanes: scalar registers and scalar loads from here on (round 1.12 -> 0.97 ms at C4)
+                rbi[u] = __builtin_amdgcn_readfirstlane(s_rb[t]); slot[u] = __builtin_amdgcn_readfirstlane(s_a[t] + y);
+                ee[u] = uniform_load(adj_eid, slot[u]); jn[u] = uniform_load(adj, slot[u]);
             }
             int ll[CEMP_U], rbj[CEMP_U]; uint32_t pw[CEMP_U]; double dd[CEMP_U];
 #pragma unroll
             for (int u = 0; u < CEMP_U; ++u) {
-                ll[u] = poe ? poe[ee[u]] : ee[u];
+                ll[u] = poe ? uniform_load(poe, ee[u]) : ee[u];
                 if (ll[u] < 0) on[u] = false;                   // no cycles: SVec stays 1 (:103, :126)
-                rbj[u] = rowptr[jn[u]];
+                rbj[u] = uniform_load(rowptr, jn[u]);
             }
 #pragma unroll
             for (int u = 0; u < CEMP_U; ++u) {
