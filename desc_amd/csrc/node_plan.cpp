@@ -177,6 +177,7 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
     };
     // largest x in [lo, e] with cycles(lo..x) <= room (cum2 increases strictly: a binary search instead of a walk over the segments)
     auto reach = [&](int64_t lo, int64_t e, int64_t room) {
+        if ((int64_t)cum2[e] - cum2[lo] <= room) return e;                   // the whole range fits (most units): no search
         return (int64_t)(std::upper_bound(cum2.begin() + lo, cum2.begin() + e + 1, (int64_t)cum2[lo] + room,
                                           [](int64_t v, int32_t c) { return v < (int64_t)c; }) - cum2.begin()) - 1;
     };
@@ -276,14 +277,27 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
             const int64_t fit_from = mcl - mcl * std::max(0, std::min(500, env_int("DESC_DEBUG_FIT", 0))) / 1000;
             int64_t fit_target = -1;                         // common final load, fixed when the fitting phase starts
             int64_t dealt = 0;
+            // where every band's segments cross the j-block limits: found band by band on all host threads (three dependent random reads per probe),
+            // so that the dealing loop below -- sequential by nature -- only does arithmetic
+            hvec<int64_t> cross((size_t)(nbands * nJ));
+            host_parallel(nbands, [&](int64_t b0, int64_t b1) {
+                for (int64_t bd = b0; bd < b1; ++bd) {
+                    int64_t from = cur[bd];
+                    for (int64_t J = 0; J < nJ; ++J) {
+                        int64_t a0 = from, a1 = bend[bd];
+                        const int64_t jlim = (J + 1) * JB;
+                        while (a0 < a1) { const int64_t mid = (a0 + a1) >> 1; if (j_of(mid) < jlim) a0 = mid + 1; else a1 = mid; }
+                        cross[(size_t)(bd * nJ + J)] = a0;
+                        from = a0;
+                    }
+                }
+            }, 1);
+            lap("j-block crossings");
             for (int64_t J = 0; J < nJ; ++J) {
-                const int64_t jlim = (J + 1) * JB;
                 for (int64_t bd = 0; bd < nbands; ++bd) {
                     int64_t lo = cur[bd]; const int64_t hi = bend[bd];
                     if (lo >= hi) continue;
-                    int64_t a0 = lo, a1 = hi;
-                    while (a0 < a1) { const int64_t mid = (a0 + a1) >> 1; if (j_of(mid) < jlim) a0 = mid + 1; else a1 = mid; }
-                    const int64_t e = a0;
+                    const int64_t e = cross[(size_t)(bd * nJ + J)];
                     cur[bd] = e;
                     while (lo < e) {
                         int64_t x = reach(lo, e, cap);
@@ -296,8 +310,11 @@ void plan_band_pieces(const desc_problem* prob, const desc_structure* s, const N
                             lo = x;
                             continue;
                         }
+                        // least-loaded workgroup, lowest index on ties: the minimum first (a plain reduction the compiler vectorises), then its first holder
+                        int64_t lmin = load[0];
+                        for (int w = 1; w < G; ++w) lmin = std::min(lmin, load[w]);
                         int wmin = 0;
-                        for (int w = 1; w < G; ++w) if (load[w] < load[wmin]) wmin = w;
+                        while (load[wmin] != lmin) ++wmin;
                         const int wl = last_wg[bd];
                         const bool merge = wl >= 0 && load[wl] <= load[wmin] + aff_slack && !per_wg[wl].empty() && per_wg[wl].back().seg_hi == (int32_t)lo &&
                                            per_wg[wl].back().row_lo == P.rowptr[P.band_lo[bd]];

@@ -174,13 +174,19 @@ __global__ __launch_bounds__(256) void k_fill_cycles(const int32_t* pos_edge, co
             run += __shfl(incl, 63, 64);
             while (x) {
                 const int k = w * 64 + __ffsll((long long)x) - 1;
-                if (pos < lds_cap) { ks[pos] = k; keys[pos] = d_sample_key(seed, (uint64_t)e, (uint64_t)k); }
+                if (pos < lds_cap) ks[pos] = k;
                 ++pos;
                 x &= x - 1;
             }
         }
         const int cd = run;                           // codegree
         __builtin_amdgcn_wave_barrier();
+        // the keys in a pass of their own over the compact list: every lane busy (in the loop above a lane holds 0 ... 6 neighbours and the wave
+        // waits for the fullest one -- the 64-bit mixing is most of this kernel's instructions)
+        if (cd >= n_sample) {
+            for (int t = lane; t < min(cd, lds_cap); t += 64) keys[t] = d_sample_key(seed, (uint64_t)e, (uint64_t)ks[t]);
+            __builtin_amdgcn_wave_barrier();
+        }
         if (cd < n_sample) {                          // DESC_PGD.m:83 samples iff codeg >= n_sample
             for (int t = lane; t < cd; t += 64) kk[base + t] = ks[t];
             if (lane == 0) { tau[e] = ~0ull; ktau[e] = 0x7FFFFFFF; }
