@@ -748,7 +748,7 @@ __global__ __launch_bounds__(256) void k_sweep_small(NodeSweepArgs a, int n_seg)
 // streams and the weight stores 1084-1091 (-7.2 %); C5 1737 -> 1670-1682, C3 105.0 -> 100.4, C2 110.8 -> 107.8.  Cache-policy bits on the
 // gathers (same file): nt 1873 us, sc1 / sc0 sc1 1253 us -- no.  Offsets are 32 bits: the descriptors of the per-cycle arrays are rebuilt per
 // piece with the piece's first cycle as base (any m_cycle), the CSR-aligned arrays (2m doubles) must stay below 4 GiB (setup_node: else no band sweep).
-// Out-of-range offsets read 0 and store nothing (num_records) instead of faulting.  DESC_BUF=0 builds the round-2 forms (A/B).
+// Out-of-range offsets read 0 and store nothing (num_records) instead of faulting.  (The round-2 global-load forms are in the history, tree ca0abdf.)
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 template <class T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const T* p, uint32_t bytes = 0xFFFFFFFFu) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);          // raw buffer (stride 0), 32-bit data format
