@@ -183,8 +183,16 @@ __global__ __launch_bounds__(256) void k_fill_cycles(const int32_t* pos_edge, co
         __builtin_amdgcn_wave_barrier();
         // the keys in a pass of their own over the compact list: every lane busy (in the loop above a lane holds 0 ... 6 neighbours and the wave
         // waits for the fullest one -- the 64-bit mixing is most of this kernel's instructions)
+        unsigned long long kr[4] = {~0ull, ~0ull, ~0ull, ~0ull};      // this lane's keys of the first 256 neighbours: the probes below count them in registers
+        bool kon[4] = {false, false, false, false};
         if (cd >= n_sample) {
-            for (int t = lane; t < min(cd, lds_cap); t += 64) keys[t] = d_sample_key(seed, (uint64_t)e, (uint64_t)ks[t]);
+            const int cdl = min(cd, lds_cap);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = lane + 64 * u;
+                if (t < cdl) { kr[u] = d_sample_key(seed, (uint64_t)e, (uint64_t)ks[t]); keys[t] = kr[u]; kon[u] = true; }
+            }
+            for (int t = lane + 256; t < cdl; t += 64) keys[t] = d_sample_key(seed, (uint64_t)e, (uint64_t)ks[t]);
             __builtin_amdgcn_wave_barrier();
         }
         if (cd < n_sample) {                          // DESC_PGD.m:83 samples iff codeg >= n_sample
@@ -194,17 +202,30 @@ __global__ __launch_bounds__(256) void k_fill_cycles(const int32_t* pos_edge, co
             // Keep the n_sample smallest keys.  A separator g with exactly n_sample keys <= g is found
             // by bisection on the key VALUE (keys are uniform 64-bit hashes: the first probe is the
             // expected quantile, ~log2(cd) probes follow; one probe = one ballot pass over the keys).
+            // Round 4: the next probe is interpolated between the bracket's ends from their counts (the keys are uniform: 2-4 probes instead of the
+            // ~10 of plain halving, whose second probe already sat half-way to the far end of the key range); every third probe halves, so the
+            // bracket shrinks geometrically whatever the keys look like.  Any separator with exactly n_sample keys <= g selects the same set.
             unsigned long long lo = 0, hi = ~0ull, g = ~0ull;
+            int c_lo = 0, c_hi = cd;                             // keys <= lo (none known below the first probe), keys <= hi
             bool have_lo = false, found = (cd == n_sample) && !exact_only;
-            if (!found) g = (unsigned long long)((double)n_sample / (double)cd * 18446744073709549568.0);
+            if (!found) g = (unsigned long long)(((double)n_sample + 0.5) / (double)cd * 18446744073709549568.0);
             for (int it = 0; !found && !exact_only && it < 96; ++it) {
                 int c = 0;
-                for (int t0 = 0; t0 < cd; t0 += 64) { const int t = t0 + lane; c += __popcll(__ballot(t < cd && keys[t] <= g)); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) c += __popcll(__ballot(kon[u] && kr[u] <= g));
+                for (int t0 = 256; t0 < cd; t0 += 64) { const int t = t0 + lane; c += __popcll(__ballot(t < cd && keys[t] <= g)); }
                 if (c == n_sample) { found = true; break; }
-                if (c < n_sample) { lo = g; have_lo = true; } else hi = g;
+                if (c < n_sample) { lo = g; c_lo = c; have_lo = true; } else { hi = g; c_hi = c; }
                 const unsigned long long b = have_lo ? lo : 0ull;
-                if (hi - b <= 1ull) break;                       // no value left in between: duplicate keys straddle the cut
-                g = b + (hi - b) / 2ull;
+                const unsigned long long span = hi - b;
+                if (span <= 1ull) break;                         // no value left in between: duplicate keys straddle the cut
+                unsigned long long step = span / 2ull;
+                if (it % 3 != 2) {
+                    const double frac = ((double)(n_sample - c_lo) + 0.5) / (double)(c_hi - c_lo + 1);
+                    step = (unsigned long long)((double)span * frac);
+                    step = step < 1ull ? 1ull : (step > span - 1ull ? span - 1ull : step);
+                }
+                g = b + step;
             }
             if (found) {
                 int outbase = 0;
