@@ -549,9 +549,8 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
     const int64_t mc = s->m_cycle;
     s->k.clear(); s->e_jk.clear(); s->e_ki.clear(); s->ikj.clear(); s->jki.clear();
     s->host_cycles = (mp == 0);                       // per-cycle arrays stay in HBM until somebody asks for them
-    s->codeg.assign((size_t)m, 0);
-    s->pos_edge.resize((size_t)mp);
-    s->cum_ind.assign((size_t)mp + 1, 0);
+    // (the host's copies of the per-edge tables are sized AFTER the kernels below are on their way: 40 MB of first touches at C4, ~2 ms the device would idle through)
+    if (mp == 0) { s->codeg.assign((size_t)m, 0); s->pos_edge.clear(); s->cum_ind.assign(1, 0); }
     if (mp > 0) {
         // Round 4: the compaction of the edges with cycles and the prefix sums of their cycle counts (DESC_PGD.m:36-37, 45-54) are a tiled device
         // scan + scatter (three launches) on a stream of their own, the cycle-sampling kernel follows on the same stream at once, and the
@@ -598,6 +597,9 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
         s->ev_fill = (void*)ev;
         DESC_HIP(hipEventRecord(ev, fs));
         // the host's copies of the per-edge tables, under the sampling kernel (the copies wait for the compaction only)
+        s->codeg.resize((size_t)m);
+        s->pos_edge.resize((size_t)mp);
+        s->cum_ind.resize((size_t)mp + 1);
         {
             const hipError_t ew = hipEventSynchronize(ev_c);
             (void)hipEventDestroy(ev_c);
