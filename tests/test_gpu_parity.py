@@ -625,6 +625,25 @@ def test_small_graph_sweep_matches_oracle_and_node_kernel(lib, oracle, kind, mon
     assert np.abs(outs["1"]["S_vec"] - outs["0"]["S_vec"]).max() <= 1e-12
 
 
+@pytest.mark.parametrize("n,p,group", [(60, 0.25, 16), (200, 0.5, 32), (260, 0.75, 64)])
+def test_small_graph_sweep_lane_groups(lib, oracle, n, p, group):
+    """The three lane-group widths of k_sweep_small (the smallest power of two >= the longest segment: unsampled sparse graph, the reference's
+    demo size, a dense graph whose median codegree lifts n_sample above 32), default kernel choice, against the oracle; early stop included (lr = 1)."""
+    mo, nn, ii, jj, rij = make_problem("uniform", n=n, p=p, q=0.2, sigma=0.1, seed=n)
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    for lr, iters in ((0.01, 30), (1.0, 80)):
+        st, S0, ref = oracle_reference(oracle, nn, ii, jj, rij, seed=1, iters=iters, lr=lr)
+        dst = lib.Structure.build(prob, 30, 1, lib.BUILD_DEVICE, 0)
+        solver = lib.Solver(prob, dst, 0)
+        dst.free()
+        assert solver.kernel_name().startswith("k_sweep_small<%d," % group), solver.kernel_name()
+        out = solver.run(c_params(iters, lr=lr, seed=1), want_w=True)
+        solver.destroy()
+        assert out["iters_run"] == ref["iters_run"]
+        bound = TOL if lr < 1 else 1e-9
+        assert np.abs(out["S_vec"] - ref["S_vec"]).max() <= bound and np.abs(out["w"] - ref["w"]).max() <= bound
+
+
 def test_concurrent_solves_from_several_host_threads(lib, oracle):
     """Distinct problems solved from distinct host threads at the same time (a serving process): every call owns its handle, streams and
     blocks; the shared parts of the library (block and stream pools, the upload-order counter, the error text) are per-thread or locked.
