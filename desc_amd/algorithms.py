@@ -22,6 +22,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -131,7 +133,7 @@ def DESC_PGD(Ind, RijMat, params, return_info=False, _marshalled=None):
     Returns the estimated corruption level of every edge (length-m vector in the
     caller's edge order).  With ``return_info`` also a dict with the objective and
     average-change traces, iteration count, timings and structure sizes.
-    ``_marshalled`` (internal, used by DESC()): (perm, ProblemArrays, DeviceProblem) already prepared."""
+    ``_marshalled`` (internal, used by DESC()): (perm, ProblemArrays, DeviceProblem or a callable that returns it) already prepared."""
     p, G = make_c_params(params)
     make_plots = bool(_get(params, "make_plots", False))
     if make_plots and (_get(params, "ErrVec") is None or _get(params, "R_orig") is None):
@@ -179,6 +181,8 @@ def DESC_PGD(Ind, RijMat, params, return_info=False, _marshalled=None):
     try:
         sizes = st.sizes()                    # O(1): the structure stays on the device
         ms_structure = sizes.pop("ms_build")
+        if callable(dprob):
+            dprob = dprob()                       # DESC(): the device problem has been going up on a helper thread meanwhile
         solver = _lib.Solver(dprob, st, p.device)
     finally:
         st.free()
@@ -317,9 +321,32 @@ def DESC(Ind, RijMat, params, return_info=False):
         raise ValueError("empty edge list")
     prob = _lib.ProblemArrays(n, ii, jj, rij)
     device = int(_get(params, "device", 0))
-    dprob = _lib.DeviceProblem(prob, device)          # Ind / RijMat / CSR index go to HBM once for all three stages
+    # Ind / RijMat / CSR index go to HBM once for all three stages -- on a helper thread, while DESC_PGD builds the cycle structure (which needs
+    # only the edge list): DESC_PGD asks for the device problem when it creates the solver
+    import threading
+    box = {}
+
+    def _upload():
+        try:
+            box["dp"] = _lib.DeviceProblem(prob, device)
+        except BaseException as e:      # noqa: BLE001  (re-raised on the calling thread)
+            box["err"] = e
+
+    th = threading.Thread(target=_upload)
+    th.start()
+    if os.environ.get("DESC_DEBUG_SERIAL_UPLOAD") == "1":       # A/B: the upload first, then the structure (as before round 4)
+        th.join()
+
+    def _dprob():
+        th.join()
+        if "err" in box:
+            raise box["err"]
+        return box["dp"]
+
+    dprob = None
     try:
-        S_vec, info = DESC_PGD(Ind, RijMat, params, return_info=True, _marshalled=(perm, prob, dprob))
+        S_vec, info = DESC_PGD(Ind, RijMat, params, return_info=True, _marshalled=(perm, prob, _dprob))
+        dprob = _dprob()
         S_sorted = S_vec if perm is None else S_vec[perm]
         R_init, ginfo = _lib.gcw_run(dprob, S_sorted)                    # GCW.m:9-36, weights (GCW.m:20) formed on the device
         verbose = bool(_get(params, "verbose", True))
@@ -329,7 +356,9 @@ def DESC(Ind, RijMat, params, return_info=False):
         if verbose:
             print("DONE!")                                                                    # DESC.m:313
     finally:
-        dprob.free()
+        th.join()
+        if "dp" in box:
+            box["dp"].free()
     if return_info:
         return R_est, R_init, S_vec, dict(pgd=info, gcw=ginfo, refine=rinfo)
     return R_est, R_init, S_vec

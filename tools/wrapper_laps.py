@@ -3,7 +3,7 @@ import argparse, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from bench import generate                            # noqa: E402
-from desc_amd import DESC_PGD, ConstantStepSize, _lib    # noqa: E402
+from desc_amd import DESC, DESC_PGD, ConstantStepSize, _lib    # noqa: E402
 from desc_amd.algorithms import marshal_edges            # noqa: E402
 
 ap = argparse.ArgumentParser(); ap.add_argument("--workload", default="C4"); ap.add_argument("--laps", type=int, default=4)
@@ -24,3 +24,7 @@ for lap in range(2):
     t0 = time.perf_counter(); S2 = DESC_PGD(mo.Ind, Rc, dict(iters=100, Gradient=ConstantStepSize(0.01), verbose=False)); t1 = time.perf_counter()
     assert np.array_equal(S2, S)
     print("C-ordered RijMat (NumPy's own order): DESC_PGD() %.1f ms" % ((t1 - t0) * 1e3), flush=True)
+for lap in range(4):
+    t0 = time.perf_counter(); Re, Ri, Sv = DESC(mo.Ind, mo.RijMat, dict(iters=100, Gradient=ConstantStepSize(0.01), verbose=False)); t1 = time.perf_counter()
+    assert np.array_equal(Sv, S)
+    print("DESC() = DESC_PGD -> GCW -> refinement on one device-resident problem: %.1f ms" % ((t1 - t0) * 1e3), flush=True)
