@@ -57,6 +57,7 @@ struct desc_structure {
     void* fill_stream = nullptr;              // hipStream_t (pooled, non-blocking) the compaction and cycle-sampling kernels of the device builder run on
     hvec<void*> d_build_blocks;               // scratch of those kernels: lives until structure_free_device (freeing a block waits for the device, i.e. for the fill)
     int32_t *d_k = nullptr;
+    int32_t* d_codeg = nullptr;               // m, one of d_build_blocks: the host's copy (desc_structure_get) is made on demand, structure_ensure_host
     unsigned long long* d_tau = nullptr;      // m, indexed by edge id (defined for edges with cycles)
     int32_t* d_ktau = nullptr;                // m
     int32_t *d_rowptr = nullptr, *d_adj = nullptr, *d_adj_eid = nullptr;   // n+1, 2m, 2m

@@ -597,7 +597,7 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
         s->ev_fill = (void*)ev;
         DESC_HIP(hipEventRecord(ev, fs));
         // the host's copies of the per-edge tables, under the sampling kernel (the copies wait for the compaction only)
-        s->codeg.resize((size_t)m);
+        s->d_codeg = d_codeg;                           // the codegrees go to the host only if somebody asks for them (structure_ensure_host)
         s->pos_edge.resize((size_t)mp);
         s->cum_ind.resize((size_t)mp + 1);
         {
@@ -607,7 +607,6 @@ int build_structure_device(const desc_problem* prob, int32_t n_sample_min, uint6
         }
         DESC_HIP(hipMemcpy(s->pos_edge.data(), s->d_pos, sizeof(int32_t) * mp, hipMemcpyDeviceToHost));
         DESC_HIP(hipMemcpy(s->cum_ind.data(), d_cumc, sizeof(int64_t) * (mp + 1), hipMemcpyDeviceToHost));
-        DESC_HIP(hipMemcpy(s->codeg.data(), d_codeg, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
         if (s->cum_ind[mp] != mc) return fail(DESC_ERR_STATE, "cycle prefix sums (%lld) disagree with the codegree histogram (%lld)", (long long)s->cum_ind[mp], (long long)mc);
         lap("tables to host", false);
         // the builder's own scratch (codegrees, histogram, degree tables) is still being read by the kernels in flight: the structure keeps it
@@ -703,6 +702,10 @@ int structure_ensure_host(desc_structure* s) {
     if (s->ev_fill) {       // the sampled cycles come from a kernel on the builder's own stream: wait for it, and report ITS failure as such
         const hipError_t ef = hipEventSynchronize((hipEvent_t)s->ev_fill);
         if (ef != hipSuccess) return fail(DESC_ERR_HIP, "cycle sampling kernel failed: %s", hipGetErrorString(ef));
+    }
+    if (s->d_codeg && (int64_t)s->codeg.size() != s->m) {
+        s->codeg.resize((size_t)s->m);
+        DESC_HIP(hipMemcpy(s->codeg.data(), s->d_codeg, sizeof(int32_t) * s->m, hipMemcpyDeviceToHost));
     }
     DevBuf D;
     int rc;
