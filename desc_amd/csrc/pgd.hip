@@ -1521,12 +1521,28 @@ __global__ __launch_bounds__(256) void k_permute_segments(const int32_t* order, 
                                                           int64_t m_pos) {
     const int lane = threadIdx.x & 63;
     const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
-    for (int64_t q = wid; q < m_pos; q += nw) {
-        const int32_t l = order[q];
-        const int64_t src = nat_cum[l], dst = cum[q];
-        const int cnt = cum[q + 1] - cum[q];
-        for (int t = lane; t < cnt; t += 64) { pk[dst + t] = pk_nat[src + t]; S0[dst + t] = S0_nat[src + t]; seg_perm[dst + t] = perm_nat[src + t]; }
-        if (lane == 0) counts[q] = counts_nat[l];
+    // PU segments in flight per wave: a segment alone is a chain of three dependent round trips (order -> starts -> data) for ~1 KB moved
+    constexpr int PU = 4;
+    for (int64_t q0 = wid * PU; q0 < m_pos; q0 += nw * PU) {
+        int32_t l[PU]; int64_t src[PU], dst[PU]; int cnt[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) l[u] = order[min(q0 + u, m_pos - 1)];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int64_t q = min(q0 + u, m_pos - 1);
+            src[u] = nat_cum[l[u]]; dst[u] = cum[q];
+            cnt[u] = q0 + u < m_pos ? cum[q + 1] - cum[q] : 0;
+        }
+        uint32_t a[PU]; double b[PU]; uint8_t c[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u)
+            if (lane < cnt[u]) { a[u] = pk_nat[src[u] + lane]; b[u] = S0_nat[src[u] + lane]; c[u] = perm_nat[src[u] + lane]; }
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            if (lane < cnt[u]) { pk[dst[u] + lane] = a[u]; S0[dst[u] + lane] = b[u]; seg_perm[dst[u] + lane] = c[u]; }
+            for (int t = lane + 64; t < cnt[u]; t += 64) { pk[dst[u] + t] = pk_nat[src[u] + t]; S0[dst[u] + t] = S0_nat[src[u] + t]; seg_perm[dst[u] + t] = perm_nat[src[u] + t]; }
+            if (lane == 0 && q0 + u < m_pos) counts[q0 + u] = counts_nat[l[u]];
+        }
     }
 }
 // per-edge slots of the CSR-aligned arrays, on the device (device-built structures): eslot[e] = this
