@@ -242,3 +242,30 @@ def test_full_size_oracle_parity(lib, oracle, name, iters):
     assert mean_S <= 1e-6                                       # the north star's acceptance figure, far looser than the bound above
     assert np.allclose(out["obj"], ref["obj"], rtol=1e-12, atol=0)
     assert np.allclose(out["avg"], ref["avg"], rtol=1e-9, atol=1e-15)
+
+
+def test_device_builder_budget_falls_back_to_the_host_builder(lib):
+    """A graph whose codegrees exceed what the device builder stages per edge (1024 common neighbours: n = 1100, p = 0.99): desc_structure_build
+    answers DESC_ERR_TOO_LARGE for DESC_BUILD_DEVICE, and every caller of the path -- desc_pgd_solve (the one-call DESC_PGD()), the three-call
+    wrapper, the explicit host build -- ends up on the host builder with the same result.  Segments of ~270 cycles: the gather layout's long-segment sweep."""
+    from desc_amd import DESC_PGD, ConstantStepSize
+    from desc_amd.algorithms import marshal_edges
+    from desc_amd.models import Uniform_Topology
+    mo = Uniform_Topology(1100, 0.99, 0.2, 0.1, "uniform", seed=11)
+    nn, ii, jj, rij, _ = marshal_edges(mo.Ind, mo.RijMat)
+    prob = lib.ProblemArrays(nn, ii, jj, rij)
+    with pytest.raises(lib.DescError) as ei:
+        lib.Structure.build(prob, 30, 2, lib.BUILD_DEVICE, 0)
+    assert ei.value.code == lib.ERR_TOO_LARGE
+    st = lib.Structure.build(prob, 30, 2, lib.BUILD_HOST, 0)
+    sz = st.sizes()
+    assert sz["max_cnt"] > 256 and sz["m_cycle"] > 100_000_000
+    solver = lib.Solver(prob, st, 0)
+    st.free()
+    ref = solver.run(c_params(3, lr=0.01, seed=2))
+    solver.destroy()
+    par = lambda: dict(iters=3, Gradient=ConstantStepSize(0.01), seed=2, verbose=False)
+    S_one = DESC_PGD(mo.Ind, mo.RijMat, par())                         # desc_pgd_solve: device builder refused inside the call
+    S_three, info = DESC_PGD(mo.Ind, mo.RijMat, par(), return_info=True)
+    assert np.array_equal(S_one, ref["S_vec"]) and np.array_equal(S_three, ref["S_vec"]) and info["iters_run"] == 3
+    assert ((ref["S_vec"] >= 0) & (ref["S_vec"] <= 1)).all() and np.mean(np.abs(ref["S_vec"] - mo.ErrVec)) < 0.2
