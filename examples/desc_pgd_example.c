@@ -20,14 +20,19 @@ static void rotz(double a, double* R) {          /* column-major 3x3, like RijMa
 int main(void) {
     enum { N = 8, M = N * (N - 1) / 2 };
     static int32_t ii[M], jj[M];
+    static double ind[2 * M];                   /* Ind as MATLAB holds it: M x 2 doubles, column-major, 1-based, sorted by (i, j) (DESC_PGD.m:5) */
     static double rij[9 * M], s_vec[M], obj[100], avg[100];
     int e = 0, bad = 5;
-    for (int i = 0; i < N; ++i)                 /* Ind sorted by (i, j), 0-based (DESC_PGD.m:5) */
+    for (int i = 0; i < N; ++i)
         for (int j = i + 1; j < N; ++j, ++e) {
-            ii[e] = i; jj[e] = j;
+            ind[e] = i + 1; ind[M + e] = j + 1;
             rotz(0.3 * i - 0.3 * j + (e == bad ? 1.0 : 0.0), rij + 9 * e);       /* R_i R_j' = rotz(a_i - a_j) */
         }
-    desc_problem prob = {N, M, ii, jj, rij};
+    int64_t n = 0; int32_t sorted = 0;          /* -> 0-based int32 endpoints, n = max(Ind(:)), checked; column-major M x 2: strides (1, M) */
+    if (desc_marshal_edges(ind, DESC_DTYPE_F64, M, 1, M, ii, jj, &n, &sorted) != DESC_OK || !sorted || n != N) {
+        fprintf(stderr, "desc_marshal_edges: %s\n", desc_last_error()); return 1;
+    }
+    desc_problem prob = {n, M, ii, jj, rij};
     desc_params p;
     desc_params_default(&p);                    /* iters 100, ConstantStepSize(0.01), patience 30 */
     desc_result r = {0};
