@@ -88,7 +88,9 @@ while time.time() < t_end:
             yard = max(float(np.abs(ref["S_vec"] - ld["S_vec"]).max()), float(np.abs(ref["w"] - ld["w"]).max()))
             eh = max(float(np.abs(out["S_vec"] - ld["S_vec"]).max()), float(np.abs(out["w"] - ld["w"]).max()))
             print("yardstick", tag, "hip-vs-oracle %.3g, oracle-vs-long-double %.3g, hip-vs-long-double %.3g" % (max(e1, e2), yard, eh), flush=True)
-            assert eh <= 4 * yard and yard <= 1e-9, "values %g %g beyond 4x the round-off yardstick %g" % (e1, e2, yard)
+            # (the cap on the yardstick itself was 1e-9 until a case with 256-cycle segments showed the double oracle 2.9e-9 from the long-double
+            #  run after 40 sweeps at lr = 1, HIP 9.8e-10 from the oracle: tests/test_gpu_parity.py::test_fuzz_case_621930630_is_roundoff)
+            assert eh <= 4 * yard and yard <= 1e-8, "values %g %g beyond 4x the round-off yardstick %g" % (e1, e2, yard)
             e1 = e2 = 0.0
         if sk == 2:
             if max(e1, e2) > worst_adam: worst_adam, worst_adam_tag = max(e1, e2), tag
